@@ -1,0 +1,154 @@
+"""Headline benchmark: alpha-vector backups / second at |S|=30000, |B|=1024 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+
+A step is ONE point-based backup (``pbvi_backup_run``: Gamma projection, score GEMM, argmax +
+fp64 tie refinement, action selection, alpha' assembly) of the resident belief block
+against the resident alpha set -- inputs are in HBM when the timed region starts, results
+stay in HBM.  With N>1 the beliefs are sharded (1024 per GPU, weak scaling) and each step
+ends with the RCCL all-gather of the new alpha rows.  Workload: the synthetic olfactory
+model of SURVEY.md 8d (BASELINE config "reachable-sparse", R=1 as in every large model of
+the reference).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(m, alpha, beliefs, sample: int):
+    """The oracle (NumPy restatement of src/pomdp.py:1485-1506, fp64) timed on this host's cores
+    on a bounded sample of the same workload: the first ``sample`` beliefs, the full alpha set."""
+    from oracle import pbvi_oracle as orc            # cpu_baseline leg only
+    b = beliefs[:sample]
+    t0 = time.perf_counter()
+    orc.backup_core(alpha, b, m.reachable_states, m.rto, m.expected_rewards, m.gamma)
+    dt = time.perf_counter() - t0
+    return {'value': sample / dt, 'unit': 'backups/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'first {sample} of the {beliefs.shape[0]} beliefs x all {alpha.shape[0]} alpha-vectors, '
+                      f'untiled NumPy fp64 statements, 1 call, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--beliefs', type=int, default=1024, help='beliefs per GPU')
+    ap.add_argument('--alphas', type=int, default=1024)
+    ap.add_argument('--reach', type=int, default=1, choices=[1, 5], help='reachable states per (s,a)')
+    ap.add_argument('--cpu-sample', type=int, default=128, help='beliefs in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--grid', type=str, default='75x400')
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N')
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from pomdp_pbvi_exploration_amd import synth
+    from pomdp_pbvi_exploration_amd.engine import Engine
+    from pomdp_pbvi_exploration_amd.dist import EngineShard, ShardedBackup
+
+    H, W = (int(x) for x in args.grid.split('x'))
+    m = synth.olfactory_model(H=H, W=W, R=args.reach)
+    alpha, _ = synth.alpha_set(m, args.alphas)
+    B = args.beliefs
+    beliefs = synth.belief_points(m, B, start=rank * B)            # this rank's block of the global set
+
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32', device=local_rank)
+    eng.set_alpha(alpha)
+    eng.set_beliefs(beliefs)
+    shard = EngineShard(eng, m.gamma)
+    sharder = ShardedBackup() if distributed else None
+
+    def step():
+        if distributed:
+            rows, acts, keep, st = shard.run_resident()
+            sharder.gather_rows(rows, acts, keep, B * world)
+            return st
+        return eng.run(m.gamma)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # PCIe-inclusive variant (host beliefs in, host alpha' out) -- reported beside, never as `value`
+    host_ms = None
+    if not distributed:
+        t1 = time.perf_counter()
+        for _ in range(3):
+            eng.set_beliefs(beliefs)
+            eng.run(m.gamma)
+            eng.fetch()
+        host_ms = (time.perf_counter() - t1) / 3 * 1e3
+
+    if rank == 0:
+        K = args.steps
+        ms_step = elapsed / K * 1e3
+        ms_score = float(np.mean([s['ms_score'] for s in stats]))
+        flops = stats[0]['score_flops']
+        achieved = flops / (ms_score * 1e-3) / 1e12
+        out = {
+            'metric': 'alpha-vector backups/sec', 'value': B * world * K / elapsed, 'unit': 'backups/s',
+            'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'olfactory-{m.S} reachable-sparse R={m.R} backup (S={m.S}, A={m.A}, O={m.O}), '
+                                   f'V={args.alphas} alpha-vectors, B={B} beliefs per GPU',
+                       'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': args.alphas, 'B_per_gpu': B,
+                       'parallelism': f'belief-sharded x{world}, 1 all-gather of alpha rows' if distributed else 'single GPU'},
+            'roofline': {'bound': 'mfma', 'kernel': 'k_gemm_nt_f32_mfma (belief x Gamma score GEMM)',
+                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'flops_per_launch': flops, 'ms_per_launch': ms_score},
+            'stage_ms': {k: float(np.mean([s[k] for s in stats])) for k in
+                         ('ms_total', 'ms_project', 'ms_score', 'ms_argmax', 'ms_refine', 'ms_action', 'ms_assemble')},
+            'refined_pairs': int(stats[-1]['n_refined']), 'dead_pairs': int(stats[-1]['n_dead']),
+            'pairs': int(stats[-1]['n_pairs']), 'split_k': int(stats[-1]['split_k']),
+        }
+        if host_ms is not None:
+            out['pcie_inclusive'] = {'ms_per_step': host_ms, 'value': B / (host_ms * 1e-3), 'unit': 'backups/s'}
+        if world == 1 and args.cpu_sample > 0:
+            out['cpu_baseline'] = cpu_baseline(m, alpha, beliefs, min(args.cpu_sample, B))
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,165 @@
+/*
+ * pbvi_hip.h -- C-ABI of the MI355X (gfx950) PBVI alpha-vector backup engine.
+ *
+ * Drop-in boundary for ONE path of PimLb/POMDP_PBVI_Exploration: one call of
+ * PBVI_Solver.backup (reference src/pomdp.py:1447-1524) plus the two kernels its
+ * callers run on the same operands (ValueFunction.prune level 2, src/mdp.py:857-866;
+ * compute_change's max_v b.alpha_v, src/pomdp.py:2165).  The reference has no FFI:
+ * its GPU seam is CuPy array-module dispatch (`xp = cp.get_array_module(...)`,
+ * src/pomdp.py:1482) over objects moved by Model.gpu_model (src/mdp.py:533-560),
+ * ValueFunction.to_gpu (src/mdp.py:782-805) and BeliefSet.to_gpu
+ * (src/pomdp.py:613-634).  Each entry point below names the reference statement(s)
+ * it replaces.  Plain C types only; every array is C-order exactly as NumPy lays
+ * the reference's arrays out.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - `dtype` selects the element type T of every `const void*` / `void*` array:
+ *     PBVI_F32 -> float, PBVI_F64 -> double.  Indices are int32 (the binding narrows
+ *     NumPy int64 after a range check).
+ *   - Return value: 0 on success, negative pbvi_status otherwise; the message is
+ *     available from pbvi_last_error() (thread-local).  The library never aborts.
+ *   - Host pointers are owned by the caller and only read/written during the call.
+ *     Device memory is owned by the handle.  A handle is not thread-safe.
+ *   - Every call is synchronous: results are in the output buffers on return.
+ */
+#ifndef PBVI_HIP_H
+#define PBVI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pbvi_engine pbvi_engine_t;
+
+enum pbvi_status {
+    PBVI_OK = 0,
+    PBVI_EINVAL = -1,        /* bad argument (the reference asserts; binding raises ValueError) */
+    PBVI_ENOMEM = -2,        /* host or hipMalloc OOM (binding raises MemoryError, which
+                                PBVI_Solver.solve catches: src/pomdp.py:2399-2401) */
+    PBVI_ERUNTIME = -3,      /* HIP runtime error */
+    PBVI_EUNSUPPORTED = -4   /* configuration not supported by this build */
+};
+
+enum pbvi_dtype { PBVI_F32 = 0, PBVI_F64 = 1 };
+
+/* Transition representation used for the Gamma projection (src/pomdp.py:1485-1491). */
+enum pbvi_mode {
+    PBVI_SPARSE = 0,   /* reachable-state padded-ELL SpMM (what the reference always does) */
+    PBVI_DENSE = 1     /* densify T[A][S][S] on device and run the projection as |A| MFMA GEMMs */
+};
+
+enum pbvi_flags {
+    PBVI_BELIEF_DOMINANCE = 1   /* backup(..., belief_dominance_prune=True), src/pomdp.py:1509-1515 */
+};
+
+/* Per-call instrumentation (kernel times from HIP events on the engine's stream). */
+typedef struct pbvi_stats {
+    double ms_total;        /* whole device-side backup, first kernel to last */
+    double ms_project;      /* Gamma projection (K1) */
+    double ms_score;        /* belief x Gamma score GEMM (K2) */
+    double ms_argmax;       /* argmax over alpha-vectors + near-tie detection */
+    double ms_refine;       /* fp64 refinement of near-ties (f32 engines) */
+    double ms_action;       /* action values + argmax (K4) */
+    double ms_assemble;     /* alpha' gather-sum (K3) */
+    double ms_dominance;    /* belief-dominance test (K5), 0 if not requested */
+    int64_t n_pairs;        /* B*A*O (belief, action, observation) triples */
+    int64_t n_dead;         /* triples with P(o|b,a) == 0 (all scores exactly 0) */
+    int64_t n_refined;      /* triples whose argmax was re-decided in fp64 */
+    int64_t n_refined_actions; /* beliefs whose action argmax was re-decided in fp64 */
+    int64_t score_flops;    /* 2*B*S*A*O*V of the score GEMM */
+    int32_t split_k;        /* K-split used by the score GEMM */
+    int32_t reserved;
+} pbvi_stats_t;
+
+/* Library / device queries. */
+int pbvi_version(void);
+int pbvi_device_count(void);                 /* hipGetDeviceCount; 0 if no GPU */
+const char* pbvi_last_error(void);
+
+/*
+ * Create an engine for one POMDP model on one device.  Replaces Model.gpu_model
+ * (src/mdp.py:533-560): uploads and re-tiles the three tables the backup reads.
+ *   reach_states [S][A][R] int32  = model.reachable_states            (src/mdp.py:194-201,296-335)
+ *   rto          [S][A][O][R] T   = model.reachable_transitional_observation_table (src/pomdp.py:201-202)
+ *   exp_reward   [S][A] T         = model.expected_rewards_table      (src/pomdp.py:251)
+ */
+int pbvi_engine_create(pbvi_engine_t** out, int device, int32_t S, int32_t A, int32_t O, int32_t R,
+                       const int32_t* reach_states, const void* rto, const void* exp_reward,
+                       int dtype, int mode);
+void pbvi_engine_destroy(pbvi_engine_t* e);
+
+/*
+ * Device-resident alpha-vector set.  Replaces ValueFunction.to_gpu (src/mdp.py:782-805)
+ * and the per-call re-stack of ValueFunction.alpha_vector_array (src/mdp.py:687-697).
+ *   alpha [V][S] T, row-major.  set replaces the whole set; append adds rows at the end.
+ */
+int pbvi_alpha_set(pbvi_engine_t* e, const void* alpha, int64_t V);
+int pbvi_alpha_append(pbvi_engine_t* e, const void* alpha, int64_t V_add);
+int64_t pbvi_alpha_count(const pbvi_engine_t* e);
+
+/*
+ * Device-resident belief block.  Replaces BeliefSet.to_gpu (src/pomdp.py:613-634).
+ *   beliefs [B][S] T, row-major.
+ */
+int pbvi_beliefs_set(pbvi_engine_t* e, const void* beliefs, int64_t B);
+
+/*
+ * One point-based backup on the resident alpha set and belief block
+ * (src/pomdp.py:1485-1515).  Results stay on the device until fetched.
+ */
+int pbvi_backup_run(pbvi_engine_t* e, double gamma, int flags, pbvi_stats_t* stats /* may be NULL */);
+
+/*
+ * Copy the results of the last pbvi_backup_run to caller buffers (any may be NULL).
+ * Destinations may be host memory or device memory of the engine's GPU (the copy kind
+ * is resolved from the address), so the multi-GPU layer can land rows in its send buffer:
+ *   out_alpha      [B][S] T        alpha_vectors  (src/pomdp.py:1506)
+ *   out_action     [B] int32       best_actions   (src/pomdp.py:1505)
+ *   out_best_alpha [B][A][O] int32 best_alpha_ind (src/pomdp.py:1495)
+ *   out_keep       [B] uint8       dominating_vectors (src/pomdp.py:1512); all 1 if the
+ *                                  run did not request PBVI_BELIEF_DOMINANCE
+ */
+int pbvi_backup_fetch(pbvi_engine_t* e, void* out_alpha, int32_t* out_action,
+                      int32_t* out_best_alpha, uint8_t* out_keep);
+
+/*
+ * Device addresses of the last run's results, for the multi-GPU layer to hand to
+ * RCCL (all-gather of the new alpha rows) without a host round trip.
+ *   *d_alpha [B][S] T (row stride S), *d_action [B] int32, *d_keep [B] uint8.
+ */
+int pbvi_backup_device_results(pbvi_engine_t* e, void** d_alpha, int32_t** d_action, uint8_t** d_keep);
+
+/*
+ * Convenience: the reference seam in one call = beliefs_set + backup_run + backup_fetch
+ * (PBVI_Solver.backup(model, belief_set, value_function, ...) before ValueFunction dedup).
+ */
+int pbvi_backup(pbvi_engine_t* e, const void* beliefs, int64_t B, double gamma, int flags,
+                void* out_alpha, int32_t* out_action, int32_t* out_best_alpha, uint8_t* out_keep,
+                pbvi_stats_t* stats);
+
+/*
+ * ValueFunction.prune(level=2) on the resident alpha set (src/mdp.py:857-866):
+ *   keep[i] = 1 iff no other row j has alpha[j][s] >= alpha[i][s] for every s.
+ */
+int pbvi_prune_dominated(pbvi_engine_t* e, uint8_t* keep /* [V] */);
+
+/*
+ * max_v b.alpha_v over the resident alpha set for the resident belief block
+ * (compute_change, src/pomdp.py:2165-2166; also the |V|-limiter scan :2349-2352).
+ *   out_value [B] double, out_index [B] int32 (first max), either may be NULL.
+ */
+int pbvi_value_max(pbvi_engine_t* e, double* out_value, int32_t* out_index);
+
+/* Tuning knob for f32 engines: relative half-width of the near-tie window that sends an
+ * argmax to fp64 refinement (<= 0 restores the default derived from |S|). */
+int pbvi_set_tie_window(pbvi_engine_t* e, double rel);
+
+/* Bytes of device memory currently held by the handle. */
+int64_t pbvi_device_bytes(const pbvi_engine_t* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBVI_HIP_H */

@@ -1,0 +1,589 @@
+// HBM-bound kernels of the PBVI backup on gfx950: Gamma projection (padded-ELL SpMM),
+// dead-triple test, wavefront argmax with near-tie detection, fp64 refinement, action
+// selection, alpha' gather-sum, belief-dominance test and point-wise domination prune.
+// Reference statements: src/pomdp.py:1485-1515, src/mdp.py:857-866.
+//
+// All kernels read the model tables in the [.][S_pad] layouts of ModelView (coalesced
+// along s, 64-wide wavefronts) and reduce with wave shuffles in a fixed order, so
+// results are deterministic run to run.
+#include "backup_kernels.h"
+
+#include <limits>
+
+namespace pbvi {
+
+// ------------------------------------------------------------------------- //
+// helpers
+// ------------------------------------------------------------------------- //
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over the block (blockDim.x = 256); every thread gets the result.  sh: >= 4 doubles.
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wid] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+template <typename T>
+__device__ __forceinline__ T slab_sum(const T* p, int64_t slab_stride, int split_k) {
+    T s = p[0];
+    for (int z = 1; z < split_k; ++z) s += p[(int64_t)z * slab_stride];
+    return s;
+}
+
+// Partial (this thread's share) of  sum_s b[s] * gamma * sum_r rto[a][o][r][s] * alpha_v[rs[a][r][s]]
+template <typename T>
+__device__ __forceinline__ double proj_dot_partial(const T* __restrict__ brow, const T* __restrict__ arow,
+                                                   const ModelView<T>& mv, int a, int o, double gamma) {
+    const int32_t* rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
+    const T* rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
+    double acc = 0.0;
+    for (int s = threadIdx.x; s < mv.S; s += blockDim.x) {
+        const double bs = (double)brow[s];
+        if (bs != 0.0) {
+            double g = 0.0;
+            for (int r = 0; r < mv.R; ++r)
+                g += (double)rto[(int64_t)r * mv.S_pad + s] * (double)arow[rs[(int64_t)r * mv.S_pad + s]];
+            acc += bs * (gamma * g);
+        }
+    }
+    return acc;
+}
+
+template <typename T>
+__device__ __forceinline__ double plain_dot_partial(const T* __restrict__ brow, const T* __restrict__ arow, int S) {
+    double acc = 0.0;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) acc += (double)brow[s] * (double)arow[s];
+    return acc;
+}
+
+// ------------------------------------------------------------------------- //
+// support mask of RTO (engine creation)
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void k_support(ModelView<T> mv, uint8_t* __restrict__ sup) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int ao = blockIdx.y;
+    if (s >= mv.S_pad) return;
+    uint8_t f = 0;
+    for (int r = 0; r < mv.R; ++r) f |= (mv.rto[((int64_t)ao * mv.R + r) * mv.S_pad + s] != T(0)) ? 1 : 0;
+    sup[(int64_t)ao * mv.S_pad + s] = f;
+}
+
+template <typename T>
+hipError_t launch_support(ModelView<T> mv, uint8_t* sup, hipStream_t st) {
+    dim3 grid((mv.S_pad + 255) / 256, mv.A * mv.O);
+    hipLaunchKernelGGL(k_support<T>, grid, dim3(256), 0, st, mv, sup);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// K1-sparse: Gamma projection (padded-ELL SpMM).  src/pomdp.py:1485-1491
+// One thread per state s (coalesced), 4 alpha-vectors x 4 observations per pass so
+// every gathered alpha value and every table load is reused from registers.
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView<T> mv, T gamma,
+                          T* __restrict__ gam, int ldg) {
+#pragma clang fp contract(off)   // einsum then scale: sum_r (rto*alpha), one rounding per op, as the reference
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= mv.S_pad) return;
+    const int v0 = blockIdx.y * 4;
+    const int a = blockIdx.z;
+    const int nv = (V - v0) < 4 ? (V - v0) : 4;
+    for (int o0 = 0; o0 < mv.O; o0 += 4) {
+        const int no = (mv.O - o0) < 4 ? (mv.O - o0) : 4;
+        T acc[4][4];
+#pragma unroll
+        for (int vj = 0; vj < 4; ++vj)
+#pragma unroll
+            for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = T(0);
+        for (int r = 0; r < mv.R; ++r) {
+            const int idx = mv.rs[((int64_t)a * mv.R + r) * mv.S_pad + s];
+            T w[4];
+#pragma unroll
+            for (int oj = 0; oj < 4; ++oj)
+                w[oj] = (oj < no) ? mv.rto[(((int64_t)a * mv.O + o0 + oj) * mv.R + r) * mv.S_pad + s] : T(0);
+#pragma unroll
+            for (int vj = 0; vj < 4; ++vj) {
+                if (vj < nv) {
+                    const T av = alpha[(int64_t)(v0 + vj) * lda + idx];
+#pragma unroll
+                    for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = acc[vj][oj] + w[oj] * av;
+                }
+            }
+        }
+#pragma unroll
+        for (int vj = 0; vj < 4; ++vj)
+#pragma unroll
+            for (int oj = 0; oj < 4; ++oj)
+                if (vj < nv && oj < no)
+                    gam[(((int64_t)a * mv.O + o0 + oj) * V + v0 + vj) * ldg + s] = gamma * acc[vj][oj];
+    }
+}
+
+template <typename T>
+hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg, hipStream_t st) {
+    if (V <= 0) return hipSuccess;
+    dim3 grid((mv.S_pad + 255) / 256, (V + 3) / 4, mv.A);
+    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_project<T>, grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// dead triples: supp(b) disjoint from supp(RTO[:,a,o,:])  <=>  every score is exactly 0
+// ------------------------------------------------------------------------- //
+constexpr int DEAD_CHUNK = 16384;
+
+template <typename T>
+__global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, uint8_t* __restrict__ dead) {
+    extern __shared__ uint8_t dsm[];
+    uint8_t* nz = dsm;                                  // [DEAD_CHUNK]
+    int* hit = (int*)(dsm + DEAD_CHUNK);                // [AO]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int AO = mv.A * mv.O;
+    for (int i = tid; i < AO; i += 256) hit[i] = 0;
+    const T* brow = bel + (int64_t)b * ldb;
+    for (int s0 = 0; s0 < mv.S; s0 += DEAD_CHUNK) {
+        const int len = (mv.S - s0) < DEAD_CHUNK ? (mv.S - s0) : DEAD_CHUNK;
+        __syncthreads();
+        for (int i = tid; i < len; i += 256) nz[i] = (brow[s0 + i] != T(0)) ? 1 : 0;
+        __syncthreads();
+        for (int ao = wid; ao < AO; ao += 4) {
+            if (hit[ao]) continue;                      // wave-uniform (own entries only)
+            const uint8_t* sp = mv.sup + (int64_t)ao * mv.S_pad + s0;
+            int found = 0;
+            for (int i = lane; i < len && !found; i += 64) {
+                const int f = nz[i] & sp[i];
+                found = __any(f);
+            }
+            if (found && lane == 0) hit[ao] = 1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < AO; i += 256) dead[(int64_t)b * AO + i] = hit[i] ? 0 : 1;
+}
+
+template <typename T>
+hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, uint8_t* dead, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    const size_t lds = DEAD_CHUNK + (size_t)mv.A * mv.O * sizeof(int);
+    hipLaunchKernelGGL(k_dead<T>, dim3(B), dim3(256), lds, st, bel, ldb, mv, dead);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// argmax over alpha-vectors, one wavefront per (belief, group) row segment.
+// np.argmax semantics: first maximum.  src/pomdp.py:1495 (argmax part)
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void k_argmax(const T* __restrict__ slabs, int64_t slab_stride, int split_k, int ldc, int V, int vstride,
+                         int G, int B, const uint8_t* __restrict__ dead, double tol_rel, double tol_abs, int flag_all,
+                         int32_t* __restrict__ best_v, double* __restrict__ best_score, double* __restrict__ err,
+                         int32_t* __restrict__ queue, int* __restrict__ qcount) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= (int64_t)B * G) return;
+    const int b = (int)(gw / G), g = (int)(gw % G);
+    if (dead != nullptr && dead[gw]) {
+        if (lane == 0) {
+            best_v[gw] = 0;
+            best_score[gw] = 0.0;
+            err[gw] = 0.0;
+        }
+        return;
+    }
+    const T* row = slabs + (int64_t)b * ldc + (int64_t)g * vstride;
+    T m = -std::numeric_limits<T>::infinity();
+    int idx = 0x7fffffff;
+    for (int v = lane; v < V; v += 64) {
+        const T sc = slab_sum(row + v, slab_stride, split_k);
+        if (sc > m || idx == 0x7fffffff) {
+            m = sc;
+            idx = v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T om = __shfl_xor(m, off, 64);
+        const int oi = __shfl_xor(idx, off, 64);
+        if (om > m || (om == m && oi < idx)) {
+            m = om;
+            idx = oi;
+        }
+    }
+    double E = 0.0;
+    int push = 0;
+    if (queue != nullptr) {
+        double mag = fabs((double)m);
+        if (vstride > V) mag = fmax(mag, fabs((double)slab_sum(row + V, slab_stride, split_k)));
+        E = tol_rel * mag + tol_abs;
+        const double thr = (double)m - 2.0 * E;
+        int cnt = 0;
+        for (int v = lane; v < V; v += 64) {
+            const double sc = (double)slab_sum(row + v, slab_stride, split_k);
+            cnt += (sc >= thr) ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        push = (flag_all || cnt > 1) ? 1 : 0;
+    }
+    if (lane == 0) {
+        best_v[gw] = idx;
+        best_score[gw] = (double)m;
+        err[gw] = E;
+        if (push) {
+            const int slot = atomicAdd(qcount, 1);
+            queue[slot] = (int32_t)gw;
+        }
+    }
+}
+
+template <typename T>
+hipError_t launch_argmax(const T* slabs, int64_t slab_stride, int split_k, int ldc, int V, int vstride, int G, int B,
+                         const uint8_t* dead, double tol_rel, double tol_abs, int flag_all, int32_t* best_v,
+                         double* best_score, double* err, int32_t* queue, int* qcount, hipStream_t st) {
+    const int64_t rows = (int64_t)B * G;
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_argmax<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, slabs, slab_stride, split_k,
+                       ldc, V, vstride, G, B, dead, tol_rel, tol_abs, flag_all, best_v, best_score, err, queue, qcount);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// fp64 re-decision of a queued (belief, group): every candidate whose f32 score is
+// within the error window of the f32 maximum is re-scored exactly (f32 x f32 products
+// are exact in f64) and the first maximum of the exact scores wins.
+// ------------------------------------------------------------------------- //
+template <typename T, bool PROJ>
+__global__ void k_refine(const T* __restrict__ slabs, int64_t slab_stride, int split_k, int ldc, int V, int vstride,
+                         int G, const int32_t* __restrict__ queue, const int* __restrict__ qcount,
+                         const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
+                         ModelView<T> mv, double gamma, int32_t* __restrict__ best_v,
+                         double* __restrict__ best_score, double* __restrict__ err) {
+    __shared__ int cand[256];
+    __shared__ int wcount[4];
+    __shared__ double red[4];
+    if ((int)blockIdx.x >= *qcount) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int e = queue[blockIdx.x];
+    const int b = e / G, g = e % G;
+    const int a = PROJ ? g / mv.O : 0, o = PROJ ? g % mv.O : 0;
+    const double m = best_score[e], E = err[e];
+    const double thr = m - 2.0 * E;
+    const T* row = slabs + (int64_t)b * ldc + (int64_t)g * vstride;
+    const T* brow = bel + (int64_t)b * ldb;
+    double bestval = -std::numeric_limits<double>::infinity();
+    int bestidx = -1;
+    for (int v0 = 0; v0 < V; v0 += 256) {
+        const int v = v0 + tid;
+        int flag = 0;
+        if (v < V) flag = ((double)slab_sum(row + v, slab_stride, split_k) >= thr) ? 1 : 0;
+        const unsigned long long mask = __ballot(flag);
+        __syncthreads();
+        if (lane == 0) wcount[wid] = __popcll(mask);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wid; ++w) base += wcount[w];
+        const int ncand = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        if (flag) cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = v;
+        __syncthreads();
+        for (int c = 0; c < ncand; ++c) {
+            const int vv = cand[c];
+            const T* arow = alpha + (int64_t)vv * lda;
+            const double part = PROJ ? proj_dot_partial(brow, arow, mv, a, o, gamma)
+                                     : plain_dot_partial(brow, arow, mv.S);
+            const double tot = block_sum(part, red);
+            if (tot > bestval) {          // candidates ascend in v: first maximum wins
+                bestval = tot;
+                bestidx = vv;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && bestidx >= 0) {
+        best_v[e] = bestidx;
+        best_score[e] = bestval;
+        err[e] = 0.0;
+    }
+}
+
+template <typename T>
+hipError_t launch_refine(bool proj, const T* slabs, int64_t slab_stride, int split_k, int ldc, int V, int vstride,
+                         int G, int max_entries, const int32_t* queue, const int* qcount, const T* bel, int ldb,
+                         const T* alpha, int lda, ModelView<T> mv, double gamma, int32_t* best_v,
+                         double* best_score, double* err, hipStream_t st) {
+    if (max_entries <= 0) return hipSuccess;
+    if (proj)
+        hipLaunchKernelGGL((k_refine<T, true>), dim3(max_entries), dim3(256), 0, st, slabs, slab_stride, split_k, ldc,
+                           V, vstride, G, queue, qcount, bel, ldb, alpha, lda, mv, gamma, best_v, best_score, err);
+    else
+        hipLaunchKernelGGL((k_refine<T, false>), dim3(max_entries), dim3(256), 0, st, slabs, slab_stride, split_k,
+                           ldc, V, vstride, G, queue, qcount, bel, ldb, alpha, lda, mv, gamma, best_v, best_score, err);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// K4: action values and first-max action.  src/pomdp.py:1502-1505 via the identity
+//   b . alpha_a[b,a,:] = b . ER[:,a] + sum_o max_v score[b,a,o,v]
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void k_action(const T* __restrict__ bel, int ldb, ModelView<T> mv, const double* __restrict__ best_score,
+                         const double* __restrict__ err, double* __restrict__ rdot, int32_t* __restrict__ action,
+                         int32_t* __restrict__ aqueue, int* __restrict__ aqcount) {
+    extern __shared__ double asm_[];
+    double* val = asm_;                  // [A]
+    double* Eb = asm_ + mv.A;            // [A]
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const T* brow = bel + (int64_t)b * ldb;
+    for (int a0 = 0; a0 < mv.A; a0 += 4) {
+        const int na = (mv.A - a0) < 4 ? (mv.A - a0) : 4;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int s = tid; s < mv.S; s += 256) {
+            const double bs = (double)brow[s];
+            if (bs != 0.0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < na) acc[j] += bs * (double)mv.er[(int64_t)(a0 + j) * mv.S_pad + s];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < na) {                                   // block-uniform
+                const double t = block_sum(acc[j], red);
+                if (tid == 0) val[a0 + j] = t;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0;
+        double bv = -std::numeric_limits<double>::infinity();
+        for (int a = 0; a < mv.A; ++a) {
+            rdot[(int64_t)b * mv.A + a] = val[a];
+            double v = val[a], E = 0.0;
+            for (int o = 0; o < mv.O; ++o) {
+                const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
+                v += best_score[e];
+                E += err[e];
+            }
+            val[a] = v;
+            Eb[a] = E;
+            if (v > bv) {
+                bv = v;
+                best = a;
+            }
+        }
+        action[b] = best;
+        if (aqueue != nullptr) {
+            double lo = -std::numeric_limits<double>::infinity();
+            for (int a = 0; a < mv.A; ++a) lo = fmax(lo, val[a] - Eb[a]);
+            int ncand = 0, anyerr = 0;
+            for (int a = 0; a < mv.A; ++a)
+                if (val[a] + Eb[a] >= lo) {
+                    ++ncand;
+                    anyerr |= (Eb[a] > 0.0);
+                }
+            if (ncand > 1 && anyerr) aqueue[atomicAdd(aqcount, 1)] = b;
+        }
+    }
+}
+
+template <typename T>
+hipError_t launch_action(const T* bel, int ldb, int B, ModelView<T> mv, const double* best_score, const double* err,
+                         double* rdot, int32_t* action, int32_t* aqueue, int* aqcount, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_action<T>, dim3(B), dim3(256), 2 * mv.A * sizeof(double), st, bel, ldb, mv, best_score, err,
+                       rdot, action, aqueue, aqcount);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
+                                ModelView<T> mv, double gamma, const int32_t* __restrict__ aqueue,
+                                const int* __restrict__ aqcount, const double* __restrict__ rdot,
+                                const int32_t* __restrict__ best_v, double* __restrict__ best_score,
+                                double* __restrict__ err, int32_t* __restrict__ action) {
+    extern __shared__ double asm_[];
+    double* val = asm_;
+    double* Eb = asm_ + mv.A;
+    __shared__ double red[4];
+    __shared__ double lo_sh;
+    if ((int)blockIdx.x >= *aqcount) return;
+    const int b = aqueue[blockIdx.x], tid = threadIdx.x;
+    const T* brow = bel + (int64_t)b * ldb;
+    if (tid == 0) {
+        double lo = -std::numeric_limits<double>::infinity();
+        for (int a = 0; a < mv.A; ++a) {
+            double v = rdot[(int64_t)b * mv.A + a], E = 0.0;
+            for (int o = 0; o < mv.O; ++o) {
+                const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
+                v += best_score[e];
+                E += err[e];
+            }
+            val[a] = v;
+            Eb[a] = E;
+            lo = fmax(lo, v - E);
+        }
+        lo_sh = lo;
+    }
+    __syncthreads();
+    const double lo = lo_sh;
+    double bv = -std::numeric_limits<double>::infinity();
+    int best = 0;
+    for (int a = 0; a < mv.A; ++a) {
+        if (!(val[a] + Eb[a] >= lo)) continue;                 // block-uniform
+        double v = rdot[(int64_t)b * mv.A + a];
+        for (int o = 0; o < mv.O; ++o) {
+            const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
+            double sc = best_score[e];
+            if (err[e] > 0.0) {                                 // block-uniform
+                const T* arow = alpha + (int64_t)best_v[e] * lda;
+                sc = block_sum(proj_dot_partial(brow, arow, mv, a, o, gamma), red);
+                __syncthreads();
+                if (tid == 0) {
+                    best_score[e] = sc;
+                    err[e] = 0.0;
+                }
+            }
+            v += sc;
+        }
+        if (v > bv) {
+            bv = v;
+            best = a;
+        }
+    }
+    if (tid == 0) action[b] = best;
+}
+
+template <typename T>
+hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv, double gamma,
+                                const int32_t* aqueue, const int* aqcount, const double* rdot, const int32_t* best_v,
+                                double* best_score, double* err, int32_t* action, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_refine_action<T>, dim3(B), dim3(256), 2 * mv.A * sizeof(double), st, bel, ldb, alpha, lda, mv,
+                       gamma, aqueue, aqcount, rdot, best_v, best_score, err, action);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// K3: alpha' rows.  src/pomdp.py:1497-1506 restricted to the winning action:
+//   out[b][s] = ER[s,a*] + ((G0 + G1) + G2 ...),  G_o = gamma * sum_r rto * alpha_{v*[b,a*,o]}[rs]
+// evaluated in f64 in the reference's association, rounded once to T.
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void k_assemble(const T* __restrict__ alpha, int lda, ModelView<T> mv, double gamma,
+                           const int32_t* __restrict__ action, const int32_t* __restrict__ best_v,
+                           T* __restrict__ out, int ldo) {
+#pragma clang fp contract(off)
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (s >= mv.S) return;
+    const int a = action[b];
+    const int32_t* rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
+    double total = 0.0;
+    for (int o = 0; o < mv.O; ++o) {
+        const int v = best_v[((int64_t)b * mv.A + a) * mv.O + o];
+        const T* arow = alpha + (int64_t)v * lda;
+        const T* rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
+        double g = 0.0;
+        for (int r = 0; r < mv.R; ++r)
+            g = g + (double)rto[(int64_t)r * mv.S_pad + s] * (double)arow[rs[(int64_t)r * mv.S_pad + s]];
+        const double go = gamma * g;
+        total = (o == 0) ? go : total + go;
+    }
+    out[(int64_t)b * ldo + s] = (T)((double)mv.er[(int64_t)a * mv.S_pad + s] + total);
+}
+
+template <typename T>
+hipError_t launch_assemble(const T* alpha, int lda, ModelView<T> mv, double gamma, const int32_t* action,
+                           const int32_t* best_v, int B, T* out, int ldo, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    if (B > 65535) return hipErrorInvalidValue;
+    dim3 grid((mv.S + 255) / 256, B);
+    hipLaunchKernelGGL(k_assemble<T>, grid, dim3(256), 0, st, alpha, lda, mv, gamma, action, best_v, out, ldo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// K5: belief-dominance test.  src/pomdp.py:1510-1512
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void k_keep(const T* __restrict__ bel, int ldb, const T* __restrict__ out, int ldo, int S,
+                       const double* __restrict__ oldmax, uint8_t* __restrict__ keep) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    const double nv = block_sum(plain_dot_partial(bel + (int64_t)b * ldb, out + (int64_t)b * ldo, S), red);
+    if (threadIdx.x == 0) keep[b] = (nv > oldmax[b]) ? 1 : 0;
+}
+
+template <typename T>
+hipError_t launch_keep(const T* bel, int ldb, const T* out, int ldo, int B, int S, const double* oldmax, uint8_t* keep,
+                       hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_keep<T>, dim3(B), dim3(256), 0, st, bel, ldb, out, ldo, S, oldmax, keep);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// prune level 2: one wavefront per ordered pair (i, j), early exit on the first
+// state where alpha[j] < alpha[i].  src/mdp.py:857-866
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void k_dominated(const T* __restrict__ alpha, int lda, int V, int S, int* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x;
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j >= V) return;
+    const T* ai = alpha + (int64_t)i * lda;
+    const T* aj = alpha + (int64_t)j * lda;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const int bad = (s < S) ? !(aj[s] >= ai[s]) : 0;
+        if (__any(bad)) return;
+    }
+    if (lane == 0) atomicAdd(&cnt[i], 1);
+}
+
+template <typename T>
+hipError_t launch_dominated(const T* alpha, int lda, int V, int S, int* cnt, hipStream_t st) {
+    if (V <= 0) return hipSuccess;
+    dim3 grid(V, (V + 3) / 4);
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_dominated<T>, grid, dim3(256), 0, st, alpha, lda, V, S, cnt);
+    return hipGetLastError();
+}
+
+// explicit instantiations
+#define PBVI_INST(T)                                                                                                   \
+    template hipError_t launch_support<T>(ModelView<T>, uint8_t*, hipStream_t);                                        \
+    template hipError_t launch_project<T>(const T*, int, int, ModelView<T>, T, T*, int, hipStream_t);                  \
+    template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, uint8_t*, hipStream_t);                       \
+    template hipError_t launch_argmax<T>(const T*, int64_t, int, int, int, int, int, int, const uint8_t*, double,      \
+                                         double, int, int32_t*, double*, double*, int32_t*, int*, hipStream_t);        \
+    template hipError_t launch_refine<T>(bool, const T*, int64_t, int, int, int, int, int, int, const int32_t*,        \
+                                         const int*,                                                                   \
+                                         const T*, int, const T*, int, ModelView<T>, double, int32_t*, double*,        \
+                                         double*, hipStream_t);                                                        \
+    template hipError_t launch_action<T>(const T*, int, int, ModelView<T>, const double*, const double*, double*,      \
+                                         int32_t*, int32_t*, int*, hipStream_t);                                       \
+    template hipError_t launch_refine_action<T>(const T*, int, int, const T*, int, ModelView<T>, double,               \
+                                                const int32_t*, const int*, const double*, const int32_t*, double*,    \
+                                                double*, int32_t*, hipStream_t);                                       \
+    template hipError_t launch_assemble<T>(const T*, int, ModelView<T>, double, const int32_t*, const int32_t*, int,   \
+                                           T*, int, hipStream_t);                                                      \
+    template hipError_t launch_keep<T>(const T*, int, const T*, int, int, int, const double*, uint8_t*, hipStream_t);  \
+    template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
+PBVI_INST(float)
+PBVI_INST(double)
+
+}  // namespace pbvi

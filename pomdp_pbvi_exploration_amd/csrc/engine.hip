@@ -1,0 +1,635 @@
+// Engine object behind include/pbvi_hip.h: device residency of the model tables,
+// the alpha-vector set and the belief block, and the kernel sequence of one backup.
+//
+// Device layouts (T = float | double, S_pad = S rounded up to 32, zero padded):
+//   model   : see ModelView in backup_kernels.h
+//   alpha   : [V_cap][S_pad]   rows 0..V-1 the set, row V = column-wise max |alpha|
+//             (the magnitude row that bounds sum_s b_s |Gamma_v,s| for the tie window)
+//   beliefs : [B_pad][S_pad]   B_pad = B rounded up to 256 (zero rows)
+//   Gamma   : [N_pad][S_pad]   row (a*O+o)*(V+1)+v, v = V being the magnitude row
+//   scores  : [split_k][B_pad][N_pad] f32 partial slabs  (f64 engines: [B][N])
+//   results : out_alpha [B][S], action [B], best_v [B][A][O], keep [B]
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "backup_kernels.h"
+
+namespace pbvi {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+            (void)hipGetLastError();                                                         \
+            return (_e == hipErrorOutOfMemory || _e == hipErrorMemoryAllocation) ? PBVI_ENOMEM : PBVI_ERUNTIME; \
+        }                                                                                    \
+    } while (0)
+
+#define FAIL(code, msg)        \
+    do {                       \
+        set_error(msg);        \
+        return (code);         \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    // grow-only; contents are NOT preserved on growth
+    int ensure(size_t bytes, int64_t* total) {
+        if (bytes <= cap) return PBVI_OK;
+        if (p) {
+            (void)hipFree(p);
+            *total -= (int64_t)cap;
+            p = nullptr;
+            cap = 0;
+        }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+            return PBVI_ENOMEM;
+        }
+        cap = bytes;
+        *total += (int64_t)bytes;
+        return PBVI_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename U>
+    U* as() const { return reinterpret_cast<U*>(p); }
+};
+
+template <typename T>
+__global__ void k_col_absmax(const T* __restrict__ alpha, int lda, int V, int S_pad, T* __restrict__ out) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S_pad) return;
+    T m = T(0);
+    for (int v = 0; v < V; ++v) {
+        const T x = alpha[(int64_t)v * lda + s];
+        const T ax = x < T(0) ? -x : x;
+        m = ax > m ? ax : m;
+    }
+    out[s] = m;
+}
+
+class EngineBase {
+   public:
+    virtual ~EngineBase() {}
+    virtual int alpha_set(const void* alpha, int64_t V) = 0;
+    virtual int alpha_append(const void* alpha, int64_t n) = 0;
+    virtual int64_t alpha_count() const = 0;
+    virtual int beliefs_set(const void* bel, int64_t B) = 0;
+    virtual int backup_run(double gamma, int flags, pbvi_stats_t* st) = 0;
+    virtual int backup_fetch(void* out_alpha, int32_t* out_action, int32_t* out_best, uint8_t* out_keep) = 0;
+    virtual int device_results(void** d_alpha, int32_t** d_action, uint8_t** d_keep) = 0;
+    virtual int prune_dominated(uint8_t* keep) = 0;
+    virtual int value_max(double* out_value, int32_t* out_index) = 0;
+    virtual int set_tie_window(double rel) = 0;
+    virtual int64_t device_bytes() const = 0;
+};
+
+template <typename T>
+class EngineT : public EngineBase {
+   public:
+    static constexpr bool kF32 = sizeof(T) == 4;
+
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    int S_ = 0, A_ = 0, O_ = 0, R_ = 0, S_pad_ = 0, mode_ = 0;
+    int64_t bytes_ = 0;
+    double tie_rel_user_ = -1.0;
+
+    DevBuf rs_, rto_, er_, sup_;
+    DevBuf alpha_;
+    int64_t V_ = 0;
+    DevBuf bel_;
+    int64_t B_ = 0, B_pad_ = 0;
+    DevBuf gam_, slabs_, best_v_, best_score_, err_, dead_, queue_, counters_, rdot_, action_, aqueue_, out_, keep_;
+    DevBuf bv2_, bs2_, err2_, queue2_, prune_cnt_;
+    hipEvent_t ev_[9] = {};
+    bool have_result_ = false;
+    int64_t res_B_ = 0;
+
+    ~EngineT() override {
+        (void)hipSetDevice(device_);
+        DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
+                         &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
+                         &err2_, &queue2_, &prune_cnt_};
+        for (DevBuf* b : all) b->release();
+        for (auto& e : ev_)
+            if (e) (void)hipEventDestroy(e);
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
+
+    ModelView<T> view() const {
+        ModelView<T> mv;
+        mv.S = S_;
+        mv.S_pad = S_pad_;
+        mv.A = A_;
+        mv.O = O_;
+        mv.R = R_;
+        mv.rs = rs_.as<int32_t>();
+        mv.rto = rto_.as<T>();
+        mv.er = er_.as<T>();
+        mv.sup = sup_.as<uint8_t>();
+        return mv;
+    }
+
+    int init(int device, int S, int A, int O, int R, const int32_t* reach, const T* rto, const T* er, int mode) {
+        device_ = device;
+        S_ = S;
+        A_ = A;
+        O_ = O;
+        R_ = R;
+        mode_ = mode;
+        S_pad_ = (int)round_up(S, GEMM_BK);
+        HIPCHK(hipSetDevice(device_));
+        HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
+
+        // re-tile the reference's [S][A][R] / [S][A][O][R] / [S][A] tables to s-contiguous planes
+        const size_t n_rs = (size_t)A * R * S_pad_, n_rto = (size_t)A * O * R * S_pad_, n_er = (size_t)A * S_pad_;
+        std::vector<int32_t> h_rs;
+        std::vector<T> h_rto, h_er;
+        try {
+            h_rs.assign(n_rs, 0);
+            h_rto.assign(n_rto, T(0));
+            h_er.assign(n_er, T(0));
+        } catch (const std::bad_alloc&) {
+            FAIL(PBVI_ENOMEM, "host allocation for table re-tiling failed");
+        }
+        for (int s = 0; s < S; ++s)
+            for (int a = 0; a < A; ++a) {
+                h_er[(size_t)a * S_pad_ + s] = er[(size_t)s * A + a];
+                for (int r = 0; r < R; ++r) {
+                    const int32_t t = reach[((size_t)s * A + a) * R + r];
+                    if (t < 0 || t >= S) FAIL(PBVI_EINVAL, "reach_states entry out of range [0,S)");
+                    h_rs[((size_t)a * R + r) * S_pad_ + s] = t;
+                    for (int o = 0; o < O; ++o)
+                        h_rto[(((size_t)a * O + o) * R + r) * S_pad_ + s] = rto[(((size_t)s * A + a) * O + o) * R + r];
+                }
+            }
+        int rc;
+        if ((rc = rs_.ensure(n_rs * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = rto_.ensure(n_rto * sizeof(T), &bytes_))) return rc;
+        if ((rc = er_.ensure(n_er * sizeof(T), &bytes_))) return rc;
+        if ((rc = sup_.ensure((size_t)A * O * S_pad_, &bytes_))) return rc;
+        HIPCHK(hipMemcpyAsync(rs_.p, h_rs.data(), n_rs * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemcpyAsync(rto_.p, h_rto.data(), n_rto * sizeof(T), hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemcpyAsync(er_.p, h_er.data(), n_er * sizeof(T), hipMemcpyHostToDevice, stream_));
+        HIPCHK(launch_support<T>(view(), sup_.as<uint8_t>(), stream_));
+        if ((rc = counters_.ensure(4 * sizeof(int), &bytes_))) return rc;
+        HIPCHK(hipStreamSynchronize(stream_));
+        return PBVI_OK;
+    }
+
+    // ---- alpha set ------------------------------------------------------- //
+    size_t alpha_rows_cap(int64_t V) const { return (size_t)round_up(V + 1, GEMM_BN); }
+
+    int refresh_magnitude_row() {
+        T* base = alpha_.as<T>();
+        hipLaunchKernelGGL(k_col_absmax<T>, dim3((S_pad_ + 255) / 256), dim3(256), 0, stream_, base, S_pad_, (int)V_,
+                           S_pad_, base + (size_t)V_ * S_pad_);
+        HIPCHK(hipGetLastError());
+        return PBVI_OK;
+    }
+
+    int alpha_set(const void* alpha, int64_t V) override {
+        if (V <= 0 || alpha == nullptr) FAIL(PBVI_EINVAL, "alpha_set: need V > 0 and a non-null array");
+        HIPCHK(hipSetDevice(device_));
+        const size_t rows = alpha_rows_cap(V);
+        int rc = alpha_.ensure(rows * S_pad_ * sizeof(T), &bytes_);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(alpha_.p, 0, alpha_.cap, stream_));
+        HIPCHK(hipMemcpy2DAsync(alpha_.p, (size_t)S_pad_ * sizeof(T), alpha, (size_t)S_ * sizeof(T),
+                                (size_t)S_ * sizeof(T), (size_t)V, hipMemcpyHostToDevice, stream_));
+        V_ = V;
+        rc = refresh_magnitude_row();
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(stream_));
+        have_result_ = false;
+        return PBVI_OK;
+    }
+
+    int alpha_append(const void* alpha, int64_t n) override {
+        if (n < 0 || (n > 0 && alpha == nullptr)) FAIL(PBVI_EINVAL, "alpha_append: bad arguments");
+        if (n == 0) return PBVI_OK;
+        HIPCHK(hipSetDevice(device_));
+        const int64_t Vn = V_ + n;
+        const size_t need = alpha_rows_cap(Vn) * S_pad_ * sizeof(T);
+        if (need > alpha_.cap) {   // grow, preserving the resident rows
+            DevBuf nb;
+            int rc = nb.ensure(std::max(need, alpha_.cap * 2), &bytes_);
+            if (rc) return rc;
+            HIPCHK(hipMemsetAsync(nb.p, 0, nb.cap, stream_));
+            if (V_ > 0)
+                HIPCHK(hipMemcpyAsync(nb.p, alpha_.p, (size_t)V_ * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            bytes_ -= (int64_t)alpha_.cap;
+            alpha_.release();
+            alpha_ = nb;
+        } else {
+            // clear the old magnitude row's pad columns / content before it becomes a data row
+            HIPCHK(hipMemsetAsync(alpha_.as<T>() + (size_t)V_ * S_pad_, 0, (size_t)S_pad_ * sizeof(T), stream_));
+        }
+        HIPCHK(hipMemcpy2DAsync(alpha_.as<T>() + (size_t)V_ * S_pad_, (size_t)S_pad_ * sizeof(T), alpha,
+                                (size_t)S_ * sizeof(T), (size_t)S_ * sizeof(T), (size_t)n, hipMemcpyHostToDevice, stream_));
+        V_ = Vn;
+        int rc = refresh_magnitude_row();
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(stream_));
+        have_result_ = false;
+        return PBVI_OK;
+    }
+
+    int64_t alpha_count() const override { return V_; }
+
+    int beliefs_set(const void* bel, int64_t B) override {
+        if (B <= 0 || bel == nullptr) FAIL(PBVI_EINVAL, "beliefs_set: need B > 0 and a non-null array");
+        if (B > 65535) FAIL(PBVI_EUNSUPPORTED, "beliefs_set: at most 65535 beliefs per block");
+        HIPCHK(hipSetDevice(device_));
+        const int64_t Bp = round_up(B, GEMM_BM);
+        int rc = bel_.ensure((size_t)Bp * S_pad_ * sizeof(T), &bytes_);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(bel_.p, 0, (size_t)Bp * S_pad_ * sizeof(T), stream_));
+        HIPCHK(hipMemcpy2DAsync(bel_.p, (size_t)S_pad_ * sizeof(T), bel, (size_t)S_ * sizeof(T), (size_t)S_ * sizeof(T),
+                                (size_t)B, hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        B_ = B;
+        B_pad_ = Bp;
+        have_result_ = false;
+        return PBVI_OK;
+    }
+
+    double tie_window(int k_chunk) const {
+        if (!kF32) return 0.0;
+        if (tie_rel_user_ > 0.0) return tie_rel_user_;
+        const double u = 5.9604644775390625e-08;   // 2^-24
+        return 8.0 * u * std::sqrt((double)std::max(k_chunk, 1)) + 8.0 * u;
+    }
+
+    // score GEMM: C = X[rows_x][S_pad] . Y[rows_y][S_pad]^T  -> slabs_; returns layout
+    struct ScoreLayout {
+        int ldc = 0, split_k = 1;
+        int64_t slab_stride = 0;
+    };
+    int score_gemm(const T* X, int64_t rows_x, int64_t rows_x_pad, const T* Y, int64_t rows_y, ScoreLayout* lay);
+
+    int backup_run(double gamma, int flags, pbvi_stats_t* st) override;
+
+    int backup_fetch(void* out_alpha, int32_t* out_action, int32_t* out_best, uint8_t* out_keep) override {
+        if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch: no backup result resident (call pbvi_backup_run first)");
+        HIPCHK(hipSetDevice(device_));
+        const size_t B = (size_t)res_B_;
+        if (out_alpha) HIPCHK(hipMemcpyAsync(out_alpha, out_.p, B * S_ * sizeof(T), hipMemcpyDefault, stream_));
+        if (out_action) HIPCHK(hipMemcpyAsync(out_action, action_.p, B * sizeof(int32_t), hipMemcpyDefault, stream_));
+        if (out_best)
+            HIPCHK(hipMemcpyAsync(out_best, best_v_.p, B * A_ * O_ * sizeof(int32_t), hipMemcpyDefault, stream_));
+        if (out_keep) HIPCHK(hipMemcpyAsync(out_keep, keep_.p, B, hipMemcpyDefault, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        return PBVI_OK;
+    }
+
+    int device_results(void** d_alpha, int32_t** d_action, uint8_t** d_keep) override {
+        if (!have_result_) FAIL(PBVI_EINVAL, "no backup result resident");
+        if (d_alpha) *d_alpha = out_.p;
+        if (d_action) *d_action = action_.as<int32_t>();
+        if (d_keep) *d_keep = keep_.as<uint8_t>();
+        return PBVI_OK;
+    }
+
+    int prune_dominated(uint8_t* keep) override {
+        if (V_ <= 0) FAIL(PBVI_EINVAL, "prune_dominated: no alpha set resident");
+        if (!keep) FAIL(PBVI_EINVAL, "prune_dominated: keep is NULL");
+        HIPCHK(hipSetDevice(device_));
+        int rc = prune_cnt_.ensure((size_t)V_ * sizeof(int), &bytes_);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(prune_cnt_.p, 0, (size_t)V_ * sizeof(int), stream_));
+        HIPCHK(launch_dominated<T>(alpha_.as<T>(), S_pad_, (int)V_, S_, prune_cnt_.as<int>(), stream_));
+        std::vector<int> cnt((size_t)V_);
+        HIPCHK(hipMemcpyAsync(cnt.data(), prune_cnt_.p, (size_t)V_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (int64_t i = 0; i < V_; ++i) keep[i] = (cnt[(size_t)i] == 1) ? 1 : 0;
+        return PBVI_OK;
+    }
+
+    // exact (f64-refined) max_v b.alpha_v of the resident blocks into bs2_/bv2_
+    int value_max_device();
+
+    int value_max(double* out_value, int32_t* out_index) override {
+        if (V_ <= 0 || B_ <= 0) FAIL(PBVI_EINVAL, "value_max: need a resident alpha set and belief block");
+        HIPCHK(hipSetDevice(device_));
+        int rc = value_max_device();
+        if (rc) return rc;
+        if (out_value) HIPCHK(hipMemcpyAsync(out_value, bs2_.p, (size_t)B_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        if (out_index) HIPCHK(hipMemcpyAsync(out_index, bv2_.p, (size_t)B_ * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        return PBVI_OK;
+    }
+
+    int set_tie_window(double rel) override {
+        tie_rel_user_ = rel;
+        return PBVI_OK;
+    }
+    int64_t device_bytes() const override { return bytes_; }
+};
+
+template <typename T>
+int EngineT<T>::score_gemm(const T* X, int64_t rows_x, int64_t rows_x_pad, const T* Y, int64_t rows_y, ScoreLayout* lay) {
+    int rc;
+    if constexpr (kF32) {
+        const int64_t n_pad = round_up(rows_y, GEMM_BN);
+        const int tiles = (int)((rows_x_pad / GEMM_BM) * (n_pad / GEMM_BN));
+        const int k_tiles = S_pad_ / GEMM_BK;
+        lay->split_k = choose_split_k(tiles, k_tiles);
+        lay->ldc = (int)n_pad;
+        lay->slab_stride = rows_x_pad * n_pad;
+        if ((rc = slabs_.ensure((size_t)lay->split_k * lay->slab_stride * sizeof(float), &bytes_))) return rc;
+        HIPCHK(launch_gemm_nt_f32((const float*)X, S_pad_, (const float*)Y, S_pad_, slabs_.as<float>(), lay->ldc,
+                                  lay->slab_stride, (int)rows_x_pad, (int)n_pad, S_pad_, lay->split_k, stream_));
+    } else {
+        lay->split_k = 1;
+        lay->ldc = (int)rows_y;
+        lay->slab_stride = 0;
+        if ((rc = slabs_.ensure((size_t)rows_x * rows_y * sizeof(T), &bytes_))) return rc;
+        HIPCHK(launch_gemm_nt_simple<T>(X, S_pad_, Y, S_pad_, slabs_.as<T>(), lay->ldc, (int)rows_x, (int)rows_y, S_,
+                                        stream_));
+    }
+    return PBVI_OK;
+}
+
+template <typename T>
+int EngineT<T>::value_max_device() {
+    int rc;
+    const int64_t Vt = V_ + 1;   // + magnitude row
+    if ((rc = bv2_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+    if ((rc = bs2_.ensure((size_t)B_ * sizeof(double), &bytes_))) return rc;
+    if ((rc = err2_.ensure((size_t)B_ * sizeof(double), &bytes_))) return rc;
+    if ((rc = queue2_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+    int* qc = counters_.as<int>() + 2;
+    HIPCHK(hipMemsetAsync(qc, 0, sizeof(int), stream_));
+    ScoreLayout lay;
+    if ((rc = score_gemm(bel_.as<T>(), B_, B_pad_, alpha_.as<T>(), Vt, &lay))) return rc;
+    const int k_chunk = S_pad_ / lay.split_k;
+    // every belief is re-scored exactly in f32 engines (flag_all): the comparison that
+    // follows (new value > old best value) is strict and must not see GEMM rounding
+    HIPCHK(launch_argmax<T>(slabs_.as<T>(), lay.slab_stride, lay.split_k, lay.ldc, (int)V_, (int)Vt, 1, (int)B_, nullptr,
+                            tie_window(k_chunk), 0.0, 1, bv2_.as<int32_t>(), bs2_.as<double>(), err2_.as<double>(),
+                            kF32 ? queue2_.as<int32_t>() : nullptr, qc, stream_));
+    if (kF32)
+        HIPCHK(launch_refine<T>(false, slabs_.as<T>(), lay.slab_stride, lay.split_k, lay.ldc, (int)V_, (int)Vt, 1,
+                                (int)B_, queue2_.as<int32_t>(), qc, bel_.as<T>(), S_pad_, alpha_.as<T>(), S_pad_, view(),
+                                0.0, bv2_.as<int32_t>(), bs2_.as<double>(), err2_.as<double>(), stream_));
+    return PBVI_OK;
+}
+
+template <typename T>
+int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
+    if (V_ <= 0) FAIL(PBVI_EINVAL, "backup_run: no alpha set resident (call pbvi_alpha_set)");
+    if (B_ <= 0) FAIL(PBVI_EINVAL, "backup_run: no belief block resident (call pbvi_beliefs_set)");
+    if (mode_ != PBVI_SPARSE) FAIL(PBVI_EUNSUPPORTED, "backup_run: dense projection mode is not built yet");
+    HIPCHK(hipSetDevice(device_));
+    int rc;
+    const int AO = A_ * O_;
+    const int64_t Vt = V_ + 1;                 // alpha rows + magnitude row
+    const int64_t N = (int64_t)AO * Vt;        // Gamma rows
+    const int64_t pairs = B_ * AO;
+    if (N > 0x7fffffff || pairs > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "backup_run: A*O*(V+1) or B*A*O exceeds int32");
+    const ModelView<T> mv = view();
+
+    const int64_t n_rows_alloc = kF32 ? round_up(N, GEMM_BN) : N;
+    if ((rc = gam_.ensure((size_t)n_rows_alloc * S_pad_ * sizeof(T), &bytes_))) return rc;
+    if ((rc = best_v_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc;
+    if ((rc = best_score_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
+    if ((rc = err_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
+    if ((rc = queue_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc;
+    if ((rc = dead_.ensure((size_t)pairs, &bytes_))) return rc;
+    if ((rc = rdot_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
+    if ((rc = action_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+    if ((rc = aqueue_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+    if ((rc = out_.ensure((size_t)B_ * S_ * sizeof(T), &bytes_))) return rc;
+    if ((rc = keep_.ensure((size_t)B_, &bytes_))) return rc;
+    int* qcount = counters_.as<int>();
+    int* aqcount = counters_.as<int>() + 1;
+    HIPCHK(hipMemsetAsync(counters_.p, 0, 4 * sizeof(int), stream_));
+    if (n_rows_alloc > N)   // zero the Gamma pad rows the GEMM tiles read
+        HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)N * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
+
+    HIPCHK(hipEventRecord(ev_[0], stream_));
+    // K1: Gamma projection of the V alpha rows and the magnitude row
+    HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, stream_));
+    if (kF32) HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, dead_.as<uint8_t>(), stream_));
+    HIPCHK(hipEventRecord(ev_[1], stream_));
+    // K2: scores
+    ScoreLayout lay;
+    if ((rc = score_gemm(bel_.as<T>(), B_, B_pad_, gam_.as<T>(), N, &lay))) return rc;
+    HIPCHK(hipEventRecord(ev_[2], stream_));
+    const int k_chunk = S_pad_ / lay.split_k;
+    HIPCHK(launch_argmax<T>(slabs_.as<T>(), lay.slab_stride, lay.split_k, lay.ldc, (int)V_, (int)Vt, AO, (int)B_,
+                            kF32 ? dead_.as<uint8_t>() : nullptr, tie_window(k_chunk), 0.0, 0, best_v_.as<int32_t>(),
+                            best_score_.as<double>(), err_.as<double>(), kF32 ? queue_.as<int32_t>() : nullptr, qcount,
+                            stream_));
+    HIPCHK(hipEventRecord(ev_[3], stream_));
+    if (kF32)
+        HIPCHK(launch_refine<T>(true, slabs_.as<T>(), lay.slab_stride, lay.split_k, lay.ldc, (int)V_, (int)Vt, AO,
+                                (int)pairs, queue_.as<int32_t>(), qcount, bel_.as<T>(), S_pad_, alpha_.as<T>(), S_pad_, mv,
+                                gamma, best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), stream_));
+    HIPCHK(hipEventRecord(ev_[4], stream_));
+    // K4: action
+    HIPCHK(launch_action<T>(bel_.as<T>(), S_pad_, (int)B_, mv, best_score_.as<double>(), err_.as<double>(),
+                            rdot_.as<double>(), action_.as<int32_t>(), kF32 ? aqueue_.as<int32_t>() : nullptr, aqcount,
+                            stream_));
+    if (kF32)
+        HIPCHK(launch_refine_action<T>(bel_.as<T>(), S_pad_, (int)B_, alpha_.as<T>(), S_pad_, mv, gamma,
+                                       aqueue_.as<int32_t>(), aqcount, rdot_.as<double>(), best_v_.as<int32_t>(),
+                                       best_score_.as<double>(), err_.as<double>(), action_.as<int32_t>(), stream_));
+    HIPCHK(hipEventRecord(ev_[5], stream_));
+    // K3: alpha' rows
+    HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, mv, gamma, action_.as<int32_t>(), best_v_.as<int32_t>(), (int)B_,
+                              out_.as<T>(), S_, stream_));
+    HIPCHK(hipEventRecord(ev_[6], stream_));
+    // K5: belief dominance
+    if (flags & PBVI_BELIEF_DOMINANCE) {
+        if ((rc = value_max_device())) return rc;
+        HIPCHK(launch_keep<T>(bel_.as<T>(), S_pad_, out_.as<T>(), S_, (int)B_, S_, bs2_.as<double>(), keep_.as<uint8_t>(),
+                              stream_));
+    } else {
+        HIPCHK(hipMemsetAsync(keep_.p, 1, (size_t)B_, stream_));
+    }
+    HIPCHK(hipEventRecord(ev_[7], stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    have_result_ = true;
+    res_B_ = B_;
+
+    if (st) {
+        std::memset(st, 0, sizeof(*st));
+        float ms = 0.f;
+        auto el = [&](int i, int j) {
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, ev_[i], ev_[j]);
+            return (double)t;
+        };
+        (void)ms;
+        st->ms_project = el(0, 1);
+        st->ms_score = el(1, 2);
+        st->ms_argmax = el(2, 3);
+        st->ms_refine = el(3, 4);
+        st->ms_action = el(4, 5);
+        st->ms_assemble = el(5, 6);
+        st->ms_dominance = el(6, 7);
+        st->ms_total = el(0, 7);
+        st->n_pairs = pairs;
+        int h[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpy(h, counters_.p, sizeof(h), hipMemcpyDeviceToHost));
+        st->n_refined = h[0];
+        st->n_refined_actions = h[1];
+        if (kF32) {
+            std::vector<uint8_t> hd((size_t)pairs);
+            HIPCHK(hipMemcpy(hd.data(), dead_.p, (size_t)pairs, hipMemcpyDeviceToHost));
+            int64_t nd = 0;
+            for (uint8_t d : hd) nd += d;
+            st->n_dead = nd;
+        }
+        st->score_flops = 2 * B_ * (int64_t)S_ * AO * V_;
+        st->split_k = lay.split_k;
+    }
+    return PBVI_OK;
+}
+
+}  // namespace pbvi
+
+// --------------------------------------------------------------------------- //
+// C-ABI
+// --------------------------------------------------------------------------- //
+struct pbvi_engine {
+    pbvi::EngineBase* impl;
+};
+
+extern "C" {
+
+int pbvi_version(void) { return 100; }
+
+int pbvi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char* pbvi_last_error(void) { return pbvi::g_err.c_str(); }
+
+int pbvi_engine_create(pbvi_engine_t** out, int device, int32_t S, int32_t A, int32_t O, int32_t R,
+                       const int32_t* reach_states, const void* rto, const void* exp_reward, int dtype, int mode) {
+    using namespace pbvi;
+    if (!out) FAIL(PBVI_EINVAL, "engine_create: out is NULL");
+    *out = nullptr;
+    if (S <= 0 || A <= 0 || O <= 0 || R <= 0) FAIL(PBVI_EINVAL, "engine_create: S, A, O, R must be positive");
+    if (!reach_states || !rto || !exp_reward) FAIL(PBVI_EINVAL, "engine_create: NULL table");
+    if (dtype != PBVI_F32 && dtype != PBVI_F64) FAIL(PBVI_EINVAL, "engine_create: dtype must be PBVI_F32 or PBVI_F64");
+    if (mode != PBVI_SPARSE && mode != PBVI_DENSE) FAIL(PBVI_EINVAL, "engine_create: unknown mode");
+    if (mode == PBVI_DENSE) FAIL(PBVI_EUNSUPPORTED, "engine_create: dense projection mode is not built yet");
+    int ndev = pbvi_device_count();
+    if (ndev <= 0) FAIL(PBVI_ERUNTIME, "engine_create: no HIP device visible");
+    if (device < 0 || device >= ndev) FAIL(PBVI_EINVAL, "engine_create: device index out of range");
+    EngineBase* impl = nullptr;
+    int rc;
+    if (dtype == PBVI_F32) {
+        auto* e = new (std::nothrow) EngineT<float>();
+        if (!e) FAIL(PBVI_ENOMEM, "engine_create: host allocation failed");
+        rc = e->init(device, S, A, O, R, reach_states, (const float*)rto, (const float*)exp_reward, mode);
+        impl = e;
+    } else {
+        auto* e = new (std::nothrow) EngineT<double>();
+        if (!e) FAIL(PBVI_ENOMEM, "engine_create: host allocation failed");
+        rc = e->init(device, S, A, O, R, reach_states, (const double*)rto, (const double*)exp_reward, mode);
+        impl = e;
+    }
+    if (rc != PBVI_OK) {
+        delete impl;
+        return rc;
+    }
+    pbvi_engine* h = new (std::nothrow) pbvi_engine{impl};
+    if (!h) {
+        delete impl;
+        FAIL(PBVI_ENOMEM, "engine_create: host allocation failed");
+    }
+    *out = h;
+    return PBVI_OK;
+}
+
+void pbvi_engine_destroy(pbvi_engine_t* e) {
+    if (!e) return;
+    delete e->impl;
+    delete e;
+}
+
+#define NEED(e)                                            \
+    do {                                                   \
+        if (!(e) || !(e)->impl) {                          \
+            pbvi::set_error("NULL engine handle");         \
+            return PBVI_EINVAL;                            \
+        }                                                  \
+    } while (0)
+
+int pbvi_alpha_set(pbvi_engine_t* e, const void* alpha, int64_t V) {
+    NEED(e);
+    return e->impl->alpha_set(alpha, V);
+}
+int pbvi_alpha_append(pbvi_engine_t* e, const void* alpha, int64_t V_add) {
+    NEED(e);
+    return e->impl->alpha_append(alpha, V_add);
+}
+int64_t pbvi_alpha_count(const pbvi_engine_t* e) { return (e && e->impl) ? e->impl->alpha_count() : -1; }
+int pbvi_beliefs_set(pbvi_engine_t* e, const void* beliefs, int64_t B) {
+    NEED(e);
+    return e->impl->beliefs_set(beliefs, B);
+}
+int pbvi_backup_run(pbvi_engine_t* e, double gamma, int flags, pbvi_stats_t* stats) {
+    NEED(e);
+    return e->impl->backup_run(gamma, flags, stats);
+}
+int pbvi_backup_fetch(pbvi_engine_t* e, void* out_alpha, int32_t* out_action, int32_t* out_best_alpha, uint8_t* out_keep) {
+    NEED(e);
+    return e->impl->backup_fetch(out_alpha, out_action, out_best_alpha, out_keep);
+}
+int pbvi_backup_device_results(pbvi_engine_t* e, void** d_alpha, int32_t** d_action, uint8_t** d_keep) {
+    NEED(e);
+    return e->impl->device_results(d_alpha, d_action, d_keep);
+}
+int pbvi_backup(pbvi_engine_t* e, const void* beliefs, int64_t B, double gamma, int flags, void* out_alpha,
+                int32_t* out_action, int32_t* out_best_alpha, uint8_t* out_keep, pbvi_stats_t* stats) {
+    NEED(e);
+    int rc = e->impl->beliefs_set(beliefs, B);
+    if (rc) return rc;
+    rc = e->impl->backup_run(gamma, flags, stats);
+    if (rc) return rc;
+    return e->impl->backup_fetch(out_alpha, out_action, out_best_alpha, out_keep);
+}
+int pbvi_prune_dominated(pbvi_engine_t* e, uint8_t* keep) {
+    NEED(e);
+    return e->impl->prune_dominated(keep);
+}
+int pbvi_value_max(pbvi_engine_t* e, double* out_value, int32_t* out_index) {
+    NEED(e);
+    return e->impl->value_max(out_value, out_index);
+}
+int pbvi_set_tie_window(pbvi_engine_t* e, double rel) {
+    NEED(e);
+    return e->impl->set_tie_window(rel);
+}
+int64_t pbvi_device_bytes(const pbvi_engine_t* e) { return (e && e->impl) ? e->impl->device_bytes() : -1; }
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""Belief-sharded backup across the GPUs of one node.
+
+One process per GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI on the
+GPU box, ``gloo`` in the CPU tests).  Every rank holds the whole model and alpha set;
+the B beliefs are split into contiguous blocks of ceil(B/G) rows; after the local
+backup ONE all-gather moves the new alpha rows ``[B/G, S]`` (+ actions, keep mask) so
+every rank ends with the full ``[B, S]`` result in belief order and the replicas stay
+identical.  No other collective is on the data path.  The reference has no
+counterpart (single GPU, ``cupy.cuda.runtime.setDevice``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(n: int, world: int, rank: int):
+    """Contiguous block ``[lo, hi)`` of rank ``rank`` and the common padded block size."""
+    per = -(-n // world)
+    lo = min(rank * per, n)
+    hi = min(lo + per, n)
+    return lo, hi, per
+
+
+class ShardedBackup:
+    """Runs a backup sharded over the ranks of ``group`` and all-gathers the results.
+
+    ``local_backup(beliefs_local) -> (alpha_new[b,S], actions[b], keep[b])`` is the
+    per-rank work: on the GPU box it is the HIP engine writing straight into torch
+    CUDA tensors (``EngineShard``); the CPU tests pass the host NumPy path.
+    """
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def gather_rows(self, local_rows, local_actions, local_keep, n_total: int):
+        """All-gather per-rank blocks (padded to ceil(B/G) rows) and trim to ``n_total``."""
+        import torch
+        lo, hi, per = shard_bounds(n_total, self.world, self.rank)
+        S = local_rows.shape[1]
+        dev = local_rows.device
+
+        def padded(t, shape):
+            if t.shape[0] == per:
+                return t.contiguous()
+            out = torch.zeros(shape, dtype=t.dtype, device=dev)
+            out[: t.shape[0]] = t
+            return out
+
+        rows = padded(local_rows, (per, S))
+        acts = padded(local_actions, (per,))
+        keep = padded(local_keep, (per,))
+        all_rows = torch.empty((self.world * per, S), dtype=rows.dtype, device=dev)
+        all_acts = torch.empty((self.world * per,), dtype=acts.dtype, device=dev)
+        all_keep = torch.empty((self.world * per,), dtype=keep.dtype, device=dev)
+        self.dist.all_gather_into_tensor(all_rows, rows, group=self.group)
+        self.dist.all_gather_into_tensor(all_acts, acts, group=self.group)
+        self.dist.all_gather_into_tensor(all_keep, keep, group=self.group)
+        return all_rows[:n_total], all_acts[:n_total], all_keep[:n_total]
+
+    def run(self, local_backup, beliefs_all: np.ndarray):
+        """Shard ``beliefs_all`` [B,S] by rank, run the local backup, all-gather."""
+        import torch
+        n = beliefs_all.shape[0]
+        lo, hi, _ = shard_bounds(n, self.world, self.rank)
+        rows, acts, keep = local_backup(beliefs_all[lo:hi])
+        if not torch.is_tensor(rows):
+            rows = torch.from_numpy(np.ascontiguousarray(rows))
+            acts = torch.from_numpy(np.ascontiguousarray(acts, dtype=np.int64))
+            keep = torch.from_numpy(np.ascontiguousarray(keep, dtype=np.uint8))
+        return self.gather_rows(rows, acts, keep, n)
+
+
+class EngineShard:
+    """Per-rank adapter: HIP engine results copied device-to-device into torch CUDA
+    tensors that RCCL can send (torch is only the carrier of device memory here)."""
+
+    def __init__(self, engine, gamma: float, belief_dominance_prune: bool = False):
+        import torch
+        self.torch = torch
+        self.engine = engine
+        self.gamma = gamma
+        self.prune = belief_dominance_prune
+        self.device = torch.device('cuda', engine.device)
+        self._bufs = None
+
+    def buffers(self, b: int):
+        t = self.torch
+        if self._bufs is None or self._bufs[0].shape[0] != b:
+            dt = t.float32 if self.engine.dtype == 'f32' else t.float64
+            self._bufs = (t.empty((b, self.engine.S), dtype=dt, device=self.device),
+                          t.empty((b,), dtype=t.int32, device=self.device),
+                          t.empty((b,), dtype=t.uint8, device=self.device))
+        return self._bufs
+
+    def run_resident(self):
+        """Backup of the belief block already resident on this rank's engine."""
+        stats = self.engine.run(self.gamma, self.prune)
+        rows, acts, keep = self.buffers(self.engine.B)
+        self.engine.fetch_into(rows.data_ptr(), acts.data_ptr(), keep.data_ptr())
+        return rows, acts, keep, stats
+
+    def __call__(self, beliefs_local: np.ndarray):
+        self.engine.set_beliefs(beliefs_local)
+        rows, acts, keep, _ = self.run_resident()
+        return rows, acts, keep

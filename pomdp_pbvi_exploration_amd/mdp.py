@@ -1,0 +1,406 @@
+"""Host-side mirror of the reference's ``src/mdp.py`` for the backup path.
+
+Only what the PBVI backup path and its callers need is here: ``log``, the MDP
+``Model`` (reachable-state tables), ``AlphaVector`` / ``ValueFunction`` (the
+backup's output contract: byte-exact dedup, new-then-old union, level-2
+domination prune) and ``VI_Solver`` (seeds FSVI/HSVI).  Plotting, simulation and
+file persistence of the reference are out of scope.
+
+Device residency replaces the reference's CuPy twins (``src/mdp.py:533-590``,
+``:782-831``): ``Model.gpu_model`` returns a twin bound to a HIP engine handle
+(``engine.Engine``); arrays stay NumPy on the host and the engine owns the
+device copies.  If the HIP library cannot be loaded, asking for the GPU twin
+raises -- there is no silent CPU fallback.
+"""
+from __future__ import annotations
+
+from datetime import datetime
+from typing import Union
+
+import numpy as np
+
+gpu_support = True   # the HIP engine is always the GPU backend; loading errors surface on first use
+
+
+def log(content: str) -> None:
+    """Timestamped print (``src/mdp.py:40-49``)."""
+    print(f'[{datetime.now().strftime("%m/%d/%Y, %H:%M:%S")}] ' + content)
+
+
+_QUIET = [False]
+
+
+def set_quiet(q: bool = True) -> None:
+    """Silence model-construction logging (tests / bench)."""
+    _QUIET[0] = bool(q)
+
+
+def _log(msg: str) -> None:
+    if not _QUIET[0]:
+        log(msg)
+
+
+class Model:
+    """MDP model with the reachable-state (padded-ELL) transition representation.
+
+    Mirrors ``src/mdp.py:52-408``: same constructor arguments and attributes
+    (``states, actions, transition_table, reachable_states,
+    reachable_probabilities, reachable_state_count, expected_rewards_table,
+    start_probabilities, end_states, end_actions, is_on_gpu, gpu_model,
+    cpu_model``).
+    """
+
+    def __init__(self, states, actions, transitions=None, reachable_states=None, rewards=None,
+                 rewards_are_probabilistic: bool = False, state_grid=None, start_probabilities=None,
+                 end_states: list = [], end_actions: list = []):
+        self._alt_model = None
+        self.is_on_gpu = False
+        self._engine = None
+        self._engine_dtype = None
+
+        # states
+        self.state_grid = None
+        if isinstance(states, int):
+            self.state_labels = [f's_{i}' for i in range(states)]
+        elif isinstance(states, list) and states and all(isinstance(r, list) for r in states):
+            width = len(states[0])
+            assert all(len(r) == width for r in states), "All sublists of states must be of equal size"
+            self.state_labels = [lab for r in states for lab in r]
+            self.state_grid = np.arange(len(states) * width).reshape(len(states), width)
+        else:
+            self.state_labels = [lab for lab in states if isinstance(lab, str)]
+        self.state_count = len(self.state_labels)
+        self.states = np.arange(self.state_count)
+
+        # actions
+        self.action_labels = [f'a_{i}' for i in range(actions)] if isinstance(actions, int) else actions
+        self.action_count = len(self.action_labels)
+        self.actions = np.arange(self.action_count)
+        _log(f'MDP model: {self.state_count} states, {self.action_count} actions')
+
+        S, A = self.state_count, self.action_count
+
+        # transitions
+        self.reachable_states = None
+        if reachable_states is not None:
+            self.reachable_states = np.array(reachable_states)
+            assert self.reachable_states.shape[:2] == (S, A), \
+                f"Reachable states provided is not of the expected shape (received {self.reachable_states.shape}, expected ({S}, {A}, :))"
+            self.reachable_state_count = self.reachable_states.shape[2]
+
+        self.transition_table = None
+        self.transition_function = None
+        if transitions is None:
+            if reachable_states is None:
+                rnd = np.random.rand(S, A, S)
+                self.transition_table = rnd / np.sum(rnd, axis=2, keepdims=True)
+        elif callable(transitions):
+            self.transition_function = transitions
+            try:
+                self.transition_table = np.fromfunction(transitions, (S, A, S))
+            except MemoryError:
+                _log('    > [Warning] Not enough memory to store transition table, using transition function provided...')
+        else:
+            self.transition_table = np.array(transitions)
+            assert self.transition_table.shape == (S, A, S), \
+                f"Transitions table provided doesnt have the right shape, it should be SxAxS (expected {(S, A, S)}, received {self.transition_table.shape})"
+
+        self.rewards_are_probabilistic = rewards_are_probabilistic
+
+        # grid
+        if state_grid is not None:
+            self.state_grid = np.array(state_grid)
+        elif self.state_grid is None:
+            self.state_grid = np.arange(S).reshape((1, S))
+
+        # start distribution
+        if start_probabilities is not None:
+            assert len(start_probabilities) == S
+            self.start_probabilities = np.array(start_probabilities, dtype=float)
+        else:
+            self.start_probabilities = np.full(S, 1 / S)
+
+        self.end_states = end_states
+        self.end_actions = end_actions
+
+        # reachable states derived from the dense table (pad with unused low indices, prob 0)
+        if self.reachable_states is None:
+            per_pair = []
+            for s in range(S):
+                row = []
+                for a in range(A):
+                    if self.transition_table is not None:
+                        row.append(np.flatnonzero(self.transition_table[s, a, :] > 0).tolist())
+                    else:
+                        row.append([sn for sn in range(S) if self.transition_function(s, a, sn) > 0])
+                per_pair.append(row)
+            self.reachable_state_count = max(len(l) for row in per_pair for l in row)
+            for row in per_pair:
+                for l in row:
+                    filler = 0
+                    while len(l) < self.reachable_state_count:
+                        if filler not in l:
+                            l.append(filler)
+                        filler += 1
+            self.reachable_states = np.array(per_pair, dtype=int)
+        _log(f'- at most {self.reachable_state_count} reachable states per state-action pair')
+
+        if self.transition_table is not None:
+            self.reachable_probabilities = self.transition_table[self.states[:, None, None],
+                                                                 self.actions[None, :, None],
+                                                                 self.reachable_states]
+        elif self.transition_function is not None:
+            rs = self.reachable_states
+            self.reachable_probabilities = np.fromfunction(
+                lambda s, a, r: self.transition_function(s.astype(int), a.astype(int),
+                                                         rs[s.astype(int), a.astype(int), r.astype(int)]), rs.shape)
+        else:
+            self.reachable_probabilities = np.full(self.reachable_states.shape, 1 / self.reachable_state_count)
+
+        # rewards (skipped when the POMDP subclass defines them: rewards == -1)
+        self.immediate_reward_table = None
+        self.immediate_reward_function = None
+        self._min_reward = None
+        self._max_reward = None
+        self.expected_rewards_table = None
+        if isinstance(rewards, int) and rewards == -1:
+            return
+        if rewards is None:
+            if len(self.end_states) > 0 or len(self.end_actions) > 0:
+                self.immediate_reward_function = self._end_reward_function
+            else:
+                self.immediate_reward_table = np.random.rand(S, A, S)
+        elif callable(rewards):
+            self.immediate_reward_function = rewards
+        else:
+            self.immediate_reward_table = np.array(rewards)
+            assert self.immediate_reward_table.shape == (S, A, S), "Rewards table doesnt have the right shape, it should be SxAxS"
+        if self.immediate_reward_table is not None:
+            reach_r = self.immediate_reward_table[self.states[:, None, None], self.actions[None, :, None], self.reachable_states]
+        else:
+            rs = self.reachable_states
+            reach_r = np.fromfunction(lambda s, a, r: self.immediate_reward_function(
+                s.astype(int), a.astype(int), rs[s.astype(int), a.astype(int), r.astype(int)]), rs.shape)
+        self._min_reward = float(np.min(reach_r))
+        self._max_reward = float(np.max(reach_r))
+        self.expected_rewards_table = np.einsum('sar,sar->sa', self.reachable_probabilities, reach_r)
+
+    def _end_reward_function(self, s, a, sn):
+        return (np.isin(sn, self.end_states) | np.isin(a, self.end_actions)).astype(int)
+
+    def transition(self, s: int, a: int) -> int:
+        """Sample a successor state (``src/mdp.py:415-438``)."""
+        if self.reachable_state_count == 1:
+            return int(self.reachable_states[s, a, 0])
+        return int(np.random.choice(a=self.reachable_states[s, a], size=1, p=self.reachable_probabilities[s, a])[0])
+
+    # -- residency ------------------------------------------------------- #
+    def to_gpu(self, dtype: str = 'f64', device: int = 0) -> 'Model':
+        """GPU twin bound to a HIP engine of the given arithmetic type."""
+        if self.is_on_gpu:
+            return self
+        if self._alt_model is None or self._alt_model._engine_dtype != dtype:
+            from .engine import Engine          # raises if the HIP library is missing
+            twin = object.__new__(self.__class__)
+            twin.__dict__.update(self.__dict__)
+            twin.is_on_gpu = True
+            twin._alt_model = self
+            twin._engine_dtype = dtype
+            twin._engine = Engine.for_model(self, dtype=dtype, device=device)
+            self._alt_model = twin
+        return self._alt_model
+
+    @property
+    def gpu_model(self) -> 'Model':
+        return self.to_gpu(self._alt_model._engine_dtype if (self._alt_model is not None and not self.is_on_gpu) else 'f64')
+
+    @property
+    def cpu_model(self) -> 'Model':
+        return self._alt_model if self.is_on_gpu else self
+
+    @property
+    def engine(self):
+        assert self.is_on_gpu, "model is not on the GPU; use model.gpu_model"
+        return self._engine
+
+
+class AlphaVector:
+    """One hyperplane over the state space and its action (``src/mdp.py:593-608``)."""
+
+    def __init__(self, values: np.ndarray, action: int) -> None:
+        self.values = values
+        self.action = int(action)
+
+
+class ValueFunction:
+    """A set of alpha-vectors with the reference's container semantics.
+
+    * constructor dedup keyed on the row's exact bytes -- first position, last
+      action wins (``src/mdp.py:660-669``);
+    * ``extend``: this set's vectors first, then the other's; on identical bytes
+      the other's object replaces ours in place (``src/mdp.py:763-779``);
+    * ``prune(level=2)``: drop every row some other row dominates point-wise
+      (``src/mdp.py:857-866``); runs on the HIP engine when the set is on the GPU.
+    """
+
+    def __init__(self, model: Model, alpha_vectors: Union[list, np.ndarray] = [], action_list=[]):
+        self.model = model
+        self._vector_array = None
+        self._actions = None
+        self.is_on_gpu = bool(getattr(model, 'is_on_gpu', False))
+        if isinstance(alpha_vectors, list):
+            assert all(v.values.shape[0] == model.state_count for v in alpha_vectors), \
+                f"Some or all alpha vectors in the list provided dont have the right size, they should be of shape: {model.state_count}"
+            vectors = alpha_vectors
+        else:
+            expected = (len(action_list), model.state_count)
+            assert alpha_vectors.shape == expected, \
+                f"Alpha vector array does not have the right shape (received: {alpha_vectors.shape}; expected: {expected})"
+            vectors = [AlphaVector(row, act) for row, act in zip(alpha_vectors, action_list)]
+        self._uniqueness_dict = {v.values.tobytes(): v for v in vectors}
+        self._vector_list = list(self._uniqueness_dict.values())
+        self._pruning_level = 1
+
+    @property
+    def alpha_vector_list(self) -> list:
+        if self._vector_list is None:
+            self._vector_list = [AlphaVector(r, a) for r, a in zip(self._vector_array, self._actions)]
+        return self._vector_list
+
+    def _materialise(self) -> None:
+        if self._vector_array is None:
+            if len(self._vector_list) == 0:
+                self._vector_array = np.zeros((0, self.model.state_count))
+            else:
+                self._vector_array = np.array([v.values for v in self._vector_list])
+            self._actions = np.array([v.action for v in self._vector_list], dtype=int)
+
+    @property
+    def alpha_vector_array(self) -> np.ndarray:
+        self._materialise()
+        return self._vector_array
+
+    @property
+    def actions(self) -> np.ndarray:
+        self._materialise()
+        return self._actions
+
+    def __len__(self) -> int:
+        return len(self._vector_list) if self._vector_list is not None else self._vector_array.shape[0]
+
+    def __add__(self, other: 'ValueFunction') -> 'ValueFunction':
+        out = object.__new__(self.__class__)
+        out.model = self.model
+        out.is_on_gpu = self.is_on_gpu
+        out._uniqueness_dict = {**self._uniqueness_dict, **other._uniqueness_dict}
+        out._vector_list = list(out._uniqueness_dict.values())
+        out._vector_array = None
+        out._actions = None
+        out._pruning_level = 1
+        return out
+
+    def append(self, alpha_vector: AlphaVector) -> None:
+        assert alpha_vector.values.shape[0] == self.model.state_count, "Vector to add to value function doesn't have the right size"
+        self._uniqueness_dict[alpha_vector.values.tobytes()] = alpha_vector
+        self._vector_list = list(self._uniqueness_dict.values())
+        self._vector_array = None
+        self._actions = None
+
+    def extend(self, other: 'ValueFunction') -> None:
+        self._uniqueness_dict.update(other._uniqueness_dict)
+        self._vector_list = list(self._uniqueness_dict.values())
+        self._vector_array = None
+        self._actions = None
+        self._pruning_level = 1
+
+    def to_gpu(self) -> 'ValueFunction':
+        gm = self.model.gpu_model
+        return ValueFunction(gm, [AlphaVector(v.values, v.action) for v in self.alpha_vector_list])
+
+    def to_cpu(self) -> 'ValueFunction':
+        cm = self.model.cpu_model
+        return ValueFunction(cm, [AlphaVector(np.asarray(v.values, dtype=np.float64), v.action) for v in self.alpha_vector_list])
+
+    def prune(self, level: int = 1) -> None:
+        if level < self._pruning_level or level > 3:
+            log("Attempting to prune a value function to a level already reached. Returning 'self'")
+            return
+        if level >= 3:
+            raise NotImplementedError("LP pruning (level 3) is broken in the reference (src/mdp.py:872) and not provided")
+        if level >= 2 and self._pruning_level < 2:
+            arr = self.alpha_vector_array
+            if self.is_on_gpu:
+                keep = self.model.engine.prune_dominated(arr)
+            else:
+                keep = np.zeros(arr.shape[0], dtype=bool)
+                for i, v in enumerate(arr):
+                    keep[i] = np.count_nonzero(np.all(arr >= v, axis=1)) == 1
+            self._vector_array = arr[keep]
+            self._actions = self._actions[keep]
+            self._vector_list = None
+            self._uniqueness_dict = {r.tobytes(): AlphaVector(r, a) for r, a in zip(self._vector_array, self._actions)}
+            self._vector_list = list(self._uniqueness_dict.values())
+        self._pruning_level = level
+
+
+class SolverHistory:
+    """Timing / size bookkeeping of a value-iteration run (subset of ``src/mdp.py:1281-1400``)."""
+
+    def __init__(self, tracking_level: int, model: Model, gamma: float, eps: float, initial_value_function=None):
+        self.tracking_level = tracking_level
+        self.model = model
+        self.gamma = gamma
+        self.eps = eps
+        self.run_ts = datetime.now()
+        self.iteration_times = []
+        self.value_function_changes = []
+        self.value_functions = [initial_value_function] if tracking_level >= 2 else []
+
+    def add(self, iteration_time: float, value_function_change: float, value_function) -> None:
+        if self.tracking_level >= 1:
+            self.iteration_times.append(float(iteration_time))
+            self.value_function_changes.append(float(value_function_change))
+        if self.tracking_level >= 2:
+            self.value_functions.append(value_function)
+
+    @property
+    def summary(self) -> str:
+        return (f'Summary of Value Iteration run\n  - Model: {self.model.state_count}-state, {self.model.action_count}-action\n'
+                f'  - Converged or stopped after {len(self.iteration_times)} iterations and {sum(self.iteration_times):.4f}s\n')
+
+
+class Solver:
+    def solve(self, model):
+        raise Exception("Method has to be implemented by subclass...")
+
+
+class VI_Solver(Solver):
+    """MDP value iteration (``src/mdp.py:1414-1525``); host-side, seeds FSVI/HSVI."""
+
+    def __init__(self, horizon: int = 10000, gamma: float = 0.99, eps: float = 0.001):
+        self.horizon = horizon
+        self.gamma = gamma
+        self.eps = eps
+
+    def solve(self, model: Model, initial_value_function=None, use_gpu: bool = False,
+              history_tracking_level: int = 1, print_progress: bool = True):
+        host = model.cpu_model
+        if initial_value_function is None:
+            V = ValueFunction(host, host.expected_rewards_table.T, host.actions)
+        else:
+            V = initial_value_function
+        v_opt = np.max(V.alpha_vector_array, axis=0)
+        hist = SolverHistory(history_tracking_level, host, self.gamma, self.eps, V)
+        limit = self.eps * (self.gamma / (1 - self.gamma))
+        er_t = host.expected_rewards_table.T
+        for _ in range(self.horizon):
+            t0 = datetime.now()
+            prev = v_opt
+            rows = er_t + self.gamma * np.einsum('sar,sar->as', host.reachable_probabilities, v_opt[host.reachable_states])
+            V = ValueFunction(host, rows, host.actions)
+            v_opt = np.max(V.alpha_vector_array, axis=0)
+            change = float(np.max(np.abs(v_opt - prev)))
+            hist.add((datetime.now() - t0).total_seconds(), change, V)
+            if change < limit:
+                break
+        return V, hist

@@ -1,0 +1,755 @@
+"""Host-side mirror of the reference's ``src/pomdp.py`` around the backup path.
+
+Same class names, signatures and container semantics as the reference so its
+notebooks' ``from src.pomdp import *`` keeps working (``src/`` at the repo root
+re-exports this module).  What differs is the seam the reference implements with
+CuPy array-module dispatch (``src/pomdp.py:1482``, ``:2243-2264``): here
+``use_gpu=True`` / ``.gpu_model`` / ``.to_gpu()`` bind the objects to a HIP
+engine (``engine.Engine``) and ``PBVI_Solver.backup`` then runs on hand-written
+gfx950 kernels through the C-ABI of ``include/pbvi_hip.h``.  With
+``use_gpu=False`` the NumPy statements of the reference run on the host
+(BASELINE config 0).  A GPU request never degrades to the CPU path: if the HIP
+library is missing the call raises.
+"""
+from __future__ import annotations
+
+import copy            # noqa: F401  (notebooks rely on these leaked names)
+import random
+from datetime import datetime
+from typing import Tuple, Union
+
+import numpy as np
+
+from .mdp import AlphaVector, ValueFunction, VI_Solver, log, _log, set_quiet   # noqa: F401
+from .mdp import Model as MDP_Model
+from .mdp import Solver as MDP_Solver
+
+gpu_support = True
+
+
+class Model(MDP_Model):
+    """POMDP model: MDP tables + observation table, fused ``RTO[s,a,o,r]`` and
+    ``expected_rewards_table[s,a]`` (``src/pomdp.py:147-254``)."""
+
+    def __init__(self, states, actions, observations, transitions=None, reachable_states=None, rewards=None,
+                 observation_table=None, rewards_are_probabilistic: bool = False, state_grid=None,
+                 start_probabilities=None, end_states: list = [], end_actions: list = []):
+        super().__init__(states=states, actions=actions, transitions=transitions, reachable_states=reachable_states,
+                         rewards=-1, rewards_are_probabilistic=rewards_are_probabilistic, state_grid=state_grid,
+                         start_probabilities=start_probabilities, end_states=end_states, end_actions=end_actions)
+        S, A = self.state_count, self.action_count
+        self.observation_labels = [f'o_{i}' for i in range(observations)] if isinstance(observations, int) else observations
+        self.observation_count = len(self.observation_labels)
+        self.observations = np.arange(self.observation_count)
+        O = self.observation_count
+
+        if observation_table is None:
+            rnd = np.random.rand(S, A, O)
+            self.observation_table = rnd / np.sum(rnd, axis=2, keepdims=True)
+        else:
+            self.observation_table = np.array(observation_table)
+            assert self.observation_table.shape == (S, A, O), \
+                f"Observations table doesnt have the right shape, it should be SxAxO (expected: {(S, A, O)}, received: {self.observation_table.shape})."
+        _log(f'POMDP model: {O} observations')
+
+        rs = self.reachable_states
+        reach_obs = self.observation_table[rs[:, :, None, :], self.actions[None, :, None, None], self.observations[None, None, :, None]]
+        self.reachable_transitional_observation_table = np.einsum('sar,saor->saor', self.reachable_probabilities, reach_obs)
+
+        self.immediate_reward_table = None
+        self.immediate_reward_function = None
+        if rewards is None:
+            if len(self.end_states) > 0 or len(self.end_actions) > 0:
+                self.immediate_reward_function = self._end_reward_function
+            else:
+                self.immediate_reward_table = np.random.rand(S, A, S, O)
+        elif callable(rewards):
+            self.immediate_reward_function = rewards
+        else:
+            self.immediate_reward_table = np.array(rewards)
+            assert self.immediate_reward_table.shape == (S, A, S, O), \
+                f"Rewards table doesnt have the right shape, it should be SxAxSxO (expected: {(S, A, S, O)}, received {self.immediate_reward_table.shape})"
+
+        if self.immediate_reward_table is not None:
+            reach_r = self.immediate_reward_table[self.states[:, None, None, None], self.actions[None, :, None, None],
+                                                  rs[:, :, :, None], self.observations[None, None, None, :]]
+        else:
+            reach_r = np.fromfunction(lambda s, a, r, o: self.immediate_reward_function(
+                s.astype(int), a.astype(int), rs[s.astype(int), a.astype(int), r.astype(int)], o.astype(int)), (*rs.shape, O))
+        self._min_reward = float(np.min(reach_r))
+        self._max_reward = float(np.max(reach_r))
+        self.expected_rewards_table = np.einsum('saor,saro->sa', self.reachable_transitional_observation_table, reach_r)
+
+    def _end_reward_function(self, s, a, sn, o):
+        return (np.isin(sn, self.end_states) | np.isin(a, self.end_actions)).astype(int)
+
+    def observe(self, s_p: int, a: int) -> int:
+        return int(np.random.choice(a=self.observations, size=1, p=self.observation_table[s_p, a])[0])
+
+
+class Belief:
+    """Probability distribution over states; Bayes update through the
+    reachable-state tables (``src/pomdp.py:311-421``)."""
+
+    def __new__(cls, *args, **kwargs):
+        inst = super().__new__(cls)
+        inst._bytes_repr = None
+        inst._successors = {}
+        return inst
+
+    def __init__(self, model: Model, values: Union[np.ndarray, None] = None):
+        assert model is not None
+        self.model = model
+        if values is not None:
+            assert values.shape[0] == model.state_count, "Belief must contain be of dimension |S|"
+            total = np.sum(values)
+            assert np.round(total, decimals=3) == 1.0, f"States probabilities in belief must sum to 1 (found: {total})"
+            self._values = values
+        else:
+            self._values = model.start_probabilities
+
+    @property
+    def values(self) -> np.ndarray:
+        return self._values
+
+    @property
+    def bytes_repr(self) -> bytes:
+        if self._bytes_repr is None:
+            self._bytes_repr = self.values.tobytes()
+        return self._bytes_repr
+
+    def __eq__(self, other) -> bool:
+        return self.bytes_repr == other.bytes_repr
+
+    def update(self, a: int, o: int) -> 'Belief':
+        key = f'{a}_{o}'
+        hit = self._successors.get(key)
+        if hit is not None:
+            return hit
+        m = self.model
+        weights = m.reachable_transitional_observation_table[:, a, o, :] * self.values[:, None]
+        nxt = np.bincount(m.reachable_states[:, a, :].flatten(), weights=weights.flatten(), minlength=m.state_count)
+        nxt /= np.sum(nxt)
+        out = self.__new__(self.__class__)
+        out.model = m
+        out._values = nxt
+        self._successors[key] = out
+        return out
+
+    def generate_successors(self) -> list:
+        return [self.update(a, o) for a in self.model.actions for o in self.model.observations]
+
+    def random_state(self) -> int:
+        return int(np.random.choice(a=self.model.states, size=1, p=self._values)[0])
+
+
+class BeliefSet:
+    """A set of beliefs as a list and as a B x S matrix (``src/pomdp.py:489-659``)."""
+
+    def __init__(self, model: Model, beliefs: Union[list, np.ndarray]) -> None:
+        self.model = model
+        self._belief_array = None
+        self._uniqueness_dict = None
+        self.is_on_gpu = bool(getattr(model, 'is_on_gpu', False))
+        if isinstance(beliefs, list):
+            assert all(len(b.values) == model.state_count for b in beliefs), \
+                f"Beliefs in belief list provided dont all have shape ({model.state_count},)"
+            self._belief_list = beliefs
+        else:
+            assert beliefs.shape[1] == model.state_count, \
+                f"Belief array provided doesnt have the right shape (expected (-,{model.state_count}), received {beliefs.shape})"
+            self._belief_list = [Belief(model, row) for row in beliefs]
+
+    @property
+    def belief_array(self) -> np.ndarray:
+        if self._belief_array is None:
+            self._belief_array = np.array([b.values for b in self._belief_list])
+        return self._belief_array
+
+    @property
+    def belief_list(self) -> list:
+        if self._belief_list is None:
+            self._belief_list = [Belief(self.model, row) for row in self._belief_array]
+        return self._belief_list
+
+    def generate_all_successors(self) -> 'BeliefSet':
+        succ = []
+        for b in self.belief_list:
+            succ.extend(b.generate_successors())
+        return BeliefSet(self.model, succ)
+
+    @property
+    def unique_belief_dict(self) -> dict:
+        if self._uniqueness_dict is None:
+            self._uniqueness_dict = {b.bytes_repr: b for b in self.belief_list}
+        return self._uniqueness_dict
+
+    def union(self, other: 'BeliefSet') -> 'BeliefSet':
+        merged = self.unique_belief_dict | other.unique_belief_dict
+        out = BeliefSet(self.model, list(merged.values()))
+        out._uniqueness_dict = merged
+        return out
+
+    def __len__(self) -> int:
+        return len(self._belief_list) if self._belief_list is not None else self._belief_array.shape[0]
+
+    def to_gpu(self) -> 'BeliefSet':
+        gm = self.model.gpu_model
+        out = BeliefSet(gm, [Belief(gm, b.values) for b in self.belief_list])
+        return out
+
+    def to_cpu(self) -> 'BeliefSet':
+        cm = self.model.cpu_model
+        return BeliefSet(cm, [Belief(cm, b.values) for b in self.belief_list])
+
+
+class SolverHistory:
+    """Times and sizes of a PBVI run (subset of ``src/pomdp.py:898-1117``)."""
+
+    def __init__(self, tracking_level, model, gamma, eps, expand_function, expand_append,
+                 initial_value_function, initial_belief_set):
+        self.tracking_level = tracking_level
+        self.model = model
+        self.gamma = gamma
+        self.eps = eps
+        self.run_ts = datetime.now()
+        self.expand_function = expand_function
+        self.expand_append = expand_append
+        self.expansion_times = []
+        self.backup_times = []
+        self.pruning_times = []
+        self.alpha_vector_counts = []
+        self.beliefs_counts = []
+        self.value_function_changes = []
+        self.prune_counts = []
+        self.value_functions = []
+        self.belief_sets = []
+        if tracking_level >= 1:
+            self.alpha_vector_counts.append(len(initial_value_function))
+            self.beliefs_counts.append(len(initial_belief_set))
+        if tracking_level >= 2:
+            self.value_functions.append(initial_value_function)
+            self.belief_sets.append(initial_belief_set)
+
+    def add_expand_step(self, expansion_time: float, belief_set: BeliefSet) -> None:
+        if self.tracking_level >= 1:
+            self.expansion_times.append(float(expansion_time))
+            self.beliefs_counts.append(len(belief_set))
+        if self.tracking_level >= 2:
+            self.belief_sets.append(belief_set)
+
+    def add_backup_step(self, backup_time: float, value_function_change: float, value_function: ValueFunction) -> None:
+        if self.tracking_level >= 1:
+            self.backup_times.append(float(backup_time))
+            self.alpha_vector_counts.append(len(value_function))
+            self.value_function_changes.append(float(value_function_change))
+        if self.tracking_level >= 2:
+            self.value_functions.append(value_function)
+
+    def add_prune_step(self, prune_time: float, alpha_vectors_pruned: int) -> None:
+        if self.tracking_level >= 1:
+            self.pruning_times.append(prune_time)
+            self.prune_counts.append(alpha_vectors_pruned)
+
+    @property
+    def solution(self) -> ValueFunction:
+        assert self.tracking_level >= 2, "Tracking level is set too low, increase it to 2 if you want to have value function tracking as well."
+        return self.value_functions[-1]
+
+    @property
+    def summary(self) -> str:
+        n_b, n_e = len(self.backup_times), len(self.expansion_times)
+        s = f'Summary of Point Based Value Iteration run\n'
+        s += f'  - Model: {self.model.state_count} state, {self.model.action_count} action, {self.model.observation_count} observations\n'
+        s += f'  - Converged or stopped after {n_e} expansion steps and {n_b} backup steps.\n'
+        if n_b and n_e:
+            s += f'  - Resulting value function has {self.alpha_vector_counts[-1]} alpha vectors.\n'
+            s += f'  - Converged in {sum(self.expansion_times) + sum(self.backup_times):.4f}s\n\n'
+            s += f'  - Expand function took on average {sum(self.expansion_times) / n_e:.4f}s\n'
+            s += f'  - Backup function took on average {sum(self.backup_times) / n_b:.4f}s\n'
+        return s
+
+
+class Solver(MDP_Solver):
+    def solve(self, model):
+        raise Exception("Method has to be implemented by subclass...")
+
+
+class PBVI_Solver(Solver):
+    """Point-Based Value Iteration (``src/pomdp.py:1301-2413``).
+
+    ``backup`` is the hot path.  On GPU-resident inputs it is one call into the
+    HIP engine; on host inputs it is the reference's NumPy statement sequence.
+    """
+
+    def __init__(self, gamma: float = 0.99, eps: float = 0.001, expand_function: str = 'ssea', **expand_function_params):
+        self.gamma = gamma
+        self.eps = eps
+        self.expand_function = expand_function
+        self.expand_function_params = expand_function_params
+
+    # ------------------------------------------------------------------ #
+    # hot path
+    # ------------------------------------------------------------------ #
+    def backup(self, model: Model, belief_set: BeliefSet, value_function: ValueFunction,
+               append: bool = False, belief_dominance_prune: bool = True) -> ValueFunction:
+        """One point-based backup (``src/pomdp.py:1447-1524``): B beliefs x V
+        alpha-vectors -> at most B new alpha-vectors (+ union with the old set)."""
+        if value_function.is_on_gpu:
+            eng = value_function.model.engine
+            alpha_new, actions, keep = eng.backup(value_function.alpha_vector_array, belief_set.belief_array,
+                                                  self.gamma, belief_dominance_prune=belief_dominance_prune)
+            if keep is not None:
+                alpha_new, actions = alpha_new[keep], actions[keep]
+            new_vf = ValueFunction(value_function.model, alpha_new, actions)
+        else:
+            alpha_new, actions = self._backup_numpy(model, belief_set.belief_array, value_function.alpha_vector_array,
+                                                    belief_dominance_prune)
+            new_vf = ValueFunction(model, alpha_new, actions)
+        if append:
+            new_vf.extend(value_function)
+        return new_vf
+
+    def _backup_numpy(self, model, b, alpha, belief_dominance_prune):
+        """Host path: the reference's array statements (``src/pomdp.py:1485-1515``)."""
+        V = alpha.shape[0]
+        alpha_r = alpha[np.arange(V)[:, None, None, None], model.reachable_states[None, :, :, :]]
+        gamma_aovs = self.gamma * np.einsum('saor,vsar->aovs', model.reachable_transitional_observation_table, alpha_r)
+        pick = np.argmax(np.tensordot(b, gamma_aovs, (1, 3)), axis=3)
+        per_o = gamma_aovs[model.actions[None, :, None, None], model.observations[None, None, :, None],
+                           pick[:, :, :, None], model.states[None, None, None, :]]
+        alpha_a = model.expected_rewards_table.T + np.sum(per_o, axis=2)
+        acts = np.argmax(np.einsum('bas,bs->ba', alpha_a, b), axis=1)
+        rows = np.take_along_axis(alpha_a, acts[:, None, None], axis=1)[:, 0, :]
+        if belief_dominance_prune:
+            new_val = np.sum(b * rows, axis=1)
+            old_val = np.max(np.matmul(b, alpha.T), axis=1)
+            better = new_val > old_val
+            rows, acts = rows[better], acts[better]
+        return rows, acts
+
+    # ------------------------------------------------------------------ #
+    # belief expansion (host side; out of the accelerated path)
+    # ------------------------------------------------------------------ #
+    def expand_ra(self, model, belief_set, max_generation: int = 10) -> BeliefSet:
+        n = min(belief_set.belief_array.shape[0], max_generation)
+        nb = np.random.random((n, model.state_count))
+        nb /= np.sum(nb, axis=1)[:, None]
+        return BeliefSet(model, nb)
+
+    def _sim_step(self, model, b: Belief, a: int) -> Belief:
+        s = b.random_state()
+        s_p = model.transition(s, a)
+        return b.update(a, model.observe(s_p, a))
+
+    def expand_ssra(self, model, belief_set, max_generation: int = 10) -> BeliefSet:
+        arr = belief_set.belief_array
+        n = min(max_generation, arr.shape[0])
+        picks = np.random.choice(np.arange(arr.shape[0]), n, replace=False)
+        out = np.empty((n, arr.shape[1]))
+        for i, row in enumerate(arr[picks]):
+            b = Belief(model, row)
+            s = b.random_state()
+            a = random.choice(model.actions)
+            s_p = model.transition(s, a)
+            out[i] = b.update(a, model.observe(s_p, a)).values
+        return BeliefSet(model, out)
+
+    def expand_ssga(self, model, belief_set, value_function, epsilon: float = 0.1, max_generation: int = 10) -> BeliefSet:
+        arr = belief_set.belief_array
+        n = min(max_generation, arr.shape[0])
+        picks = np.random.choice(np.arange(arr.shape[0]), n, replace=False)
+        out = np.empty((n, arr.shape[1]))
+        for i, row in enumerate(arr[picks]):
+            b = Belief(model, row)
+            s = b.random_state()
+            if random.random() < epsilon:
+                a = random.choice(model.actions)
+            else:
+                a = value_function.actions[np.argmax(np.dot(value_function.alpha_vector_array, b.values))]
+            s_p = model.transition(s, a)
+            out[i] = b.update(a, model.observe(s_p, a)).values
+        return BeliefSet(model, out)
+
+    def expand_ssea(self, model, belief_set, max_generation: int = 10) -> BeliefSet:
+        arr = belief_set.belief_array
+        n = min(max_generation, arr.shape[0])
+        succ = np.array([[[b.update(a, o).values for o in model.observations] for a in model.actions]
+                         for b in belief_set.belief_list])
+        diff = arr[:, None, None, None, :] - succ
+        dist = np.sqrt(np.einsum('bnaos,bnaos->bnao', diff, diff))
+        nearest = np.min(dist, axis=0)
+        b_i, a_i, o_i = np.unravel_index(np.argsort(nearest, axis=None)[::-1][:n], succ.shape[:-1])
+        return BeliefSet(model, succ[b_i[:, None], a_i[:, None], o_i[:, None], model.states[None, :]])
+
+    def expand_ger(self, model, belief_set, value_function, max_generation: int = 10) -> BeliefSet:
+        arr = belief_set.belief_array
+        n = min(max_generation, arr.shape[0])
+        r_lo = model._min_reward / (1 - self.gamma)
+        r_hi = model._max_reward / (1 - self.gamma)
+        succ = np.array([[[b.update(a, o).values for o in model.observations] for a in model.actions]
+                         for b in belief_set.belief_list])
+        va = value_function.alpha_vector_array
+        own = va[np.argmax(np.dot(arr, va.T), axis=1)]
+        d_b = succ - arr[:, None, None, :]
+        d_a = np.where(d_b >= 0, r_hi, r_lo) - own[:, None, None, :]
+        err = np.einsum('baos,baos->bao', d_a, d_b)
+        p_bao = np.einsum('bs,saor->bao', arr, model.reachable_transitional_observation_table)
+        score = np.einsum('bao,bao->ba', p_bao, err)
+        b_i, a_i = np.unravel_index(np.argsort(score, axis=None)[::-1][:n], score.shape)
+        o_i = np.argmax(p_bao[b_i[:, None], a_i[:, None], model.observations[None, :]]
+                        * err[b_i[:, None], a_i[:, None], model.observations[None, :]], axis=1)
+        return BeliefSet(model, succ[b_i[:, None], a_i[:, None], o_i[:, None], model.states[None, :]])
+
+    def _walk(self, model, b0: Belief, policy_action, max_generation: int) -> BeliefSet:
+        seq = [b0]
+        s = b0.random_state()
+        b = b0
+        for i in range(max_generation - 1):
+            a = policy_action(i, s)
+            s_p = model.transition(s, a)
+            b = b.update(a, model.observe(s_p, a))
+            seq.append(b)
+            s = s_p
+            if s in model.end_states:
+                s = b0.random_state()
+                b = b0
+        return BeliefSet(model, seq)
+
+    def expand_fsvi(self, model, b0: Belief, mdp_policy: ValueFunction, max_generation: int = 10) -> BeliefSet:
+        q = mdp_policy.alpha_vector_array
+        return self._walk(model, b0, lambda i, s: np.argmax(q[:, s]), max_generation)
+
+    def expand_fsvi_eg(self, model, b0, mdp_policy, eps_greedy=None, max_generation: int = 10) -> BeliefSet:
+        q = mdp_policy.alpha_vector_array
+        eg = eps_greedy if eps_greedy is not None else (lambda t: 0.2)
+        return self._walk(model, b0, lambda i, s: int(random.choice(model.actions)) if random.random() < eg(i)
+                          else np.argmax(q[:, s]), max_generation)
+
+    def expand_perseus(self, model, b: Belief, max_generation: int = 10) -> BeliefSet:
+        seq = []
+        for _ in range(max_generation):
+            a = int(np.random.choice(model.actions, size=1)[0])
+            p_o = np.einsum('sor,s->o', model.reachable_transitional_observation_table[:, a, :, :], b.values)
+            o = int(np.random.choice(model.observations, size=1, p=p_o)[0])
+            b = b.update(a, o)
+            seq.append(b)
+        return BeliefSet(model, seq)
+
+    def expand(self, model, belief_set, max_generation: int, **params) -> BeliefSet:
+        """Dispatch by substring exactly like ``src/pomdp.py:2088-2136``."""
+        f = self.expand_function
+        if f in 'expand_ra':
+            return self.expand_ra(model, belief_set, max_generation)
+        if f in 'expand_ssra':
+            return self.expand_ssra(model, belief_set, max_generation)
+        if f in 'expand_ssga':
+            kw = {k: params[k] for k in ('value_function', 'epsilon') if k in params}
+            return self.expand_ssga(model, belief_set, max_generation=max_generation, **kw)
+        if f in 'expand_ssea':
+            return self.expand_ssea(model, belief_set, max_generation)
+        if f in 'expand_ger':
+            return self.expand_ger(model, belief_set, params['value_function'], max_generation)
+        if f in 'expand_hsvi':
+            raise NotImplementedError('HSVI expansion (BeliefValueMapping upper bound) is outside the accelerated path; see SURVEY.md 2.1 rows 10-11')
+        if f in 'expand_fsvi':
+            return self.expand_fsvi(model, belief_set.belief_list[0], params['mdp_policy'], max_generation)
+        if f in 'expand_fsvi_eg':
+            return self.expand_fsvi_eg(model, belief_set.belief_list[0], params['mdp_policy'],
+                                       params.get('eps_greedy'), max_generation)
+        if f in 'expand_perseus':
+            return self.expand_perseus(model, belief_set.belief_list[0], max_generation)
+        raise Exception('Not implemented')
+
+    def compute_change(self, value_function: ValueFunction, new_value_function: ValueFunction, belief_set: BeliefSet) -> float:
+        """Largest change of ``max_v b.alpha_v`` over the belief set (``src/pomdp.py:2141-2169``)."""
+        b = belief_set.belief_array
+        if value_function.is_on_gpu:
+            eng = value_function.model.engine
+            old = eng.max_value(value_function.alpha_vector_array, b)[0]
+            new = eng.max_value(new_value_function.alpha_vector_array, b)[0]
+        else:
+            old = np.max(np.matmul(b, value_function.alpha_vector_array.T), axis=1)
+            new = np.max(np.matmul(b, new_value_function.alpha_vector_array.T), axis=1)
+        return float(np.max(np.abs(new - old)))
+
+    def solve(self, model: Model, expansions: int, full_backup: Union[bool, None] = None, update_passes: int = 1,
+              max_belief_growth: int = 10, initial_belief=None, initial_value_function=None, prune_level: int = 1,
+              prune_interval: int = 10, limit_value_function_size: int = -1, use_gpu: bool = False,
+              history_tracking_level: int = 1, print_progress: bool = True, engine_dtype: str = 'f64'):
+        """Expand / backup loop (``src/pomdp.py:2172-2413``).  ``engine_dtype``
+        ('f64' or 'f32') is the one added keyword: the arithmetic type of the HIP
+        engine when ``use_gpu=True``."""
+        if use_gpu:
+            model = model.to_gpu(engine_dtype) if not model.is_on_gpu else model
+
+        if initial_belief is None:
+            belief_set = BeliefSet(model, [Belief(model)])
+        elif isinstance(initial_belief, BeliefSet):
+            belief_set = initial_belief.to_gpu() if use_gpu else initial_belief
+        else:
+            belief_set = BeliefSet(model, [Belief(model, np.array(initial_belief.values))])
+
+        if initial_value_function is None:
+            value_function = ValueFunction(model, model.expected_rewards_table.T, model.actions)
+        else:
+            value_function = initial_value_function.to_gpu() if use_gpu else initial_value_function
+
+        if full_backup is None:
+            full_backup = any(self.expand_function in f for f in
+                              ['expand_ra', 'expand_ssra', 'expand_ssga', 'expand_ssea', 'expand_ger'])
+
+        if ('fsvi' in self.expand_function or 'hsvi' in self.expand_function) and \
+                self.expand_function_params.get('mdp_policy') is None:
+            log('[Warning] MDP solution not provided, running value iteration on the problem to retrieve it...')
+            mdp_solution, _ = VI_Solver(gamma=self.gamma, eps=self.eps).solve(model, use_gpu=use_gpu, print_progress=False)
+            self.expand_function_params['mdp_policy'] = mdp_solution
+
+        max_allowed_change = self.eps * (self.gamma / (1 - self.gamma))
+        history = SolverHistory(history_tracking_level, model, self.gamma, self.eps, self.expand_function,
+                                full_backup, value_function, belief_set)
+
+        iteration = 0
+        expand_value_function = value_function
+        old_value_function = value_function
+        try:
+            for expansion_i in range(expansions):
+                t0 = datetime.now()
+                new_belief_set = self.expand(model=model, belief_set=belief_set, value_function=value_function,
+                                             max_generation=max_belief_growth, **self.expand_function_params)
+                belief_set = belief_set.union(new_belief_set)
+                history.add_expand_step((datetime.now() - t0).total_seconds(), belief_set)
+
+                for _ in range(update_passes):
+                    t0 = datetime.now()
+                    value_function = self.backup(model, belief_set if full_backup else new_belief_set, value_function,
+                                                 append=(not full_backup), belief_dominance_prune=False)
+                    backup_time = (datetime.now() - t0).total_seconds()
+
+                    if (iteration % prune_interval) == 0 and iteration > 0:
+                        t0 = datetime.now()
+                        before = len(value_function)
+                        value_function.prune(prune_level)
+                        history.add_prune_step((datetime.now() - t0).total_seconds(), len(value_function) - before)
+
+                    if limit_value_function_size >= 0 and len(value_function) > limit_value_function_size:
+                        scores = np.matmul(value_function.alpha_vector_array, belief_set.belief_array.T)
+                        useful = np.unique(np.argmax(scores, axis=0))
+                        useless = np.delete(np.arange(len(value_function)), useful)
+                        w = np.arange(len(useless))[::-1]
+                        drop = np.random.choice(useless, size=max_belief_growth, p=w / np.sum(w))
+                        value_function = ValueFunction(model, np.delete(value_function.alpha_vector_array, drop, axis=0),
+                                                       np.delete(value_function.actions, drop))
+
+                    max_change = self.compute_change(value_function, old_value_function, belief_set)
+                    history.add_backup_step(backup_time, max_change, value_function)
+                    if max_change < max_allowed_change:
+                        break
+                    old_value_function = value_function
+                    iteration += 1
+
+                if self.compute_change(expand_value_function, value_function, belief_set) < max_allowed_change:
+                    print('Converged!')
+                    break
+                expand_value_function = value_function
+        except MemoryError as e:
+            print(f'Memory full: {e}')
+            print('Returning value function and history as is...\n')
+
+        t0 = datetime.now()
+        before = len(value_function)
+        value_function.prune(prune_level)
+        history.add_prune_step((datetime.now() - t0).total_seconds(), len(value_function) - before)
+        return value_function, history
+
+
+class FSVI_Solver(PBVI_Solver):
+    """Forward Search Value Iteration preset (``src/pomdp.py:2470-2544``)."""
+
+    def __init__(self, gamma: float = 0.99, eps: float = 0.001, mdp_policy: Union[ValueFunction, None] = None):
+        super().__init__(gamma, eps, 'fsvi', mdp_policy=mdp_policy)
+
+    def solve(self, model, expansions, update_passes: int = 1, max_belief_growth: int = 10, initial_belief=None,
+              initial_value_function=None, prune_level: int = 1, prune_interval: int = 10,
+              limit_value_function_size: int = -1, use_gpu: bool = False, history_tracking_level: int = 1,
+              print_progress: bool = True, engine_dtype: str = 'f64'):
+        return super().solve(model=model, expansions=expansions, full_backup=False, update_passes=update_passes,
+                             max_belief_growth=max_belief_growth, initial_belief=initial_belief,
+                             initial_value_function=initial_value_function, prune_level=prune_level,
+                             prune_interval=prune_interval, limit_value_function_size=limit_value_function_size,
+                             use_gpu=use_gpu, history_tracking_level=history_tracking_level,
+                             print_progress=print_progress, engine_dtype=engine_dtype)
+
+
+class FSVI_EG_Solver(FSVI_Solver):
+    """Epsilon-greedy FSVI preset (``src/pomdp.py:2547-2578``)."""
+
+    def __init__(self, gamma: float = 0.99, eps: float = 0.001, mdp_policy=None, eps_greedy=None):
+        PBVI_Solver.__init__(self, gamma, eps, 'fsvi_eg', mdp_policy=mdp_policy, eps_greedy=eps_greedy)
+
+
+class HSVI_Solver(PBVI_Solver):
+    """HSVI preset (``src/pomdp.py:2416-2467``); its expansion is not provided here."""
+
+    def __init__(self, gamma: float = 0.99, eps: float = 0.001, mdp_policy=None):
+        super().__init__(gamma, eps, 'hsvi', mdp_policy=mdp_policy)
+
+
+# --------------------------------------------------------------------------- #
+# Cassandra .POMDP files (inputs of BASELINE configs 0-1)
+# --------------------------------------------------------------------------- #
+def load_POMDP_file(file_name: str) -> Tuple[Model, PBVI_Solver]:
+    """Parse a Cassandra ``.POMDP`` file into ``(Model, PBVI_Solver(gamma))``.
+
+    Covers the constructs the reference's loader handles (``src/pomdp.py:3383-3737``):
+    ``discount/values/states/actions/observations/start`` headers and ``T``, ``O``,
+    ``R`` entries given as single values, rows, or matrices with ``uniform`` /
+    ``identity`` shortcuts and ``*`` wildcards.  Rewards land in ``R[s,a,s',o]``.
+    """
+    with open(file_name) as fh:
+        lines = [ln.split('#')[0].strip() for ln in fh]
+    lines = [ln for ln in lines if ln]
+
+    gamma = 1.0
+    names = {'states': None, 'actions': None, 'observations': None}
+    start = None
+    T = Ob = Rw = None
+
+    def counts():
+        return len(names['states']), len(names['actions']), len(names['observations'])
+
+    def ensure_tables():
+        nonlocal T, Ob, Rw
+        if T is None and all(v is not None for v in names.values()):
+            S, A, O = counts()
+            T = np.zeros((S, A, S))
+            Ob = np.zeros((S, A, O))
+            Rw = np.zeros((S, A, S, O))
+
+    def sel(kind: str, tok: str):
+        n = len(names[kind])
+        if tok == '*':
+            return list(range(n))
+        if tok.isnumeric():
+            return [int(tok)]
+        return [names[kind].index(tok)]
+
+    def is_number(tok: str) -> bool:
+        try:
+            float(tok)
+            return True
+        except ValueError:
+            return False
+
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        i += 1
+        head, _, rest = ln.partition(':')
+        head = head.strip()
+        if head == 'discount':
+            gamma = float(rest)
+        elif head == 'values':
+            pass
+        elif head in names:
+            toks = rest.split()
+            if len(toks) == 1 and toks[0].isnumeric():
+                prefix = {'states': 's', 'actions': 'a', 'observations': 'o'}[head]
+                names[head] = [f'{prefix}{k}' for k in range(int(toks[0]))]
+            else:
+                names[head] = toks
+            ensure_tables()
+        elif head == 'start':
+            toks = rest.split()
+            if not toks:
+                toks = lines[i].split()
+                i += 1
+            assert len(toks) == len(names['states']), 'Not enough states in initial belief'
+            start = np.array([float(t) for t in toks])
+        elif head in ('T', 'O', 'R'):
+            S, A, O = counts()
+            fields = [f.strip() for f in rest.split(':')]
+            value = None
+            last = fields[-1].split()
+            if len(last) > 1:                       # "... : x value"
+                fields[-1] = last[0]
+                value = float(last[1])
+            keys = [f for f in fields if f != '']
+            full = {'T': 3, 'O': 3, 'R': 4}[head]
+            if value is None and len(keys) == full + 1 and is_number(keys[-1]):
+                value = float(keys.pop())
+            acts = sel('actions', keys[0])
+            if head == 'T':
+                if len(keys) == 3:
+                    for a in acts:
+                        for s in sel('states', keys[1]):
+                            for sp in sel('states', keys[2]):
+                                T[s, a, sp] = value
+                elif len(keys) == 2:
+                    row = lines[i].split()
+                    i += 1
+                    for a in acts:
+                        for s in sel('states', keys[1]):
+                            T[s, a, :] = (np.ones(S) / S) if row[0] == 'uniform' else [float(t) for t in row]
+                else:
+                    first = lines[i].split()
+                    if first[0] in ('uniform', 'identity'):
+                        i += 1
+                        for a in acts:
+                            T[:, a, :] = (np.ones((S, S)) / S) if first[0] == 'uniform' else np.eye(S)
+                    else:
+                        mat = np.array([[float(t) for t in lines[i + k].split()] for k in range(S)])
+                        i += S
+                        for a in acts:
+                            T[:, a, :] = mat
+            elif head == 'O':
+                if len(keys) == 3:
+                    for a in acts:
+                        for sp in sel('states', keys[1]):
+                            for o in sel('observations', keys[2]):
+                                Ob[sp, a, o] = value
+                elif len(keys) == 2:
+                    row = lines[i].split()
+                    i += 1
+                    for a in acts:
+                        for sp in sel('states', keys[1]):
+                            Ob[sp, a, :] = (np.ones(O) / O) if row[0] == 'uniform' else [float(t) for t in row]
+                else:
+                    first = lines[i].split()
+                    if first[0] == 'uniform':
+                        i += 1
+                        for a in acts:
+                            Ob[:, a, :] = np.ones((S, O)) / O
+                    else:
+                        mat = np.array([[float(t) for t in lines[i + k].split()] for k in range(S)])
+                        i += S
+                        for a in acts:
+                            Ob[:, a, :] = mat
+            else:  # R
+                if len(keys) == 4:
+                    for a in acts:
+                        for s in sel('states', keys[1]):
+                            for sp in sel('states', keys[2]):
+                                for o in sel('observations', keys[3]):
+                                    Rw[s, a, sp, o] = value
+                elif len(keys) == 3:
+                    row = [float(t) for t in lines[i].split()]
+                    i += 1
+                    for a in acts:
+                        for s in sel('states', keys[1]):
+                            for sp in sel('states', keys[2]):
+                                Rw[s, a, sp, :] = row
+                elif len(keys) == 2:
+                    mat = np.array([[float(t) for t in lines[i + k].split()] for k in range(S)])
+                    i += S
+                    for a in acts:
+                        for s in sel('states', keys[1]):
+                            Rw[s, a, :, :] = mat
+                else:
+                    raise Exception('Need more than 1 parameter for rewards')
+
+    params = dict(states=names['states'], actions=names['actions'], observations=names['observations'],
+                  transitions=T, observation_table=Ob, rewards=Rw)
+    if start is not None:
+        params['start_probabilities'] = start
+    return Model(**params), PBVI_Solver(gamma=gamma)

@@ -1,0 +1,4 @@
+"""``src.mdp`` of the reference, served by the MI355X engine package."""
+import numpy as np                                   # noqa: F401  (leaked names the notebooks use)
+from pomdp_pbvi_exploration_amd.mdp import *         # noqa: F401,F403
+from pomdp_pbvi_exploration_amd.mdp import Model, AlphaVector, ValueFunction, VI_Solver, SolverHistory, Solver, log  # noqa: F401

@@ -1,0 +1,283 @@
+"""Generate the golden fixtures by running the REFERENCE itself.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    MPLBACKEND=Agg python tests/golden/make_golden.py [small] [kat] [c2] [full]
+
+It imports ``/root/reference/src/pomdp.py`` (NumPy path; CuPy is absent), feeds it
+inputs produced by this repo's own deterministic generator
+(``pomdp_pbvi_exploration_amd/synth.py``) or the reference's example ``.POMDP``
+files, and stores inputs + the reference's outputs as small ``.npz`` / ``.json``
+files next to this script.  Fixtures are data only: no reference source text.
+
+The oracle (``oracle/pbvi_oracle.py``) is asserted bit-identical to the reference
+here on every case before its per-belief intermediates (best_alpha_ind, which the
+reference does not return) are added to a fixture.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, '..', '..'))
+REF = '/root/reference'
+EXAMPLES = os.path.join(REF, 'Experiments', 'Example Models')
+
+
+def _import_reference():
+    """Import the reference's ``src`` package without shadowing by this repo's ``src`` shim."""
+    for k in [k for k in sys.modules if k == 'src' or k.startswith('src.')]:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            import src.pomdp as ref_pomdp
+            import src.mdp as ref_mdp
+    finally:
+        sys.path.remove(REF)
+    assert ref_pomdp.__file__.startswith(REF), ref_pomdp.__file__
+    return ref_pomdp, ref_mdp
+
+
+ref, ref_mdp = _import_reference()
+sys.path.insert(0, REPO)
+from oracle import pbvi_oracle as orc                     # noqa: E402
+from pomdp_pbvi_exploration_amd import synth              # noqa: E402
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def ref_model_from_synth(m: synth.SynthModel):
+    """Reference ``Model`` over the synthetic olfactory tables.  R=1: the reference builds
+    RTO / ER itself and they must equal synth's bit for bit.  R=5: the per-slot
+    probabilities cannot be passed through the constructor, so the three tables the
+    backup reads are assigned (they are inputs of the path)."""
+    model = quiet(ref.Model, states=m.S, actions=m.A, observations=m.O, reachable_states=m.reachable_states,
+                  observation_table=m.observation_table, end_states=[m.goal],
+                  start_probabilities=list(m.start_belief))
+    if m.R == 1:
+        assert np.array_equal(model.reachable_transitional_observation_table, m.rto)
+        assert np.array_equal(model.expected_rewards_table, m.expected_rewards)
+    else:
+        model.reachable_probabilities = m.reachable_probabilities
+        model.reachable_transitional_observation_table = m.rto
+        model.expected_rewards_table = m.expected_rewards
+    return model
+
+
+def ref_backup(model, alpha, actions, beliefs, gamma, append, prune):
+    solver = ref.PBVI_Solver(gamma=gamma)
+    vf = ref.ValueFunction(model, alpha, actions)
+    bs = ref.BeliefSet(model, beliefs)
+    out = solver.backup(model, bs, vf, append=append, belief_dominance_prune=prune)
+    return out.alpha_vector_array, np.asarray(out.actions, dtype=np.int64)
+
+
+def check_oracle(alpha, actions, beliefs, rs, rto, er, gamma, append, prune, ref_rows, ref_acts):
+    rows, acts = orc.backup(alpha, actions, beliefs, rs, rto, er, gamma, append=append, belief_dominance_prune=prune)
+    assert rows.shape == ref_rows.shape, (rows.shape, ref_rows.shape)
+    assert np.array_equal(rows, ref_rows), float(np.max(np.abs(rows - ref_rows)))
+    assert np.array_equal(acts, ref_acts)
+
+
+# --------------------------------------------------------------------------- #
+def gen_small():
+    """Synthetic olfactory models at S=600 (R=1 and R=5): full inputs + reference outputs."""
+    for R in (1, 5):
+        m = synth.olfactory_model(H=15, W=40, R=R)
+        model = ref_model_from_synth(m)
+        alpha, acts = synth.alpha_set(m, 48)
+        beliefs = synth.belief_points(m, 64, max_depth=16)
+        out = {}
+        for tag, append, prune in (('plain', False, False), ('prune', False, True), ('append', True, False)):
+            rows, ra = ref_backup(model, alpha, acts, beliefs, m.gamma, append, prune)
+            check_oracle(alpha, acts, beliefs, m.reachable_states, m.rto, m.expected_rewards, m.gamma, append, prune, rows, ra)
+            out[f'{tag}_alpha'] = rows
+            out[f'{tag}_actions'] = ra
+        a_new, a_star, v_star = orc.backup_core(alpha, beliefs, m.reachable_states, m.rto, m.expected_rewards, m.gamma)
+        keep = orc.belief_dominance_mask(alpha, beliefs, a_new)
+        # the tiled oracle (used at |S|~30k) must agree with the untiled one
+        t_new, t_star, t_v = orc.backup_core_tiled(alpha, beliefs, m.reachable_states, m.rto, m.expected_rewards, m.gamma, v_tile=16)
+        assert np.array_equal(t_star, a_star) and np.array_equal(t_v, v_star) and np.allclose(t_new, a_new, rtol=1e-13, atol=0)
+        np.savez_compressed(os.path.join(HERE, f'olfactory_small_R{R}.npz'),
+                            H=m.H, W=m.W, R=R, gamma=m.gamma,
+                            reachable_states=m.reachable_states.astype(np.int32), rto=m.rto.astype(np.float32),
+                            expected_rewards=m.expected_rewards.astype(np.float32),
+                            alpha=alpha.astype(np.float32), alpha_actions=acts.astype(np.int8),
+                            beliefs=beliefs.astype(np.float32),
+                            core_alpha=a_new, core_actions=a_star.astype(np.int8), core_best=v_star.astype(np.int16),
+                            core_keep=keep, **out)
+        print(f'small R={R}: |V_out| plain={len(out["plain_actions"])} prune={len(out["prune_actions"])} append={len(out["append_actions"])}')
+
+
+# --------------------------------------------------------------------------- #
+def two_state_model(obs_rnd: float):
+    """The 2-state model of observation_variation_comparisson.ipynb cells [3]-[6]."""
+    T = np.zeros((2, 2, 2))
+    for s in range(2):
+        for a in range(2):
+            for sp in range(2):
+                T[s, a, sp] = 0.8 if (s + a) % 2 == sp else round((1.0 - 0.8) / 1, 1)
+    Ob = np.zeros((2, 2, 2))
+    for sp in range(2):
+        for a in range(2):
+            for o in range(2):
+                Ob[sp, a, o] = obs_rnd if sp == o else (1.0 - obs_rnd) / 1
+    Rw = np.zeros((2, 2, 2, 2))
+    for sp in range(2):
+        Rw[:, :, sp, :] = [0.2, 0.6][sp]
+    return T, Ob, Rw
+
+
+def gen_kat():
+    kat = {}
+    # KAT-1/2/3: tiger
+    model, solver = quiet(ref.load_POMDP_file, os.path.join(EXAMPLES, 'tiger.95.POMDP'))
+    vf0 = ref.ValueFunction(model, model.expected_rewards_table.T, model.actions)
+    one = solver.backup(model, ref.BeliefSet(model, [ref.Belief(model)]), vf0, belief_dominance_prune=False)
+    kat['kat1_alpha'] = one.alpha_vector_array.tolist()
+    kat['kat1_actions'] = [int(a) for a in one.actions]
+    kat['kat2_belief'] = ref.Belief(model).update(0, 0).values.tolist()
+    model.end_actions = [1, 2]
+    vf, hist = quiet(solver.solve, model, expansions=8, update_passes=8, print_progress=False)
+    kat['kat3_belief_counts'] = [int(c) for c in hist.beliefs_counts]
+    kat['kat3_alpha'] = vf.alpha_vector_array.tolist()
+    kat['kat3_actions'] = [int(a) for a in vf.actions]
+    kat['kat3_alpha_counts'] = [int(c) for c in hist.alpha_vector_counts]
+    np.savez_compressed(os.path.join(HERE, 'tiger_tables.npz'),
+                        reachable_states=model.reachable_states, reachable_probabilities=model.reachable_probabilities,
+                        rto=model.reachable_transitional_observation_table, expected_rewards=model.expected_rewards_table,
+                        observation_table=model.observation_table, start=model.start_probabilities, gamma=solver.gamma)
+
+    # KAT-4/5: 2-state model, repeated backup with belief-dominance prune on
+    def run(obs_rnd, belief_rows, eps):
+        T, Ob, Rw = two_state_model(obs_rnd)
+        m = quiet(ref.Model, states=['s0', 's1'], actions=['stay', 'move'], observations=['s0', 's1'], transitions=T,
+                  rewards=Rw, observation_table=Ob, rewards_are_probabilistic=True)
+        s = ref.PBVI_Solver(gamma=0.99)
+        bs = ref.BeliefSet(m, [ref.Belief(m, np.array(r)) for r in belief_rows])
+        v = ref.ValueFunction(m, m.expected_rewards_table, m.actions)
+        limit = eps * (0.99 / (1 - 0.99))
+        old = None
+        its = 1000
+        for it in range(1000):
+            v = s.backup(m, bs, v)
+            cur = np.max(np.matmul(bs.belief_array, v.alpha_vector_array.T), axis=1)
+            if old is not None and np.max(np.abs(cur - old)) < limit:
+                its = it
+                break
+            old = cur
+        return dict(max=float(np.max(v.alpha_vector_array)), min=float(np.min(v.alpha_vector_array)), iters=its,
+                    n=len(v), alpha=v.alpha_vector_array.tolist(), actions=[int(a) for a in v.actions])
+
+    kat['kat4'] = {}
+    for i in (0, 17, 50):
+        kat['kat4'][str(i)] = run(0.7, [[i / 100, 1.0 - (i / 100)], [1.0 - (i / 100), i / 100]], 0.0001)
+    all102 = []
+    for i in range(51):
+        all102 += [[i / 100, 1.0 - (i / 100)], [1.0 - (i / 100), i / 100]]
+    kat['kat5'] = {str(acc): run(acc, all102, 0.001) for acc in (0.5, 0.7, 1.0)}
+    with open(os.path.join(HERE, 'kat.json'), 'w') as fh:
+        json.dump(kat, fh, indent=1)
+    print('kat3 belief counts', kat['kat3_belief_counts'], '|V|', len(kat['kat3_actions']))
+    print('kat4', {k: (v['max'], v['min'], v['iters']) for k, v in kat['kat4'].items()})
+    print('kat5', {k: (v['max'], v['min'], v['iters'], v['n']) for k, v in kat['kat5'].items()})
+
+
+# --------------------------------------------------------------------------- #
+def gen_c2():
+    """4x3 grid (BASELINE config 1): seeded FSVI run of the reference; every backup's
+    inputs and outputs are stored."""
+    path = os.path.join(EXAMPLES, '4x3.95-no_loop_2_grid.POMDP')
+    model, _ = quiet(ref.load_POMDP_file, path)
+    np.savez_compressed(os.path.join(HERE, 'grid4x3_tables.npz'),
+                        reachable_states=model.reachable_states, reachable_probabilities=model.reachable_probabilities,
+                        rto=model.reachable_transitional_observation_table, expected_rewards=model.expected_rewards_table,
+                        observation_table=model.observation_table, start=model.start_probabilities)
+    solver = ref.FSVI_Solver(gamma=0.95, eps=1e-6)
+    calls = []
+    orig = ref.PBVI_Solver.backup
+
+    def spy(self, mdl, belief_set, value_function, append=False, belief_dominance_prune=True):
+        a_in = np.array(value_function.alpha_vector_array)
+        act_in = np.array(value_function.actions, dtype=np.int64)
+        b_in = np.array(belief_set.belief_array)
+        out = orig(self, mdl, belief_set, value_function, append=append, belief_dominance_prune=belief_dominance_prune)
+        calls.append(dict(alpha=a_in, actions=act_in, beliefs=b_in, append=append, prune=belief_dominance_prune,
+                          out_alpha=np.array(out.alpha_vector_array), out_actions=np.array(out.actions, dtype=np.int64)))
+        return out
+
+    ref.PBVI_Solver.backup = spy            # observe the reference's own calls; nothing is altered
+    try:
+        np.random.seed(0)
+        random.seed(0)
+        model.end_states = [3, 6]
+        vf, hist = quiet(solver.solve, model, expansions=10, max_belief_growth=10, print_progress=False)
+    finally:
+        ref.PBVI_Solver.backup = orig
+    rs, rto, er = model.reachable_states, model.reachable_transitional_observation_table, model.expected_rewards_table
+    store = {'n_calls': len(calls), 'gamma': 0.95, 'alpha_counts': np.array(hist.alpha_vector_counts)}
+    for i, c in enumerate(calls):
+        check_oracle(c['alpha'], c['actions'], c['beliefs'], rs, rto, er, 0.95, c['append'], c['prune'],
+                     c['out_alpha'], c['out_actions'])
+        a_new, a_star, v_star = orc.backup_core(c['alpha'], c['beliefs'], rs, rto, er, 0.95)
+        keep = orc.belief_dominance_mask(c['alpha'], c['beliefs'], a_new)
+        # direct-call pattern of the notebooks (prune on, append off) on the same inputs
+        p_rows, p_acts = ref_backup(model, c['alpha'], c['actions'], c['beliefs'], 0.95, False, True)
+        check_oracle(c['alpha'], c['actions'], c['beliefs'], rs, rto, er, 0.95, False, True, p_rows, p_acts)
+        for k, v in dict(alpha=c['alpha'], actions=c['actions'], beliefs=c['beliefs'], append=np.array(c['append']),
+                         out_alpha=c['out_alpha'], out_actions=c['out_actions'], core_alpha=a_new, core_actions=a_star,
+                         core_best=v_star, core_keep=keep, prune_alpha=p_rows, prune_actions=p_acts).items():
+            store[f'c{i}_{k}'] = v
+    np.savez_compressed(os.path.join(HERE, 'grid4x3_fsvi.npz'), **store)
+    print('c2: calls', len(calls), '|V| trajectory', hist.alpha_vector_counts)
+
+
+# --------------------------------------------------------------------------- #
+def gen_full():
+    """|S|=30000, V=B=1024 (BASELINE configs 2-3): only OUTPUT summaries are stored;
+    both sides regenerate the inputs from synth (checksums pin them)."""
+    for R, V, B in ((1, 1024, 1024), (5, 512, 512)):
+        t0 = time.time()
+        m = synth.olfactory_model(R=R)
+        alpha, acts = synth.alpha_set(m, V)
+        beliefs = synth.belief_points(m, B)
+        print(f'full R={R}: inputs in {time.time() - t0:.1f}s, belief density {np.mean(beliefs > 0):.3f}', flush=True)
+        model = ref_model_from_synth(m)
+        t0 = time.time()
+        rows, ra = ref_backup(model, alpha, acts, beliefs, m.gamma, False, False)
+        t_ref = time.time() - t0
+        print(f'  reference backup {t_ref:.1f}s -> |V_out| {len(ra)}', flush=True)
+        a_new, a_star, v_star = orc.backup_core_tiled(alpha, beliefs, m.reachable_states, m.rto, m.expected_rewards, m.gamma)
+        d_rows, d_acts = orc.dedup_rows(a_new, a_star)
+        assert d_rows.shape == rows.shape and np.array_equal(d_acts, ra)
+        assert np.allclose(d_rows, rows, rtol=1e-12, atol=0)
+        keep = orc.belief_dominance_mask(alpha, beliefs, a_new)
+        idx = synth.splitmix64(99, np.arange(4096, dtype=np.uint64))
+        sb = (idx % np.uint64(B)).astype(np.int64)
+        ss = ((idx >> np.uint64(20)) % np.uint64(m.S)).astype(np.int64)
+        np.savez_compressed(os.path.join(HERE, f'olfactory_full_R{R}.npz'),
+                            R=R, V=V, B=B, gamma=m.gamma, ref_seconds=t_ref, n_unique=len(ra),
+                            inputs_sha256=synth.checksum(m.reachable_states, m.rto, m.expected_rewards, alpha, beliefs),
+                            core_actions=a_star.astype(np.int8), core_best=v_star.astype(np.int16), core_keep=keep,
+                            row_sum=a_new.sum(axis=1), b_dot=np.sum(beliefs * a_new, axis=1),
+                            sample_b=sb, sample_s=ss, sample_val=a_new[sb, ss],
+                            value_max=orc.max_value_per_belief(alpha, beliefs))
+        print(f'  stored; keep={int(keep.sum())}/{B}', flush=True)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['small', 'kat', 'c2']
+    for w in which:
+        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full}[w]()

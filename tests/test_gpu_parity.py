@@ -1,0 +1,269 @@
+"""Parity of the HIP engine (through the C-ABI) with the oracle / the reference's golden outputs.
+
+Bar (BASELINE.json north_star): argmax indices bit-exact, fp32 alpha values within 1e-6
+relative; f64 engines within 1e-12.  All tests here need a real MI355X.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_npz
+from oracle import pbvi_oracle as orc
+from pomdp_pbvi_exploration_amd import (Belief, BeliefSet, PBVI_Solver, ValueFunction, load_POMDP_file, synth)
+from pomdp_pbvi_exploration_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+F32_RTOL = 1e-6
+F64_RTOL = 1e-12
+
+
+def rel_err(x, ref):
+    scale = np.maximum(np.abs(ref), 1e-30)
+    return float(np.max(np.abs(np.asarray(x, dtype=np.float64) - ref) / np.maximum(scale, np.max(np.abs(ref)) * 1e-6)))
+
+
+def assert_alpha_close(x, ref, rtol):
+    x = np.asarray(x, dtype=np.float64)
+    np.testing.assert_allclose(x, ref, rtol=rtol, atol=rtol * max(1e-300, float(np.max(np.abs(ref)))) * 1e-3)
+
+
+def small(R):
+    z = load_npz(f'olfactory_small_R{R}.npz')
+    return z, z['reachable_states'].astype(np.int64), z['rto'].astype(np.float64), z['expected_rewards'].astype(np.float64)
+
+
+@pytest.mark.parametrize('R', [1, 5])
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_small_olfactory_matches_reference(R, dtype):
+    z, rs, rto, er = small(R)
+    S, A, Rr = rs.shape
+    eng = Engine(S, A, rto.shape[2], Rr, rs, rto, er, dtype=dtype)
+    res = eng.backup_full(z['alpha'], z['beliefs'], float(z['gamma']), belief_dominance_prune=True)
+    assert np.array_equal(res.best_alpha_ind, z['core_best']), 'best_alpha_ind differs from the reference'
+    assert np.array_equal(res.actions, z['core_actions'])
+    assert_alpha_close(res.alpha, z['core_alpha'], F32_RTOL if dtype == 'f32' else F64_RTOL)
+    if dtype == 'f64':
+        assert np.array_equal(res.keep, z['core_keep'])
+    st = res.stats
+    assert st['n_pairs'] == z['beliefs'].shape[0] * A * 3 and st['ms_total'] > 0
+    # dedup of the engine rows reproduces the reference ValueFunction (first position, last action)
+    rows, acts = orc.dedup_rows(res.alpha, res.actions)
+    assert rows.shape == z['plain_alpha'].shape and np.array_equal(acts, z['plain_actions'])
+    eng.close()
+
+
+def test_grid4x3_every_reference_call_f64():
+    """BASELINE config 1: 4x3 grid, fp64, every backup call of the reference's seeded FSVI run."""
+    z = load_npz('grid4x3_fsvi.npz')
+    t = load_npz('grid4x3_tables.npz')
+    rs, rto, er = t['reachable_states'], t['rto'], t['expected_rewards']
+    eng = Engine(12, 4, 6, rs.shape[2], rs, rto, er, dtype='f64')
+    for i in range(int(z['n_calls'])):
+        res = eng.backup_full(z[f'c{i}_alpha'], z[f'c{i}_beliefs'], 0.95, belief_dominance_prune=True)
+        assert np.array_equal(res.best_alpha_ind, z[f'c{i}_core_best']), f'call {i}'
+        assert np.array_equal(res.actions, z[f'c{i}_core_actions']), f'call {i}'
+        assert_alpha_close(res.alpha, z[f'c{i}_core_alpha'], F64_RTOL)
+        assert np.array_equal(res.keep, z[f'c{i}_core_keep']), f'call {i}'
+    eng.close()
+
+
+def test_grid4x3_f32_engine_against_oracle_on_rounded_inputs():
+    z = load_npz('grid4x3_fsvi.npz')
+    t = load_npz('grid4x3_tables.npz')
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    rs, rto, er = t['reachable_states'], r32(t['rto']), r32(t['expected_rewards'])
+    eng = Engine(12, 4, 6, rs.shape[2], rs, rto, er, dtype='f32')
+    for i in (0, 3, 9):
+        alpha, b = r32(z[f'c{i}_alpha']), r32(z[f'c{i}_beliefs'])
+        new, act, best = orc.backup_core(alpha, b, rs, rto, er, 0.95)
+        res = eng.backup_full(alpha, b, 0.95)
+        assert np.array_equal(res.best_alpha_ind, best) and np.array_equal(res.actions, act)
+        assert_alpha_close(res.alpha, new, F32_RTOL)
+    eng.close()
+
+
+def test_python_api_backup_on_gpu_objects():
+    """The reference seam: PBVI_Solver.backup on .to_gpu() objects returns the reference ValueFunction."""
+    z = load_npz('grid4x3_fsvi.npz')
+    model, _ = load_POMDP_file(os.path.join(GOLDEN, 'models', '4x3.95-no_loop_2_grid.POMDP'))
+    solver = PBVI_Solver(gamma=0.95)
+    gm = model.gpu_model
+    for i in (1, 5):
+        vf = ValueFunction(gm, z[f'c{i}_alpha'], z[f'c{i}_actions'])
+        bs = BeliefSet(gm, z[f'c{i}_beliefs'])
+        assert vf.is_on_gpu and bs.is_on_gpu
+        out = solver.backup(gm, bs, vf, append=bool(z[f'c{i}_append']), belief_dominance_prune=False)
+        assert out.alpha_vector_array.shape == z[f'c{i}_out_alpha'].shape
+        assert_alpha_close(out.alpha_vector_array, z[f'c{i}_out_alpha'], F64_RTOL)
+        assert np.array_equal(out.actions, z[f'c{i}_out_actions'])
+        out = solver.backup(gm, bs, vf)                       # notebook-style direct call: prune on, append off
+        assert out.alpha_vector_array.shape == z[f'c{i}_prune_alpha'].shape
+        assert np.array_equal(out.actions, z[f'c{i}_prune_actions'])
+
+
+def test_kat_tiger_on_gpu_and_full_solve():
+    kat = json.load(open(os.path.join(GOLDEN, 'kat.json')))
+    model, solver = load_POMDP_file(os.path.join(GOLDEN, 'models', 'tiger.95.POMDP'))
+    gm = model.gpu_model
+    vf0 = ValueFunction(gm, model.expected_rewards_table.T, model.actions)
+    out = solver.backup(gm, BeliefSet(gm, [Belief(gm)]), vf0, belief_dominance_prune=False)
+    np.testing.assert_allclose(out.alpha_vector_array, [[-1.95, -1.95]], rtol=1e-14)
+    assert list(out.actions) == [0]
+    model.end_actions = [1, 2]
+    vf, hist = solver.solve(model, expansions=8, update_passes=8, use_gpu=True, print_progress=False)
+    assert hist.beliefs_counts == kat['kat3_belief_counts']
+    assert len(vf) == 5
+    order = np.lexsort(np.asarray(kat['kat3_alpha']).T)
+    got = np.asarray(vf.alpha_vector_array)
+    np.testing.assert_allclose(got[np.lexsort(got.T)], np.asarray(kat['kat3_alpha'])[order], rtol=1e-9)
+
+
+def random_model(rng, S, A, O, R):
+    rs = rng.integers(0, S, size=(S, A, R))
+    p = rng.random((S, A, R))
+    p[rng.random((S, A, R)) < 0.3] = 0.0          # padded / impossible successors
+    p[:, :, 0] += 1e-3
+    p /= p.sum(axis=2, keepdims=True)
+    obs = rng.random((S, A, O))
+    obs[rng.random((S, A, O)) < 0.3] = 0.0
+    obs[:, :, 0] += 1e-3
+    obs /= obs.sum(axis=2, keepdims=True)
+    rto = p[:, :, None, :] * obs[rs[:, :, None, :], np.arange(A)[None, :, None, None], np.arange(O)[None, None, :, None]]
+    er = rng.normal(size=(S, A))
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    return rs, r32(rto), r32(er)
+
+
+@pytest.mark.parametrize('S,A,O,R,V,B', [(12, 4, 6, 3, 1, 1), (33, 1, 1, 1, 5, 3), (100, 3, 2, 4, 257, 300),
+                                         (1000, 2, 5, 2, 64, 513), (257, 5, 3, 1, 300, 17)])
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_ragged_shapes_and_mixed_sign_alpha(S, A, O, R, V, B, dtype):
+    """Edge shapes (single rows, sizes straddling the 256/32 padding, one action/observation) with
+    mixed-sign alpha and sparse beliefs; oracle on the same (f32-representable) inputs."""
+    rng = np.random.default_rng(S * 7 + V)
+    rs, rto, er = random_model(rng, S, A, O, R)
+    alpha = rng.normal(scale=10.0, size=(V, S)).astype(np.float32).astype(np.float64)
+    if V > 2:
+        alpha[2] = alpha[0]                                   # exact duplicate: first index must win
+    b = rng.random((B, S)) * (rng.random((B, S)) < 0.3)
+    b[:, 0] += 1e-3
+    b = (b / b.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    new, act, best = orc.backup_core(alpha, b, rs, rto, er, 0.9)
+    eng = Engine(S, A, O, R, rs, rto, er, dtype=dtype)
+    res = eng.backup_full(alpha, b, 0.9, belief_dominance_prune=True)
+    assert np.array_equal(res.best_alpha_ind, best)
+    assert np.array_equal(res.actions, act)
+    assert_alpha_close(res.alpha, new, F32_RTOL if dtype == 'f32' else F64_RTOL)
+    keep = orc.belief_dominance_mask(alpha, b, np.asarray(res.alpha, dtype=np.float64))
+    assert np.array_equal(res.keep, keep)
+    val, idx = eng.max_value(alpha, b)
+    np.testing.assert_allclose(val, orc.max_value_per_belief(alpha, b), rtol=1e-12, atol=1e-12)
+    assert np.array_equal(idx, np.argmax(b @ alpha.T, axis=1))
+    eng.close()
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_prune_dominated_matches_reference_loop(dtype):
+    rng = np.random.default_rng(5)
+    S, V = 700, 90
+    base = rng.random((V, S))
+    base[10] = base[3] - 0.5             # dominated
+    base[11] = base[4]                   # duplicate pair: both go
+    base[12] = np.maximum(base[5], base[6]) + 0.1   # dominates 5 and 6
+    base = base.astype(np.float32).astype(np.float64)
+    rs = np.zeros((S, 1, 1), dtype=np.int64)
+    eng = Engine(S, 1, 1, 1, rs, np.ones((S, 1, 1, 1)), np.zeros((S, 1)), dtype=dtype)
+    keep = eng.prune_dominated(base)
+    assert np.array_equal(keep, orc.prune_dominated_mask(base))
+    assert not keep[10] and not keep[11] and not keep[4] and not keep[5] and not keep[6] and keep[12]
+    eng.close()
+
+
+def test_gemm_alone_decides_almost_everything():
+    """With the fp64 refinement window shut, the raw MFMA score GEMM must still reproduce the
+    reference argmax except on genuine near-ties (guards against refinement masking a GEMM bug)."""
+    z, rs, rto, er = small(5)
+    eng = Engine(600, 6, 3, 5, rs, rto, er, dtype='f32')
+    eng.set_tie_window(1e-30)
+    res = eng.backup_full(z['alpha'], z['beliefs'], float(z['gamma']))
+    agree = np.mean(res.best_alpha_ind == z['core_best'])
+    assert agree > 0.97, agree
+    eng.set_tie_window(-1.0)
+    res = eng.backup_full(z['alpha'], z['beliefs'], float(z['gamma']))
+    assert np.array_equal(res.best_alpha_ind, z['core_best'])
+    eng.close()
+
+
+def test_errors_are_reported_not_fatal():
+    z, rs, rto, er = small(1)
+    eng = Engine(600, 6, 3, 1, rs, rto, er, dtype='f32')
+    with pytest.raises(ValueError):
+        eng.run(0.99)                                        # nothing resident yet
+    with pytest.raises(ValueError):
+        eng.set_alpha(np.zeros((3, 599)))
+    with pytest.raises(ValueError):
+        Engine(600, 6, 3, 1, rs + 600, rto, er)
+    eng.set_alpha(z['alpha'])
+    eng.append_alpha(z['alpha'][:7])
+    assert eng.alpha_count == 48 + 7
+    eng.close()
+
+
+def full_inputs(R, V, B):
+    m = synth.olfactory_model(R=R)
+    alpha, _ = synth.alpha_set(m, V)
+    beliefs = synth.belief_points(m, B)
+    return m, alpha, beliefs
+
+
+@pytest.mark.parametrize('R', [1, 5])
+def test_full_size_against_reference_summary(R):
+    """BASELINE configs 2-3 (|S|=30000): the engine against the reference's own backup on the same
+    regenerated inputs.  Indices exact; row sums, b.alpha' and 4096 sampled values within 1e-6."""
+    path = os.path.join(GOLDEN, f'olfactory_full_R{R}.npz')
+    if not os.path.exists(path):
+        pytest.skip('full-size fixture missing')
+    z = np.load(path, allow_pickle=False)
+    V, B = int(z['V']), int(z['B'])
+    m, alpha, beliefs = full_inputs(R, V, B)
+    sha = synth.checksum(m.reachable_states, m.rto, m.expected_rewards, alpha, beliefs)
+    if sha != str(z['inputs_sha256']):
+        pytest.skip('host regenerated different input bits than the fixture machine (exp/libm); parity unpinned here')
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32')
+    res = eng.backup_full(alpha, beliefs, m.gamma, belief_dominance_prune=True)
+    mism = int(np.sum(res.best_alpha_ind != z['core_best']))
+    assert mism == 0, f'{mism} of {res.best_alpha_ind.size} best_alpha_ind differ'
+    assert np.array_equal(res.actions, z['core_actions'])
+    a64 = res.alpha.astype(np.float64)
+    np.testing.assert_allclose(a64.sum(axis=1), z['row_sum'], rtol=F32_RTOL)
+    np.testing.assert_allclose(np.sum(beliefs * a64, axis=1), z['b_dot'], rtol=F32_RTOL)
+    np.testing.assert_allclose(a64[z['sample_b'], z['sample_s']], z['sample_val'], rtol=F32_RTOL, atol=1e-12)
+    assert len(orc.dedup_rows(res.alpha, res.actions)[1]) == int(z['n_unique'])
+    val, _ = eng.max_value(alpha, beliefs)
+    np.testing.assert_allclose(val, z['value_max'], rtol=1e-12)
+    # belief dominance: equal wherever the f64 margin is not inside f32 rounding of alpha'
+    margin = np.abs(z['b_dot'] - z['value_max']) / np.maximum(np.abs(z['value_max']), 1e-30)
+    clear = margin > 1e-6
+    assert np.array_equal(res.keep[clear], z['core_keep'][clear])
+    print(f"R={R}: refined {res.stats['n_refined']}/{res.stats['n_pairs']} pairs, dead {res.stats['n_dead']}, "
+          f"score GEMM {res.stats['ms_score']:.2f} ms, total {res.stats['ms_total']:.2f} ms")
+
+    # size-independent properties at the full size ------------------------------------------ #
+    again = eng.backup_full(alpha, beliefs, m.gamma)
+    assert np.array_equal(again.alpha, res.alpha) and np.array_equal(again.best_alpha_ind, res.best_alpha_ind)  # deterministic
+    perm = np.argsort(synth.splitmix64(5, np.arange(B, dtype=np.uint64)))
+    pb = eng.backup_full(alpha, beliefs[perm], m.gamma)
+    assert np.array_equal(pb.alpha, res.alpha[perm]) and np.array_equal(pb.actions, res.actions[perm])          # belief order is free
+    vperm = np.argsort(synth.splitmix64(6, np.arange(V, dtype=np.uint64)))
+    pv = eng.backup_full(alpha[vperm], beliefs, m.gamma)
+    # alpha order only renames indices -- except all-tie triples (P(o|b,a)=0), where both runs pick index 0
+    mism = vperm[pv.best_alpha_ind] != res.best_alpha_ind
+    assert np.all((pv.best_alpha_ind[mism] == 0) & (res.best_alpha_ind[mism] == 0))
+    assert np.array_equal(pv.actions, res.actions)
+    np.testing.assert_allclose(np.sum(beliefs * pv.alpha, axis=1), np.sum(beliefs * res.alpha, axis=1), rtol=F32_RTOL)
+    sc = eng.backup_full(alpha * 2.0, beliefs, m.gamma)                                                           # scaling by 2 is exact
+    assert np.array_equal(sc.best_alpha_ind, res.best_alpha_ind)
+    eng.close()

@@ -1,0 +1,174 @@
+"""Host-side mirror of the reference interface (NumPy path, BASELINE config 0): same tables,
+same container semantics, same known answers as the reference."""
+import copy
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_npz
+from pomdp_pbvi_exploration_amd import (Belief, BeliefSet, FSVI_Solver, Model, PBVI_Solver, ValueFunction,
+                                        load_POMDP_file, synth)
+
+EXAMPLES = os.path.join(GOLDEN, 'models')
+KAT = json.load(open(os.path.join(GOLDEN, 'kat.json')))
+
+
+def _two_state(obs_rnd):
+    T = np.zeros((2, 2, 2))
+    Ob = np.zeros((2, 2, 2))
+    Rw = np.zeros((2, 2, 2, 2))
+    for s in range(2):
+        for a in range(2):
+            for sp in range(2):
+                T[s, a, sp] = 0.8 if (s + a) % 2 == sp else round(1.0 - 0.8, 1)
+                Ob[sp, a, s] = obs_rnd if sp == s else 1.0 - obs_rnd
+    for sp in range(2):
+        Rw[:, :, sp, :] = [0.2, 0.6][sp]
+    return Model(states=['s0', 's1'], actions=['stay', 'move'], observations=['s0', 's1'], transitions=T, rewards=Rw,
+                 observation_table=Ob, rewards_are_probabilistic=True)
+
+
+@pytest.mark.parametrize('fname,tables', [('tiger.95.POMDP', 'tiger_tables.npz'),
+                                          ('4x3.95-no_loop_2_grid.POMDP', 'grid4x3_tables.npz')])
+def test_pomdp_file_tables_equal_reference(fname, tables):
+    model, solver = load_POMDP_file(os.path.join(EXAMPLES, fname))
+    t = load_npz(tables)
+    assert np.array_equal(model.reachable_states, t['reachable_states'])
+    assert np.array_equal(model.reachable_probabilities, t['reachable_probabilities'])
+    assert np.array_equal(model.reachable_transitional_observation_table, t['rto'])
+    assert np.array_equal(model.expected_rewards_table, t['expected_rewards'])
+    assert np.array_equal(model.start_probabilities, t['start'])
+    assert solver.gamma == 0.95 and solver.expand_function == 'ssea' and solver.eps == 0.001
+
+
+def test_kat1_kat2_tiger():
+    model, solver = load_POMDP_file(os.path.join(EXAMPLES, 'tiger.95.POMDP'))
+    vf0 = ValueFunction(model, model.expected_rewards_table.T, model.actions)
+    out = solver.backup(model, BeliefSet(model, [Belief(model)]), vf0, belief_dominance_prune=False)
+    assert out.alpha_vector_array.tolist() == KAT['kat1_alpha'] == [[-1.95, -1.95]]
+    assert list(out.actions) == [0]
+    assert Belief(model).update(0, 0).values.tolist() == KAT['kat2_belief']
+    np.testing.assert_allclose(KAT['kat2_belief'], [0.85, 0.15], rtol=1e-15)
+
+
+def test_kat3_tiger_full_solve_matches_reference():
+    model, solver = load_POMDP_file(os.path.join(EXAMPLES, 'tiger.95.POMDP'))
+    model.end_actions = [1, 2]
+    vf, hist = solver.solve(model, expansions=8, update_passes=8, print_progress=False)
+    assert hist.beliefs_counts == KAT['kat3_belief_counts'] == [1, 2, 4, 7, 11, 15, 21, 31, 41]
+    assert len(vf) == 5                                                   # tiger_problem_from_file.ipynb cell [22]
+    np.testing.assert_allclose(vf.alpha_vector_array, KAT['kat3_alpha'], rtol=1e-12)
+    assert list(vf.actions) == KAT['kat3_actions'] == [0, 0, 0, 1, 2]   # reference run; SURVEY 8c lists the last two swapped
+    assert hist.alpha_vector_counts == KAT['kat3_alpha_counts']
+    # policy thresholds printed by the notebook (tiger_problem_from_file.ipynb:205,388)
+    a = vf.alpha_vector_array
+    x = (a[2, 1] - a[4, 1]) / ((a[4, 0] - a[4, 1]) - (a[2, 0] - a[2, 1]))
+    np.testing.assert_allclose([1 - x, x], [0.041972822899461214, 0.9580271771005388], rtol=1e-9)
+
+
+def _iterate(model, belief_rows, eps):
+    solver = PBVI_Solver(gamma=0.99)
+    bs = BeliefSet(model, [Belief(model, np.array(r)) for r in belief_rows])
+    vf = copy.deepcopy(ValueFunction(model, model.expected_rewards_table, model.actions))
+    limit = eps * (0.99 / (1 - 0.99))
+    old, its = None, 1000
+    for it in range(1000):
+        vf = solver.backup(model, bs, vf)
+        cur = np.max(np.matmul(bs.belief_array, vf.alpha_vector_array.T), axis=1)
+        if old is not None and np.max(np.abs(cur - old)) < limit:
+            its = it
+            break
+        old = cur
+    return float(np.max(vf.alpha_vector_array)), float(np.min(vf.alpha_vector_array)), its, len(vf)
+
+
+@pytest.mark.parametrize('i,expect', [(0, (39.324873290949945, 38.73374028602384, 368)),
+                                      (17, (43.89860938273302, 43.65860938273302, 379)),
+                                      (50, (39.3162567916742, 38.725123786748085, 367))])
+def test_kat4_repeated_backup_notebook_numbers(i, expect):
+    """observation_variation_comparisson.ipynb:238,255,288 (stored cell outputs)."""
+    mx, mn, its, _ = _iterate(_two_state(0.7), [[i / 100, 1.0 - (i / 100)], [1.0 - (i / 100), i / 100]], 0.0001)
+    assert its == expect[2]
+    np.testing.assert_allclose([mx, mn], expect[:2], rtol=1e-12)
+    ref = KAT['kat4'][str(i)]
+    assert (ref['max'], ref['min'], ref['iters']) == expect
+
+
+@pytest.mark.parametrize('acc,expect', [(0.5, (30.500954541065976, 29.90982153613987, 138)),
+                                        (0.7, (35.201002743439766, 34.77750362678456, 150)),
+                                        (1.0, (42.29309361078366, 42.053093610783655, 165))])
+def test_kat5_102_beliefs_notebook_numbers(acc, expect):
+    """observation_variation_comparisson.ipynb:787,791,797 (stored cell outputs)."""
+    rows = []
+    for i in range(51):
+        rows += [[i / 100, 1.0 - (i / 100)], [1.0 - (i / 100), i / 100]]
+    mx, mn, its, n = _iterate(_two_state(acc), rows, 0.001)
+    assert its == expect[2] and n == KAT['kat5'][str(acc)]['n']
+    np.testing.assert_allclose([mx, mn], expect[:2], rtol=1e-12)
+
+
+def test_grid4x3_seeded_fsvi_trajectory():
+    """G-C2: seeded FSVI on the 4x3 grid reproduces the reference's |V| trajectory and final set."""
+    z = load_npz('grid4x3_fsvi.npz')
+    model, _ = load_POMDP_file(os.path.join(EXAMPLES, '4x3.95-no_loop_2_grid.POMDP'))
+    model.end_states = [3, 6]
+    np.random.seed(0)
+    random.seed(0)
+    vf, hist = FSVI_Solver(gamma=0.95, eps=1e-6).solve(model, expansions=10, max_belief_growth=10, print_progress=False)
+    assert hist.alpha_vector_counts == list(z['alpha_counts'])
+    last = int(z['n_calls']) - 1
+    np.testing.assert_allclose(vf.alpha_vector_array, z[f'c{last}_out_alpha'], rtol=1e-12, atol=1e-13)
+    assert np.array_equal(vf.actions, z[f'c{last}_out_actions'])
+
+
+def test_value_function_container_semantics():
+    model = _two_state(0.7)
+    rows = np.array([[1., 2.], [3., 4.], [1., 2.]])
+    vf = ValueFunction(model, rows, [0, 1, 1])
+    assert vf.alpha_vector_array.tolist() == [[1., 2.], [3., 4.]] and list(vf.actions) == [1, 1]
+    new = ValueFunction(model, np.array([[9., 9.], [3., 4.]]), [0, 0])
+    new.extend(vf)
+    assert new.alpha_vector_array.tolist() == [[9., 9.], [3., 4.], [1., 2.]] and list(new.actions) == [0, 1, 1]
+    dom = ValueFunction(model, np.array([[1., 2.], [0., 1.], [2., 0.]]), [0, 1, 0])
+    dom.prune(2)
+    assert dom.alpha_vector_array.tolist() == [[1., 2.], [2., 0.]] and len(dom) == 2
+
+
+def test_gpu_request_never_falls_back(monkeypatch):
+    """use_gpu=True must raise when the HIP engine cannot be created (no silent CPU path)."""
+    from pomdp_pbvi_exploration_amd import engine as eng
+    model = _two_state(0.7)
+    monkeypatch.setattr(eng, 'LIB_PATH', '/nonexistent/libpbvi_hip.so')
+    monkeypatch.setattr(eng, '_lib', None)
+    with pytest.raises(eng.EngineUnavailable):
+        eng.load_library('/nonexistent/libpbvi_hip.so')
+    if eng.device_count.__call__ and not _has_gpu():
+        with pytest.raises((eng.EngineUnavailable, RuntimeError)):
+            PBVI_Solver().solve(model, expansions=1, use_gpu=True, print_progress=False)
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:
+        return False
+
+
+def test_synth_generator_is_deterministic():
+    m1 = synth.olfactory_model(H=15, W=40, R=5)
+    m2 = synth.olfactory_model(H=15, W=40, R=5)
+    assert synth.checksum(m1.rto, m1.reachable_states) == synth.checksum(m2.rto, m2.reachable_states)
+    z = load_npz('olfactory_small_R5.npz')
+    assert np.array_equal(m1.reachable_states, z['reachable_states'])
+    assert np.array_equal(m1.rto.astype(np.float32), z['rto'])
+    a, acts = synth.alpha_set(m1, 48)
+    assert np.array_equal(a.astype(np.float32), z['alpha']) and np.array_equal(acts, z['alpha_actions'])
+    b = synth.belief_points(m1, 64, max_depth=16)
+    assert np.array_equal(b.astype(np.float32), z['beliefs'])
+    np.testing.assert_allclose(b.sum(axis=1), 1.0, atol=1e-6)
+    # R=5 rows are proper distributions over five distinct successors
+    assert all(len(set(row)) == 5 for row in m1.reachable_states.reshape(-1, 5)[:50])
