@@ -122,7 +122,8 @@ def main():
         K = args.steps
         ms_step = elapsed / K * 1e3
         ms_score = float(np.mean([s['ms_score'] for s in stats]))
-        flops = stats[0]['score_flops']
+        flops_dense = stats[0]['score_flops']                   # 2*B*S*A*O*V
+        flops = stats[0]['score_flops_executed']                # same, restricted to structurally non-zero tiles
         achieved = flops / (ms_score * 1e-3) / 1e12
         out = {
             'metric': 'alpha-vector backups/sec', 'value': B * world * K / elapsed, 'unit': 'backups/s',
@@ -135,11 +136,14 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'k_gemm_nt_f32_mfma (belief x Gamma score GEMM)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-                         'flops_per_launch': flops, 'ms_per_launch': ms_score},
+                         'flops_per_launch': flops, 'ms_per_launch': ms_score,
+                         'dense_flops_per_launch': flops_dense,
+                         'dense_equivalent_tflops': flops_dense / (ms_score * 1e-3) / 1e12,
+                         'tiles_run_over_dense': stats[0]['score_tiles_run'] / max(1, stats[0]['score_tiles_dense'])},
             'stage_ms': {k: float(np.mean([s[k] for s in stats])) for k in
                          ('ms_total', 'ms_project', 'ms_score', 'ms_argmax', 'ms_refine', 'ms_action', 'ms_assemble')},
             'refined_pairs': int(stats[-1]['n_refined']), 'dead_pairs': int(stats[-1]['n_dead']),
-            'pairs': int(stats[-1]['n_pairs']), 'split_k': int(stats[-1]['split_k']),
+            'refined_actions': int(stats[-1]['n_refined_actions']), 'pairs': int(stats[-1]['n_pairs']), 'split_k': int(stats[-1]['split_k']),
         }
         if host_ms is not None:
             out['pcie_inclusive'] = {'ms_per_step': host_ms, 'value': B / (host_ms * 1e-3), 'unit': 'backups/s'}

@@ -68,8 +68,11 @@ typedef struct pbvi_stats {
     int64_t n_dead;         /* triples with P(o|b,a) == 0 (all scores exactly 0) */
     int64_t n_refined;      /* triples whose argmax was re-decided in fp64 */
     int64_t n_refined_actions; /* beliefs whose action argmax was re-decided in fp64 */
-    int64_t score_flops;    /* 2*B*S*A*O*V of the score GEMM */
-    int32_t split_k;        /* K-split used by the score GEMM */
+    int64_t score_flops;    /* algorithmic 2*B*S*A*O*V of the score GEMM */
+    int64_t score_flops_executed; /* MFMA flops actually issued (zero tiles skipped, pad tiles included) */
+    int64_t score_tiles_dense;    /* 256x256x32 tile steps a dense GEMM of the padded shape would run */
+    int64_t score_tiles_run;      /* tile steps actually run */
+    int32_t split_k;        /* max K-chunks (partial slabs) per tile pair */
     int32_t reserved;
 } pbvi_stats_t;
 

@@ -20,38 +20,62 @@ struct ModelView {
     const uint8_t* sup;
 };
 
+// Score matrix as written by the GEMM: split-K partial slabs.  f32 engines: nchunks[pair] slabs
+// exist for tile pair (col>>8, row>>8) (zero-tile skipping makes the count per pair vary); f64
+// engines: one dense slab (nchunks == nullptr, fixed = 1).
+template <typename T>
+struct SlabView {
+    const T* slabs;
+    int64_t slab_stride;
+    int ldc;
+    const int* nchunks;   // [tiles_n][tiles_m] or nullptr
+    int tiles_m;
+    int fixed;
+    __device__ __forceinline__ T at(int row, int64_t col) const {
+        const T* p = slabs + (int64_t)row * ldc + col;
+        const int n = nchunks ? nchunks[(col >> 8) * tiles_m + (row >> 8)] : fixed;
+        T s = T(0);
+        for (int z = 0; z < n; ++z) s += p[(int64_t)z * slab_stride];
+        return s;
+    }
+};
+
 template <typename T>
 hipError_t launch_support(ModelView<T> mv, uint8_t* sup, hipStream_t st);
 
-// K1-sparse: Gamma[(a*O+o)*V + v][s] = gamma * sum_r rto[a][o][r][s] * alpha[v][rs[a][r][s]]
+// K1-sparse: Gamma[(a*O+o)*V + v][s] = gamma * sum_r rto[a][o][r][s] * alpha[v][rs[a][r][s]] for v < V;
+// alpha row V (the magnitude row max_v|alpha|) is projected to Gamma row A*O*V + (a*O+o), so every
+// (a,o) group is exactly V rows and stays aligned to the GEMM's 256-row tiles when V % 256 == 0.
 template <typename T>
-hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg, hipStream_t st);
+hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg,
+                          const uint8_t* need /* [A*O][k_tiles] or nullptr = all */, int k_tiles, hipStream_t st);
+hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB, int AO, int k_tiles, uint8_t* need,
+                             hipStream_t st);
 
 // dead[b][ao] = 1 iff supp(b) and supp(RTO[:,a,o,:]) are disjoint (P(o|b,a) == 0 exactly)
 template <typename T>
 hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, uint8_t* dead, hipStream_t st);
 
-// first-max argmax over the first V columns of each (row b, group g) segment of the (split-K)
-// score slabs; segments are vstride columns apart and, when vstride > V, column V of a segment
-// holds the magnitude score (b . Gamma of the max|alpha| row) that scales the tie window.
+// first-max argmax over the V columns [g*V, (g+1)*V) of each (row b, group g) of the score matrix;
+// column G*V + g holds the magnitude score (b . Gamma of the max|alpha| row) that scales the tie
+// window.
 template <typename T>
-hipError_t launch_argmax(const T* slabs, int64_t slab_stride, int split_k, int ldc, int V, int vstride, int G, int B,
-                         const uint8_t* dead, double tol_rel, double tol_abs, int flag_all,
-                         int32_t* best_v, double* best_score, double* err, int32_t* queue, int* qcount,
+hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dead, double tol_rel, double tol_abs,
+                         int flag_all, int32_t* best_v, double* best_score, double* err, int32_t* queue, int* qcount,
                          hipStream_t st);
 
 // fp64 re-decision of queued near-ties.  PROJ: scores are b . Gamma[a,o,v,:]; else b . alpha[v,:]
 template <typename T>
-hipError_t launch_refine(bool proj, const T* slabs, int64_t slab_stride, int split_k, int ldc, int V, int vstride,
-                         int G, int max_entries, const int32_t* queue, const int* qcount, const T* bel, int ldb,
-                         const T* alpha, int lda, ModelView<T> mv, double gamma, int32_t* best_v,
-                         double* best_score, double* err, hipStream_t st);
+hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entries, const int32_t* queue,
+                         const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
+                         double gamma, int32_t* best_v, double* best_score, double* err, hipStream_t st);
 
 // K4: val[b][a] = b.ER[:,a] + sum_o best_score[b][a][o]; action = first max; near-ties queued
 template <typename T>
-hipError_t launch_action(const T* bel, int ldb, int B, ModelView<T> mv, const double* best_score,
-                         const double* err, double* rdot, int32_t* action, int32_t* aqueue, int* aqcount,
-                         hipStream_t st);
+hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, double* rdot, hipStream_t st);
+template <typename T>
+hipError_t launch_action(int B, ModelView<T> mv, const double* rdot, const double* best_score, const double* err,
+                         int32_t* action, int32_t* aqueue, int* aqcount, hipStream_t st);
 template <typename T>
 hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv,
                                 double gamma, const int32_t* aqueue, const int* aqcount, const double* rdot,

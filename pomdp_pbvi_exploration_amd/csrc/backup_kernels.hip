@@ -31,13 +31,6 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
-template <typename T>
-__device__ __forceinline__ T slab_sum(const T* p, int64_t slab_stride, int split_k) {
-    T s = p[0];
-    for (int z = 1; z < split_k; ++z) s += p[(int64_t)z * slab_stride];
-    return s;
-}
-
 // Partial (this thread's share) of  sum_s b[s] * gamma * sum_r rto[a][o][r][s] * alpha_v[rs[a][r][s]]
 template <typename T>
 __device__ __forceinline__ double proj_dot_partial(const T* __restrict__ brow, const T* __restrict__ arow,
@@ -91,15 +84,28 @@ hipError_t launch_support(ModelView<T> mv, uint8_t* sup, hipStream_t st) {
 // ------------------------------------------------------------------------- //
 template <typename T>
 __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView<T> mv, T gamma,
-                          T* __restrict__ gam, int ldg) {
+                          T* __restrict__ gam, int ldg, const uint8_t* __restrict__ need, int k_tiles) {
 #pragma clang fp contract(off)   // einsum then scale: sum_r (rto*alpha), one rounding per op, as the reference
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= mv.S_pad) return;
     const int v0 = blockIdx.y * 4;
     const int a = blockIdx.z;
     const int nv = (V - v0) < 4 ? (V - v0) : 4;
+    const int kt = s >> 5;                                  // GEMM K tile of this state (32 states per tile)
     for (int o0 = 0; o0 < mv.O; o0 += 4) {
-        const int no = (mv.O - o0) < 4 ? (mv.O - o0) : 4;
+        int no = (mv.O - o0) < 4 ? (mv.O - o0) : 4;
+        // Gamma tiles the score GEMM never reads (no RTO support, or no belief mass in any row
+        // block) are not computed or written: `need` is exactly the GEMM's tile-list criterion.
+        bool want[4] = {true, true, true, true};
+        if (need != nullptr) {
+            bool any = false;
+#pragma unroll
+            for (int oj = 0; oj < 4; ++oj) {
+                want[oj] = (oj < no) && need[((int64_t)a * mv.O + o0 + oj) * k_tiles + kt];
+                any |= want[oj];
+            }
+            if (!any) continue;
+        }
         T acc[4][4];
 #pragma unroll
         for (int vj = 0; vj < 4; ++vj)
@@ -124,17 +130,39 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
         for (int vj = 0; vj < 4; ++vj)
 #pragma unroll
             for (int oj = 0; oj < 4; ++oj)
-                if (vj < nv && oj < no)
-                    gam[(((int64_t)a * mv.O + o0 + oj) * V + v0 + vj) * ldg + s] = gamma * acc[vj][oj];
+                if (vj < nv && oj < no && want[oj]) {
+                    const int64_t ao = (int64_t)a * mv.O + o0 + oj;
+                    const int v = v0 + vj;
+                    // alpha rows -> group-major rows; the magnitude row (v == V-1 of the Vt rows) -> tail
+                    const int64_t row = (v < V - 1) ? ao * (V - 1) + v : (int64_t)mv.A * mv.O * (V - 1) + ao;
+                    gam[row * ldg + s] = gamma * acc[vj][oj];
+                }
     }
 }
 
 template <typename T>
-hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg, hipStream_t st) {
+hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg,
+                          const uint8_t* need, int k_tiles, hipStream_t st) {
     if (V <= 0) return hipSuccess;
     dim3 grid((mv.S_pad + 255) / 256, (V + 3) / 4, mv.A);
     if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_project<T>, grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg);
+    hipLaunchKernelGGL(k_project<T>, grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles);
+    return hipGetLastError();
+}
+
+// need[ao][kt] = nzB[ao][kt] && (some 256-row belief block has a non-zero in K tile kt)
+__global__ void k_need_tiles(const uint8_t* __restrict__ nzA, int tiles_m, const uint8_t* __restrict__ nzB, int AO,
+                             int k_tiles, uint8_t* __restrict__ need) {
+    const int kt = blockIdx.x * 256 + threadIdx.x;
+    if (kt >= k_tiles) return;
+    int any = 0;
+    for (int m = 0; m < tiles_m; ++m) any |= nzA[(int64_t)m * k_tiles + kt];
+    for (int ao = 0; ao < AO; ++ao) need[(int64_t)ao * k_tiles + kt] = (any && nzB[(int64_t)ao * k_tiles + kt]) ? 1 : 0;
+}
+
+hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB, int AO, int k_tiles, uint8_t* need,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(k_need_tiles, dim3((k_tiles + 255) / 256), dim3(256), 0, st, nzA, tiles_m, nzB, AO, k_tiles, need);
     return hipGetLastError();
 }
 
@@ -185,10 +213,9 @@ hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, uint8_t* d
 // np.argmax semantics: first maximum.  src/pomdp.py:1495 (argmax part)
 // ------------------------------------------------------------------------- //
 template <typename T>
-__global__ void k_argmax(const T* __restrict__ slabs, int64_t slab_stride, int split_k, int ldc, int V, int vstride,
-                         int G, int B, const uint8_t* __restrict__ dead, double tol_rel, double tol_abs, int flag_all,
-                         int32_t* __restrict__ best_v, double* __restrict__ best_score, double* __restrict__ err,
-                         int32_t* __restrict__ queue, int* __restrict__ qcount) {
+__global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __restrict__ dead, double tol_rel,
+                         double tol_abs, int flag_all, int32_t* __restrict__ best_v, double* __restrict__ best_score,
+                         double* __restrict__ err, int32_t* __restrict__ queue, int* __restrict__ qcount) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gw >= (int64_t)B * G) return;
@@ -201,11 +228,11 @@ __global__ void k_argmax(const T* __restrict__ slabs, int64_t slab_stride, int s
         }
         return;
     }
-    const T* row = slabs + (int64_t)b * ldc + (int64_t)g * vstride;
+    const int64_t col0 = (int64_t)g * V;
     T m = -std::numeric_limits<T>::infinity();
     int idx = 0x7fffffff;
     for (int v = lane; v < V; v += 64) {
-        const T sc = slab_sum(row + v, slab_stride, split_k);
+        const T sc = sv.at(b, col0 + v);
         if (sc > m || idx == 0x7fffffff) {
             m = sc;
             idx = v;
@@ -223,15 +250,11 @@ __global__ void k_argmax(const T* __restrict__ slabs, int64_t slab_stride, int s
     double E = 0.0;
     int push = 0;
     if (queue != nullptr) {
-        double mag = fabs((double)m);
-        if (vstride > V) mag = fmax(mag, fabs((double)slab_sum(row + V, slab_stride, split_k)));
+        const double mag = fmax(fabs((double)m), fabs((double)sv.at(b, (int64_t)G * V + g)));
         E = tol_rel * mag + tol_abs;
         const double thr = (double)m - 2.0 * E;
         int cnt = 0;
-        for (int v = lane; v < V; v += 64) {
-            const double sc = (double)slab_sum(row + v, slab_stride, split_k);
-            cnt += (sc >= thr) ? 1 : 0;
-        }
+        for (int v = lane; v < V; v += 64) cnt += ((double)sv.at(b, col0 + v) >= thr) ? 1 : 0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
         push = (flag_all || cnt > 1) ? 1 : 0;
@@ -248,13 +271,13 @@ __global__ void k_argmax(const T* __restrict__ slabs, int64_t slab_stride, int s
 }
 
 template <typename T>
-hipError_t launch_argmax(const T* slabs, int64_t slab_stride, int split_k, int ldc, int V, int vstride, int G, int B,
-                         const uint8_t* dead, double tol_rel, double tol_abs, int flag_all, int32_t* best_v,
-                         double* best_score, double* err, int32_t* queue, int* qcount, hipStream_t st) {
+hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dead, double tol_rel, double tol_abs,
+                         int flag_all, int32_t* best_v, double* best_score, double* err, int32_t* queue, int* qcount,
+                         hipStream_t st) {
     const int64_t rows = (int64_t)B * G;
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_argmax<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, slabs, slab_stride, split_k,
-                       ldc, V, vstride, G, B, dead, tol_rel, tol_abs, flag_all, best_v, best_score, err, queue, qcount);
+    hipLaunchKernelGGL(k_argmax<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sv, V, G, B, dead, tol_rel,
+                       tol_abs, flag_all, best_v, best_score, err, queue, qcount);
     return hipGetLastError();
 }
 
@@ -264,8 +287,8 @@ hipError_t launch_argmax(const T* slabs, int64_t slab_stride, int split_k, int l
 // are exact in f64) and the first maximum of the exact scores wins.
 // ------------------------------------------------------------------------- //
 template <typename T, bool PROJ>
-__global__ void k_refine(const T* __restrict__ slabs, int64_t slab_stride, int split_k, int ldc, int V, int vstride,
-                         int G, const int32_t* __restrict__ queue, const int* __restrict__ qcount,
+__global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict__ queue,
+                         const int* __restrict__ qcount,
                          const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
                          ModelView<T> mv, double gamma, int32_t* __restrict__ best_v,
                          double* __restrict__ best_score, double* __restrict__ err) {
@@ -279,14 +302,14 @@ __global__ void k_refine(const T* __restrict__ slabs, int64_t slab_stride, int s
     const int a = PROJ ? g / mv.O : 0, o = PROJ ? g % mv.O : 0;
     const double m = best_score[e], E = err[e];
     const double thr = m - 2.0 * E;
-    const T* row = slabs + (int64_t)b * ldc + (int64_t)g * vstride;
+    const int64_t col0 = (int64_t)g * V;
     const T* brow = bel + (int64_t)b * ldb;
     double bestval = -std::numeric_limits<double>::infinity();
     int bestidx = -1;
     for (int v0 = 0; v0 < V; v0 += 256) {
         const int v = v0 + tid;
         int flag = 0;
-        if (v < V) flag = ((double)slab_sum(row + v, slab_stride, split_k) >= thr) ? 1 : 0;
+        if (v < V) flag = ((double)sv.at(b, col0 + v) >= thr) ? 1 : 0;
         const unsigned long long mask = __ballot(flag);
         __syncthreads();
         if (lane == 0) wcount[wid] = __popcll(mask);
@@ -317,17 +340,16 @@ __global__ void k_refine(const T* __restrict__ slabs, int64_t slab_stride, int s
 }
 
 template <typename T>
-hipError_t launch_refine(bool proj, const T* slabs, int64_t slab_stride, int split_k, int ldc, int V, int vstride,
-                         int G, int max_entries, const int32_t* queue, const int* qcount, const T* bel, int ldb,
-                         const T* alpha, int lda, ModelView<T> mv, double gamma, int32_t* best_v,
-                         double* best_score, double* err, hipStream_t st) {
+hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entries, const int32_t* queue,
+                         const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
+                         double gamma, int32_t* best_v, double* best_score, double* err, hipStream_t st) {
     if (max_entries <= 0) return hipSuccess;
     if (proj)
-        hipLaunchKernelGGL((k_refine<T, true>), dim3(max_entries), dim3(256), 0, st, slabs, slab_stride, split_k, ldc,
-                           V, vstride, G, queue, qcount, bel, ldb, alpha, lda, mv, gamma, best_v, best_score, err);
+        hipLaunchKernelGGL((k_refine<T, true>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,
+                           alpha, lda, mv, gamma, best_v, best_score, err);
     else
-        hipLaunchKernelGGL((k_refine<T, false>), dim3(max_entries), dim3(256), 0, st, slabs, slab_stride, split_k,
-                           ldc, V, vstride, G, queue, qcount, bel, ldb, alpha, lda, mv, gamma, best_v, best_score, err);
+        hipLaunchKernelGGL((k_refine<T, false>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel,
+                           ldb, alpha, lda, mv, gamma, best_v, best_score, err);
     return hipGetLastError();
 }
 
@@ -335,13 +357,9 @@ hipError_t launch_refine(bool proj, const T* slabs, int64_t slab_stride, int spl
 // K4: action values and first-max action.  src/pomdp.py:1502-1505 via the identity
 //   b . alpha_a[b,a,:] = b . ER[:,a] + sum_o max_v score[b,a,o,v]
 // ------------------------------------------------------------------------- //
+// rdot[b][a] = b . ER[:,a] in f64 (depends on the beliefs only: runs beside the score GEMM)
 template <typename T>
-__global__ void k_action(const T* __restrict__ bel, int ldb, ModelView<T> mv, const double* __restrict__ best_score,
-                         const double* __restrict__ err, double* __restrict__ rdot, int32_t* __restrict__ action,
-                         int32_t* __restrict__ aqueue, int* __restrict__ aqcount) {
-    extern __shared__ double asm_[];
-    double* val = asm_;                  // [A]
-    double* Eb = asm_ + mv.A;            // [A]
+__global__ void k_rdot(const T* __restrict__ bel, int ldb, ModelView<T> mv, double* __restrict__ rdot) {
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const T* brow = bel + (int64_t)b * ldb;
@@ -360,50 +378,66 @@ __global__ void k_action(const T* __restrict__ bel, int ldb, ModelView<T> mv, co
         for (int j = 0; j < 4; ++j) {
             if (j < na) {                                   // block-uniform
                 const double t = block_sum(acc[j], red);
-                if (tid == 0) val[a0 + j] = t;
+                if (tid == 0) rdot[(int64_t)b * mv.A + a0 + j] = t;
             }
         }
     }
-    __syncthreads();
-    if (tid == 0) {
-        int best = 0;
-        double bv = -std::numeric_limits<double>::infinity();
+}
+
+// one thread per belief: val[a] = rdot[b][a] + sum_o best_score[b][a][o]; first max; near-ties queued
+template <typename T>
+__global__ void k_action_select(int B, ModelView<T> mv, const double* __restrict__ rdot,
+                                const double* __restrict__ best_score, const double* __restrict__ err,
+                                int32_t* __restrict__ action, int32_t* __restrict__ aqueue, int* __restrict__ aqcount) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    int best = 0;
+    double bv = -std::numeric_limits<double>::infinity(), lo = bv;
+    for (int a = 0; a < mv.A; ++a) {
+        double v = rdot[(int64_t)b * mv.A + a], E = 0.0;
+        for (int o = 0; o < mv.O; ++o) {
+            const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
+            v += best_score[e];
+            E += err[e];
+        }
+        if (v > bv) {
+            bv = v;
+            best = a;
+        }
+        lo = fmax(lo, v - E);
+    }
+    action[b] = best;
+    if (aqueue != nullptr) {
+        int ncand = 0, anyerr = 0;
         for (int a = 0; a < mv.A; ++a) {
-            rdot[(int64_t)b * mv.A + a] = val[a];
-            double v = val[a], E = 0.0;
+            double v = rdot[(int64_t)b * mv.A + a], E = 0.0;
             for (int o = 0; o < mv.O; ++o) {
                 const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
                 v += best_score[e];
                 E += err[e];
             }
-            val[a] = v;
-            Eb[a] = E;
-            if (v > bv) {
-                bv = v;
-                best = a;
+            if (v + E >= lo) {
+                ++ncand;
+                anyerr |= (E > 0.0);
             }
         }
-        action[b] = best;
-        if (aqueue != nullptr) {
-            double lo = -std::numeric_limits<double>::infinity();
-            for (int a = 0; a < mv.A; ++a) lo = fmax(lo, val[a] - Eb[a]);
-            int ncand = 0, anyerr = 0;
-            for (int a = 0; a < mv.A; ++a)
-                if (val[a] + Eb[a] >= lo) {
-                    ++ncand;
-                    anyerr |= (Eb[a] > 0.0);
-                }
-            if (ncand > 1 && anyerr) aqueue[atomicAdd(aqcount, 1)] = b;
-        }
+        if (ncand > 1 && anyerr) aqueue[atomicAdd(aqcount, 1)] = b;
     }
 }
 
 template <typename T>
-hipError_t launch_action(const T* bel, int ldb, int B, ModelView<T> mv, const double* best_score, const double* err,
-                         double* rdot, int32_t* action, int32_t* aqueue, int* aqcount, hipStream_t st) {
+hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, double* rdot, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_action<T>, dim3(B), dim3(256), 2 * mv.A * sizeof(double), st, bel, ldb, mv, best_score, err,
-                       rdot, action, aqueue, aqcount);
+    hipLaunchKernelGGL(k_rdot<T>, dim3(B), dim3(256), 0, st, bel, ldb, mv, rdot);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_action(int B, ModelView<T> mv, const double* rdot, const double* best_score, const double* err,
+                         int32_t* action, int32_t* aqueue, int* aqcount, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_action_select<T>, dim3((B + 255) / 256), dim3(256), 0, st, B, mv, rdot, best_score, err, action,
+                       aqueue, aqcount);
     return hipGetLastError();
 }
 
@@ -566,16 +600,16 @@ hipError_t launch_dominated(const T* alpha, int lda, int V, int S, int* cnt, hip
 // explicit instantiations
 #define PBVI_INST(T)                                                                                                   \
     template hipError_t launch_support<T>(ModelView<T>, uint8_t*, hipStream_t);                                        \
-    template hipError_t launch_project<T>(const T*, int, int, ModelView<T>, T, T*, int, hipStream_t);                  \
+    template hipError_t launch_project<T>(const T*, int, int, ModelView<T>, T, T*, int, const uint8_t*, int,           \
+                                          hipStream_t);                                                                \
+    template hipError_t launch_rdot<T>(const T*, int, int, ModelView<T>, double*, hipStream_t);                        \
     template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, uint8_t*, hipStream_t);                       \
-    template hipError_t launch_argmax<T>(const T*, int64_t, int, int, int, int, int, int, const uint8_t*, double,      \
-                                         double, int, int32_t*, double*, double*, int32_t*, int*, hipStream_t);        \
-    template hipError_t launch_refine<T>(bool, const T*, int64_t, int, int, int, int, int, int, const int32_t*,        \
-                                         const int*,                                                                   \
-                                         const T*, int, const T*, int, ModelView<T>, double, int32_t*, double*,        \
-                                         double*, hipStream_t);                                                        \
-    template hipError_t launch_action<T>(const T*, int, int, ModelView<T>, const double*, const double*, double*,      \
-                                         int32_t*, int32_t*, int*, hipStream_t);                                       \
+    template hipError_t launch_argmax<T>(SlabView<T>, int, int, int, const uint8_t*, double, double, int, int32_t*,    \
+                                         double*, double*, int32_t*, int*, hipStream_t);                               \
+    template hipError_t launch_refine<T>(bool, SlabView<T>, int, int, int, const int32_t*, const int*, const T*, int,  \
+                                         const T*, int, ModelView<T>, double, int32_t*, double*, double*, hipStream_t); \
+    template hipError_t launch_action<T>(int, ModelView<T>, const double*, const double*, const double*, int32_t*,     \
+                                         int32_t*, int*, hipStream_t);                                                 \
     template hipError_t launch_refine_action<T>(const T*, int, int, const T*, int, ModelView<T>, double,               \
                                                 const int32_t*, const int*, const double*, const int32_t*, double*,    \
                                                 double*, int32_t*, hipStream_t);                                       \

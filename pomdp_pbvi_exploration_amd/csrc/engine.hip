@@ -117,6 +117,10 @@ class EngineT : public EngineBase {
     int64_t B_ = 0, B_pad_ = 0;
     DevBuf gam_, slabs_, best_v_, best_score_, err_, dead_, queue_, counters_, rdot_, action_, aqueue_, out_, keep_;
     DevBuf bv2_, bs2_, err2_, queue2_, prune_cnt_;
+    DevBuf nzB_, nzA_, klist_, kcount_, nchunks_, need_;   // zero-tile bookkeeping of the f32 score GEMM
+    hipStream_t stream2_ = nullptr;                  // belief-only kernels run beside projection + GEMM
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    GemmPlan plan_ = {};
     hipEvent_t ev_[9] = {};
     bool have_result_ = false;
     int64_t res_B_ = 0;
@@ -125,10 +129,13 @@ class EngineT : public EngineBase {
         (void)hipSetDevice(device_);
         DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
-                         &err2_, &queue2_, &prune_cnt_};
+                         &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
             if (e) (void)hipEventDestroy(e);
+        if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+        if (ev_join_) (void)hipEventDestroy(ev_join_);
+        if (stream2_) (void)hipStreamDestroy(stream2_);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
 
@@ -156,7 +163,10 @@ class EngineT : public EngineBase {
         S_pad_ = (int)round_up(S, GEMM_BK);
         HIPCHK(hipSetDevice(device_));
         HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
         for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
+        HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
 
         // re-tile the reference's [S][A][R] / [S][A][O][R] / [S][A] tables to s-contiguous planes
         const size_t n_rs = (size_t)A * R * S_pad_, n_rto = (size_t)A * O * R * S_pad_, n_er = (size_t)A * S_pad_;
@@ -190,6 +200,17 @@ class EngineT : public EngineBase {
         HIPCHK(hipMemcpyAsync(er_.p, h_er.data(), n_er * sizeof(T), hipMemcpyHostToDevice, stream_));
         HIPCHK(launch_support<T>(view(), sup_.as<uint8_t>(), stream_));
         if ((rc = counters_.ensure(4 * sizeof(int), &bytes_))) return rc;
+        {   // nzB[(a,o)][kt] = 1 iff RTO[:,a,o,:] has support inside K tile kt (32 states)
+            const int k_tiles = S_pad_ / GEMM_BK;
+            std::vector<uint8_t> h_nz((size_t)A * O * k_tiles, 0);
+            for (int ao = 0; ao < A * O; ++ao)
+                for (int r = 0; r < R; ++r)
+                    for (int s = 0; s < S; ++s)
+                        if (h_rto[((size_t)ao * R + r) * S_pad_ + s] != T(0)) h_nz[(size_t)ao * k_tiles + s / GEMM_BK] = 1;
+            if ((rc = nzB_.ensure(h_nz.size(), &bytes_))) return rc;
+            HIPCHK(hipMemcpyAsync(nzB_.p, h_nz.data(), h_nz.size(), hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+        }
         HIPCHK(hipStreamSynchronize(stream_));
         return PBVI_OK;
     }
@@ -265,6 +286,11 @@ class EngineT : public EngineBase {
         HIPCHK(hipMemsetAsync(bel_.p, 0, (size_t)Bp * S_pad_ * sizeof(T), stream_));
         HIPCHK(hipMemcpy2DAsync(bel_.p, (size_t)S_pad_ * sizeof(T), bel, (size_t)S_ * sizeof(T), (size_t)S_ * sizeof(T),
                                 (size_t)B, hipMemcpyHostToDevice, stream_));
+        if (kF32) {   // which 256x32 belief tiles hold a non-zero (A-operand side of zero-tile skipping)
+            const int k_tiles = S_pad_ / GEMM_BK;
+            if ((rc = nzA_.ensure((size_t)(Bp / GEMM_BM) * k_tiles, &bytes_))) return rc;
+            HIPCHK(launch_tile_nonzero_f32((const float*)bel_.p, S_pad_, (int)Bp, k_tiles, nzA_.as<uint8_t>(), stream_));
+        }
         HIPCHK(hipStreamSynchronize(stream_));
         B_ = B;
         B_pad_ = Bp;
@@ -279,12 +305,9 @@ class EngineT : public EngineBase {
         return 8.0 * u * std::sqrt((double)std::max(k_chunk, 1)) + 8.0 * u;
     }
 
-    // score GEMM: C = X[rows_x][S_pad] . Y[rows_y][S_pad]^T  -> slabs_; returns layout
-    struct ScoreLayout {
-        int ldc = 0, split_k = 1;
-        int64_t slab_stride = 0;
-    };
-    int score_gemm(const T* X, int64_t rows_x, int64_t rows_x_pad, const T* Y, int64_t rows_y, ScoreLayout* lay);
+    // score GEMM: C = beliefs[B_pad][S_pad] . Y[rows_y][S_pad]^T -> slabs_.  Y's zero structure:
+    // G row groups of v_group rows with support nzB (nullptr = dense Y).
+    int score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv);
 
     int backup_run(double gamma, int flags, pbvi_stats_t* st) override;
 
@@ -346,25 +369,35 @@ class EngineT : public EngineBase {
 };
 
 template <typename T>
-int EngineT<T>::score_gemm(const T* X, int64_t rows_x, int64_t rows_x_pad, const T* Y, int64_t rows_y, ScoreLayout* lay) {
+int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv) {
     int rc;
     if constexpr (kF32) {
         const int64_t n_pad = round_up(rows_y, GEMM_BN);
-        const int tiles = (int)((rows_x_pad / GEMM_BM) * (n_pad / GEMM_BN));
-        const int k_tiles = S_pad_ / GEMM_BK;
-        lay->split_k = choose_split_k(tiles, k_tiles);
-        lay->ldc = (int)n_pad;
-        lay->slab_stride = rows_x_pad * n_pad;
-        if ((rc = slabs_.ensure((size_t)lay->split_k * lay->slab_stride * sizeof(float), &bytes_))) return rc;
-        HIPCHK(launch_gemm_nt_f32((const float*)X, S_pad_, (const float*)Y, S_pad_, slabs_.as<float>(), lay->ldc,
-                                  lay->slab_stride, (int)rows_x_pad, (int)n_pad, S_pad_, lay->split_k, stream_));
+        plan_ = make_gemm_plan((int)B_pad_, (int)n_pad, S_pad_);
+        const size_t pairs = (size_t)plan_.tiles_m * plan_.tiles_n;
+        if ((rc = slabs_.ensure((size_t)plan_.max_chunks * plan_.slab_stride * sizeof(float), &bytes_))) return rc;
+        if ((rc = klist_.ensure(pairs * plan_.k_tiles * sizeof(int), &bytes_))) return rc;
+        if ((rc = kcount_.ensure(pairs * sizeof(int), &bytes_))) return rc;
+        if ((rc = nchunks_.ensure(pairs * sizeof(int), &bytes_))) return rc;
+        HIPCHK(launch_gemm_nt_f32((const float*)bel_.p, S_pad_, (const float*)Y, S_pad_, slabs_.as<float>(), plan_,
+                                  nzA_.as<uint8_t>(), nzB, G, v_group, (int)rows_y, klist_.as<int>(), kcount_.as<int>(),
+                                  nchunks_.as<int>(), stream_));
+        sv->slabs = slabs_.as<T>();
+        sv->slab_stride = plan_.slab_stride;
+        sv->ldc = plan_.ldc;
+        sv->nchunks = nchunks_.as<int>();
+        sv->tiles_m = plan_.tiles_m;
+        sv->fixed = 0;
     } else {
-        lay->split_k = 1;
-        lay->ldc = (int)rows_y;
-        lay->slab_stride = 0;
-        if ((rc = slabs_.ensure((size_t)rows_x * rows_y * sizeof(T), &bytes_))) return rc;
-        HIPCHK(launch_gemm_nt_simple<T>(X, S_pad_, Y, S_pad_, slabs_.as<T>(), lay->ldc, (int)rows_x, (int)rows_y, S_,
-                                        stream_));
+        if ((rc = slabs_.ensure((size_t)B_ * rows_y * sizeof(T), &bytes_))) return rc;
+        HIPCHK(launch_gemm_nt_simple<T>(bel_.as<T>(), S_pad_, Y, S_pad_, slabs_.as<T>(), (int)rows_y, (int)B_, (int)rows_y,
+                                        S_, stream_));
+        sv->slabs = slabs_.as<T>();
+        sv->slab_stride = 0;
+        sv->ldc = (int)rows_y;
+        sv->nchunks = nullptr;
+        sv->tiles_m = 0;
+        sv->fixed = 1;
     }
     return PBVI_OK;
 }
@@ -379,18 +412,17 @@ int EngineT<T>::value_max_device() {
     if ((rc = queue2_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
     int* qc = counters_.as<int>() + 2;
     HIPCHK(hipMemsetAsync(qc, 0, sizeof(int), stream_));
-    ScoreLayout lay;
-    if ((rc = score_gemm(bel_.as<T>(), B_, B_pad_, alpha_.as<T>(), Vt, &lay))) return rc;
-    const int k_chunk = S_pad_ / lay.split_k;
+    SlabView<T> sv;
+    if ((rc = score_gemm(alpha_.as<T>(), Vt, nullptr, 1, (int)V_, &sv))) return rc;
+    const int k_chunk = kF32 ? plan_.chunk_len * GEMM_BK : S_pad_;
     // every belief is re-scored exactly in f32 engines (flag_all): the comparison that
     // follows (new value > old best value) is strict and must not see GEMM rounding
-    HIPCHK(launch_argmax<T>(slabs_.as<T>(), lay.slab_stride, lay.split_k, lay.ldc, (int)V_, (int)Vt, 1, (int)B_, nullptr,
-                            tie_window(k_chunk), 0.0, 1, bv2_.as<int32_t>(), bs2_.as<double>(), err2_.as<double>(),
-                            kF32 ? queue2_.as<int32_t>() : nullptr, qc, stream_));
+    HIPCHK(launch_argmax<T>(sv, (int)V_, 1, (int)B_, nullptr, tie_window(k_chunk), 0.0, 1, bv2_.as<int32_t>(),
+                            bs2_.as<double>(), err2_.as<double>(), kF32 ? queue2_.as<int32_t>() : nullptr, qc, stream_));
     if (kF32)
-        HIPCHK(launch_refine<T>(false, slabs_.as<T>(), lay.slab_stride, lay.split_k, lay.ldc, (int)V_, (int)Vt, 1,
-                                (int)B_, queue2_.as<int32_t>(), qc, bel_.as<T>(), S_pad_, alpha_.as<T>(), S_pad_, view(),
-                                0.0, bv2_.as<int32_t>(), bs2_.as<double>(), err2_.as<double>(), stream_));
+        HIPCHK(launch_refine<T>(false, sv, (int)V_, 1, (int)B_, queue2_.as<int32_t>(), qc, bel_.as<T>(), S_pad_,
+                                alpha_.as<T>(), S_pad_, view(), 0.0, bv2_.as<int32_t>(), bs2_.as<double>(),
+                                err2_.as<double>(), stream_));
     return PBVI_OK;
 }
 
@@ -427,29 +459,47 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)N * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
 
     HIPCHK(hipEventRecord(ev_[0], stream_));
-    // K1: Gamma projection of the V alpha rows and the magnitude row
-    HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, stream_));
-    if (kF32) HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, dead_.as<uint8_t>(), stream_));
+    // Belief-only work (dead triples, b.ER) on the side stream, overlapping projection + GEMM.
+    HIPCHK(hipEventRecord(ev_fork_, stream_));
+    HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+    if (kF32) HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, dead_.as<uint8_t>(), stream2_));
+    HIPCHK(launch_rdot<T>(bel_.as<T>(), S_pad_, (int)B_, mv, rdot_.as<double>(), stream2_));
+    HIPCHK(hipEventRecord(ev_join_, stream2_));
+    // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
+    const int k_tiles = S_pad_ / GEMM_BK;
+    const uint8_t* need = nullptr;
+    if (kF32) {
+        if ((rc = need_.ensure((size_t)AO * k_tiles, &bytes_))) return rc;
+        HIPCHK(launch_need_tiles(nzA_.as<uint8_t>(), (int)(B_pad_ / GEMM_BM), nzB_.as<uint8_t>(), AO, k_tiles,
+                                 need_.as<uint8_t>(), stream_));
+        need = need_.as<uint8_t>();
+    }
+    HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_));
     HIPCHK(hipEventRecord(ev_[1], stream_));
     // K2: scores
-    ScoreLayout lay;
-    if ((rc = score_gemm(bel_.as<T>(), B_, B_pad_, gam_.as<T>(), N, &lay))) return rc;
+    SlabView<T> sv;
+    if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv))) return rc;
     HIPCHK(hipEventRecord(ev_[2], stream_));
-    const int k_chunk = S_pad_ / lay.split_k;
-    HIPCHK(launch_argmax<T>(slabs_.as<T>(), lay.slab_stride, lay.split_k, lay.ldc, (int)V_, (int)Vt, AO, (int)B_,
-                            kF32 ? dead_.as<uint8_t>() : nullptr, tie_window(k_chunk), 0.0, 0, best_v_.as<int32_t>(),
-                            best_score_.as<double>(), err_.as<double>(), kF32 ? queue_.as<int32_t>() : nullptr, qcount,
-                            stream_));
+    HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));       // dead flags + rdot ready
+    const GemmPlan plan = plan_;    // value_max_device (K5) re-plans; keep this GEMM's for the stats
+    const int k_chunk = kF32 ? plan.chunk_len * GEMM_BK : S_pad_;
+    HIPCHK(launch_argmax<T>(sv, (int)V_, AO, (int)B_, kF32 ? dead_.as<uint8_t>() : nullptr, tie_window(k_chunk), 0.0, 0,
+                            best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(),
+                            kF32 ? queue_.as<int32_t>() : nullptr, qcount, stream_));
     HIPCHK(hipEventRecord(ev_[3], stream_));
+    std::vector<int> h_kcount;
+    if (kF32 && st) {   // list lengths of this GEMM (K5 rebuilds the lists for its own GEMM later)
+        h_kcount.resize((size_t)plan.tiles_m * plan.tiles_n);
+        HIPCHK(hipMemcpyAsync(h_kcount.data(), kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    }
     if (kF32)
-        HIPCHK(launch_refine<T>(true, slabs_.as<T>(), lay.slab_stride, lay.split_k, lay.ldc, (int)V_, (int)Vt, AO,
-                                (int)pairs, queue_.as<int32_t>(), qcount, bel_.as<T>(), S_pad_, alpha_.as<T>(), S_pad_, mv,
-                                gamma, best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), stream_));
+        HIPCHK(launch_refine<T>(true, sv, (int)V_, AO, (int)pairs, queue_.as<int32_t>(), qcount, bel_.as<T>(), S_pad_,
+                                alpha_.as<T>(), S_pad_, mv, gamma, best_v_.as<int32_t>(), best_score_.as<double>(),
+                                err_.as<double>(), stream_));
     HIPCHK(hipEventRecord(ev_[4], stream_));
     // K4: action
-    HIPCHK(launch_action<T>(bel_.as<T>(), S_pad_, (int)B_, mv, best_score_.as<double>(), err_.as<double>(),
-                            rdot_.as<double>(), action_.as<int32_t>(), kF32 ? aqueue_.as<int32_t>() : nullptr, aqcount,
-                            stream_));
+    HIPCHK(launch_action<T>((int)B_, mv, rdot_.as<double>(), best_score_.as<double>(), err_.as<double>(),
+                            action_.as<int32_t>(), kF32 ? aqueue_.as<int32_t>() : nullptr, aqcount, stream_));
     if (kF32)
         HIPCHK(launch_refine_action<T>(bel_.as<T>(), S_pad_, (int)B_, alpha_.as<T>(), S_pad_, mv, gamma,
                                        aqueue_.as<int32_t>(), aqcount, rdot_.as<double>(), best_v_.as<int32_t>(),
@@ -502,7 +552,17 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
             st->n_dead = nd;
         }
         st->score_flops = 2 * B_ * (int64_t)S_ * AO * V_;
-        st->split_k = lay.split_k;
+        if (kF32) {
+            int64_t kt_sum = 0;
+            for (int c : h_kcount) kt_sum += c;
+            st->score_flops_executed = kt_sum * 2LL * GEMM_BM * GEMM_BN * GEMM_BK;
+            st->score_tiles_dense = (int64_t)plan.tiles_m * plan.tiles_n * plan.k_tiles;
+            st->score_tiles_run = kt_sum;
+            st->split_k = plan.max_chunks;
+        } else {
+            st->score_flops_executed = st->score_flops;
+            st->split_k = 1;
+        }
     }
     return PBVI_OK;
 }

@@ -21,6 +21,8 @@
 // that share one Gamma tile run on the same XCD (one L2 fill per Gamma tile).
 #include "pbvi_common.h"
 
+#include <cstdlib>
+
 namespace pbvi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,25 +38,33 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 
 __global__ __launch_bounds__(512) void k_gemm_nt_f32_mfma(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
-    int ldc, int64_t slab_stride, int tiles_m, int tiles_n, int k_tiles, int split_k) {
+    int ldc, int64_t slab_stride, int tiles_m, int tiles_n, int k_tiles, int chunk_len, int max_chunks,
+    const int* __restrict__ klist, const int* __restrict__ kcount) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
-    // XCD-aware, bijective remap: blocks b and b+8 share an XCD; give each XCD a
-    // contiguous run of logical ids so its L2 sees each Gamma tile once.
-    int L;
-    {
-        const int total = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, q = total >> 3, r = total & 7;
-        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        L = base + (bid >> 3);
-    }
-    const int tm = L % tiles_m;
-    const int rest = L / tiles_m;
-    const int tn = rest % tiles_n;
-    const int z = rest / tiles_n;
-    const int kt0 = (int)(((unsigned)z * (unsigned)k_tiles) / (unsigned)split_k);
-    const int kt1 = (int)(((unsigned)(z + 1) * (unsigned)k_tiles) / (unsigned)split_k);
+    // Work-item map.  Blocks b and b+8 share an XCD (round-robin dispatch), and the dispatcher
+    // hands blocks out in id order.  A group = the tiles_m M-tiles of one (n-tile, chunk): they
+    // read the same Gamma tile rows, so a group stays on ONE XCD (one L2 fill), while groups are
+    // dealt round-robin over the 8 XCDs with the chunk index slowest -- every XCD gets the same
+    // share of each chunk level, and the chunks that do not exist (short K lists) sit at the end
+    // of the grid where they exit at once.  Placement affects speed only.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int tm = slot % tiles_m;
+    const int q = (slot / tiles_m) * 8 + xcd;           // group id
+    const int tn = q % tiles_n;
+    const int z = q / tiles_n;
+    if (z >= max_chunks) return;                        // grid is padded to a multiple of 8 groups
+    // K-tile list of this (m-tile, n-tile) pair: only tiles where both operands are non-zero.
+    // Chunk z of the pair covers list entries [z*chunk_len, (z+1)*chunk_len); a chunk past the
+    // end of the list does not exist (its slab is never read: consumers use the same count).
+    const int pair = tn * tiles_m + tm;
+    const int cnt = kcount[pair];
+    const int kt0 = z * chunk_len;
+    const int kt1 = (kt0 + chunk_len < cnt) ? kt0 + chunk_len : cnt;
+    if (kt0 >= kt1) return;
+    const int* __restrict__ kl = klist + (int64_t)pair * k_tiles;
 
     const float* Ablk = A + (int64_t)tm * 256 * lda;
     const float* Bblk = B + (int64_t)tn * 256 * ldb;
@@ -124,13 +134,13 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_mfma(
         }
     };
 
-    if (kt0 < kt1) {
-        stage(0, kt0);
+    {
+        stage(0, kl[kt0]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int buf = 0;
-        for (int kt = kt0; kt < kt1; ++kt) {
-            if (kt + 1 < kt1) stage(buf ^ 1, kt + 1);
+        for (int it = kt0; it < kt1; ++it) {
+            if (it + 1 < kt1) stage(buf ^ 1, kl[it + 1]);
             compute(buf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -153,28 +163,109 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_mfma(
         }
 }
 
-int choose_split_k(int tiles_mn, int k_tiles) {
-    const int cus = 256;
-    int best = 1;
-    double best_eff = 0.0;
-    const int smax = k_tiles < 64 ? (k_tiles < 1 ? 1 : k_tiles) : 64;
-    for (int s = 1; s <= smax; ++s) {
-        if (s > 1 && k_tiles / s < 4) break;                 // keep chunks long enough to pipeline
-        const int64_t total = (int64_t)tiles_mn * s;
-        const int64_t rounds = (total + cus - 1) / cus;
-        const double eff = (double)total / (double)(rounds * cus);
-        if (eff > best_eff + 1e-9) {
-            best_eff = eff;
-            best = s;
+// --------------------------------------------------------------------------- //
+// Zero-tile bookkeeping (exact: a skipped tile contributes only +0 products)
+// --------------------------------------------------------------------------- //
+// nz[tile][kt] = 1 iff the 256-row x 32-column block of X has a non-zero entry.
+__global__ void k_tile_nonzero(const float* __restrict__ X, int ld, int k_tiles, uint8_t* __restrict__ nz) {
+    const int tile = blockIdx.y;
+    const int row = tile * 256 + threadIdx.x;
+    const f32x4* p = (const f32x4*)(X + (int64_t)row * ld);
+    for (int j = 0; j < 8; ++j) {
+        const int kt = blockIdx.x * 8 + j;
+        if (kt >= k_tiles) break;                       // block-uniform
+        int f = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 v = p[kt * 8 + c];
+            f |= (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f);
         }
-        if (eff >= 0.95) break;                               // smallest split that fills the chip
+        const int any = __syncthreads_or(f);
+        if (threadIdx.x == 0) nz[(int64_t)tile * k_tiles + kt] = any ? 1 : 0;
     }
-    return best;
 }
 
-hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                              int64_t slab_stride, int M_pad, int N_pad, int K_pad, int split_k,
-                              hipStream_t stream) {
+// One block per (m-tile, n-tile) pair: compact the K tiles where both operands are non-zero.
+// The B operand's zero structure is per row group: rows [g*v_group, (g+1)*v_group) share the
+// support nzB[g][kt] (Gamma rows of one (action, observation)); rows >= G*v_group (the magnitude
+// rows) may touch any group.  nzB == nullptr means a dense B operand.
+__global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* __restrict__ nzB, int G,
+                               int v_group, int n_rows, int tiles_m, int k_tiles, int chunk_len, int force_dense,
+                               int* __restrict__ klist, int* __restrict__ kcount, int* __restrict__ nchunks) {
+    __shared__ int wcount[4];
+    __shared__ int total;
+    const int pair = blockIdx.x;
+    const int tm = pair % tiles_m, tn = pair / tiles_m;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r0 = tn * 256;
+    int r1 = r0 + 255;
+    if (r1 >= n_rows) r1 = n_rows - 1;
+    int g0 = 0, g1 = -1;                                // group range touched by this n-tile
+    if (nzB != nullptr && r0 < n_rows) {
+        if (r1 >= G * v_group) {
+            g0 = 0;
+            g1 = G - 1;
+        } else {
+            g0 = r0 / v_group;
+            g1 = r1 / v_group;
+        }
+    }
+    if (tid == 0) total = 0;
+    __syncthreads();
+    for (int base = 0; base < k_tiles; base += 256) {
+        const int kt = base + tid;
+        int f = 0;
+        if (force_dense) {
+            f = kt < k_tiles;
+        } else if (kt < k_tiles && r0 < n_rows && nzA[(int64_t)tm * k_tiles + kt]) {
+            if (nzB == nullptr) {
+                f = 1;
+            } else {
+                for (int g = g0; g <= g1; ++g) f |= nzB[(int64_t)g * k_tiles + kt];
+            }
+        }
+        const unsigned long long mask = __ballot(f);
+        if (lane == 0) wcount[wid] = __popcll(mask);
+        __syncthreads();
+        int off = total;
+        for (int w = 0; w < wid; ++w) off += wcount[w];
+        if (f) klist[(int64_t)pair * k_tiles + off + __popcll(mask & ((1ull << lane) - 1ull))] = kt;
+        __syncthreads();
+        if (tid == 0) total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        kcount[pair] = total;
+        nchunks[pair] = (total + chunk_len - 1) / chunk_len;
+    }
+}
+
+int choose_chunk_len(int tiles_mn, int k_tiles) {
+    // Work items are (pair, chunk of <= chunk_len listed K tiles).  Aim at ~8 items per CU when
+    // every tile is non-zero; sparse inputs only make items fewer / shorter.  Longer chunks mean
+    // fewer partial slabs for the argmax to reduce (measured at C4: 96 -> 5.41 ms/step, 32 -> 5.86).
+    // Override with PBVI_GEMM_CHUNK for tuning.
+    if (const char* env = getenv("PBVI_GEMM_CHUNK")) {
+        const int v = atoi(env);
+        if (v > 0) return v < k_tiles ? v : k_tiles;
+    }
+    const int64_t total = (int64_t)tiles_mn * k_tiles;
+    int64_t len = total / (256 * 8);
+    if (len < 8) len = 8;
+    if (len > 96) len = 96;
+    if (len > k_tiles) len = k_tiles;
+    return (int)len;
+}
+
+hipError_t launch_tile_nonzero_f32(const float* X, int ld, int rows_pad, int k_tiles, uint8_t* nz, hipStream_t stream) {
+    dim3 grid((k_tiles + 7) / 8, rows_pad / 256);
+    hipLaunchKernelGGL(k_tile_nonzero, grid, dim3(256), 0, stream, X, ld, k_tiles, nz);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, const GemmPlan& pl,
+                              const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
+                              int* kcount, int* nchunks, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nt_f32_mfma,
@@ -182,12 +273,31 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int tiles_m = M_pad / GEMM_BM, tiles_n = N_pad / GEMM_BN, k_tiles = K_pad / GEMM_BK;
-    const int64_t total = (int64_t)tiles_m * tiles_n * split_k;
+    const int pairs = pl.tiles_m * pl.tiles_n;
+    static const int force_dense = getenv("PBVI_GEMM_DENSE") ? atoi(getenv("PBVI_GEMM_DENSE")) : 0;   // debug / A-B only
+    hipLaunchKernelGGL(k_build_klists, dim3(pairs), dim3(256), 0, stream, nzA, nzB, G, v_group, n_rows, pl.tiles_m,
+                       pl.k_tiles, pl.chunk_len, force_dense, klist, kcount, nchunks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t groups = ((int64_t)pl.tiles_n * pl.max_chunks + 7) / 8 * 8;
+    const int64_t total = groups * pl.tiles_m;
     if (total <= 0 || total > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_gemm_nt_f32_mfma, dim3((unsigned)total), dim3(512), GEMM_LDS_BYTES, stream,
-                       A, lda, B, ldb, C, ldc, slab_stride, tiles_m, tiles_n, k_tiles, split_k);
+    hipLaunchKernelGGL(k_gemm_nt_f32_mfma, dim3((unsigned)total), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B, ldb, C,
+                       pl.ldc, pl.slab_stride, pl.tiles_m, pl.tiles_n, pl.k_tiles, pl.chunk_len, pl.max_chunks, klist,
+                       kcount);
     return hipGetLastError();
+}
+
+GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad) {
+    GemmPlan pl;
+    pl.tiles_m = M_pad / GEMM_BM;
+    pl.tiles_n = N_pad / GEMM_BN;
+    pl.k_tiles = K_pad / GEMM_BK;
+    pl.chunk_len = choose_chunk_len(pl.tiles_m * pl.tiles_n, pl.k_tiles);
+    pl.max_chunks = (pl.k_tiles + pl.chunk_len - 1) / pl.chunk_len;
+    pl.ldc = N_pad;
+    pl.slab_stride = (int64_t)M_pad * N_pad;
+    return pl;
 }
 
 // --------------------------------------------------------------------------- //

@@ -19,18 +19,25 @@ constexpr int GEMM_BK = 32;
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-// C[z][m][n] = sum over K-chunk z of A[m][k] * B[n][k]   (both operands K-contiguous).
-// f32: hand-written MFMA kernel, split-K partial slabs (z = 0..split_k-1), fixed-order
-// reduction left to the consumer.  M_pad/N_pad multiples of 256, K_pad multiple of 32.
-hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                              int64_t slab_stride, int M_pad, int N_pad, int K_pad, int split_k,
-                              hipStream_t stream);
+// f32 score GEMM on MFMA with exact zero-tile skipping.
+//   C[z][m][n] = sum over chunk z of the pair's K-tile list of A[m][k] * B[n][k]
+// Both operands K-contiguous; M_pad/N_pad multiples of 256, K_pad a multiple of 32.  For every
+// (m-tile, n-tile) pair the K tiles where both operands are non-zero are listed (klist/kcount);
+// chunk z covers list entries [z*chunk_len, (z+1)*chunk_len).  nchunks[pair] tells the consumer
+// how many slabs to sum (fixed order; pairs with an empty list have score exactly 0).
+struct GemmPlan {
+    int tiles_m, tiles_n, k_tiles, chunk_len, max_chunks, ldc;
+    int64_t slab_stride;
+};
+GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad);
+hipError_t launch_tile_nonzero_f32(const float* X, int ld, int rows_pad, int k_tiles, uint8_t* nz, hipStream_t stream);
+hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, const GemmPlan& pl,
+                              const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
+                              int* kcount, int* nchunks, hipStream_t stream);
 // Any-size reference GEMM (used for f64 engines): C[m][n], no padding requirements.
 template <typename T>
 hipError_t launch_gemm_nt_simple(const T* A, int lda, const T* B, int ldb, T* C, int ldc,
                                  int M, int N, int K, hipStream_t stream);
 
-// Pick the K-split so tiles * split_k fills the 256 CUs evenly.
-int choose_split_k(int tiles_mn, int k_tiles);
 
 }  // namespace pbvi
