@@ -37,9 +37,17 @@ def cpu_baseline(m, alpha, beliefs, sample: int):
     t0 = time.perf_counter()
     orc.backup_core(alpha, b, m.reachable_states, m.rto, m.expected_rewards, m.gamma)
     dt = time.perf_counter() - t0
-    return {'value': sample / dt, 'unit': 'backups/s', 'cores': os.cpu_count(), 'kind': 'port',
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    blas_threads = None
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max((p.get('num_threads', 0) for p in threadpool_info() if p.get('user_api') == 'blas'), default=None)
+    except Exception:
+        pass
+    return {'value': sample / dt, 'unit': 'backups/s', 'cores': blas_threads or cores, 'kind': 'port',
             'sample': f'first {sample} of the {beliefs.shape[0]} beliefs x all {alpha.shape[0]} alpha-vectors, '
-                      f'untiled NumPy fp64 statements, 1 call, {dt:.1f} s'}
+                      f'untiled NumPy fp64 statements (oracle/pbvi_oracle.py::backup_core), 1 call, {dt:.1f} s; '
+                      f'{cores} schedulable cores, OpenBLAS threads {blas_threads}'}
 
 
 def main():
@@ -50,7 +58,7 @@ def main():
     ap.add_argument('--beliefs', type=int, default=1024, help='beliefs per GPU')
     ap.add_argument('--alphas', type=int, default=1024)
     ap.add_argument('--reach', type=int, default=1, choices=[1, 5], help='reachable states per (s,a)')
-    ap.add_argument('--cpu-sample', type=int, default=128, help='beliefs in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=1024, help='beliefs in the CPU baseline sample (0 = skip)')
     ap.add_argument('--grid', type=str, default='75x400')
     args = ap.parse_args()
 
@@ -62,7 +70,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N')
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get('PBVI_FORCE_DIST') == '1'   # the latter: rehearse the RCCL path on one GPU
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -32,29 +32,57 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 }
 
 // Partial (this thread's share) of  sum_s b[s] * gamma * sum_r rto[a][o][r][s] * alpha_v[rs[a][r][s]]
+// in f64.  Four states per thread are in flight at once (independent load chains) because this
+// runs in latency-bound refinement kernels; b[s] = 0 terms are multiplied through, not branched.
 template <typename T>
 __device__ __forceinline__ double proj_dot_partial(const T* __restrict__ brow, const T* __restrict__ arow,
                                                    const ModelView<T>& mv, int a, int o, double gamma) {
-    const int32_t* rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
-    const T* rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
-    double acc = 0.0;
-    for (int s = threadIdx.x; s < mv.S; s += blockDim.x) {
-        const double bs = (double)brow[s];
-        if (bs != 0.0) {
-            double g = 0.0;
-            for (int r = 0; r < mv.R; ++r)
-                g += (double)rto[(int64_t)r * mv.S_pad + s] * (double)arow[rs[(int64_t)r * mv.S_pad + s]];
-            acc += bs * (gamma * g);
+    const int32_t* __restrict__ rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
+    const T* __restrict__ rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
+    const int stride = blockDim.x;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int s = threadIdx.x;
+    for (; s + 3 * stride < mv.S; s += 4 * stride) {
+        const double b0 = (double)brow[s], b1 = (double)brow[s + stride], b2 = (double)brow[s + 2 * stride],
+                     b3 = (double)brow[s + 3 * stride];
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+        for (int r = 0; r < mv.R; ++r) {
+            const int64_t ro = (int64_t)r * mv.S_pad;
+            const int i0 = rs[ro + s], i1 = rs[ro + s + stride], i2 = rs[ro + s + 2 * stride], i3 = rs[ro + s + 3 * stride];
+            const double w0 = (double)rto[ro + s], w1 = (double)rto[ro + s + stride], w2 = (double)rto[ro + s + 2 * stride],
+                         w3 = (double)rto[ro + s + 3 * stride];
+            g0 += w0 * (double)arow[i0];
+            g1 += w1 * (double)arow[i1];
+            g2 += w2 * (double)arow[i2];
+            g3 += w3 * (double)arow[i3];
         }
+        acc0 += b0 * (gamma * g0);
+        acc1 += b1 * (gamma * g1);
+        acc2 += b2 * (gamma * g2);
+        acc3 += b3 * (gamma * g3);
     }
-    return acc;
+    for (; s < mv.S; s += stride) {
+        double g = 0.0;
+        for (int r = 0; r < mv.R; ++r)
+            g += (double)rto[(int64_t)r * mv.S_pad + s] * (double)arow[rs[(int64_t)r * mv.S_pad + s]];
+        acc0 += (double)brow[s] * (gamma * g);
+    }
+    return (acc0 + acc1) + (acc2 + acc3);
 }
 
 template <typename T>
 __device__ __forceinline__ double plain_dot_partial(const T* __restrict__ brow, const T* __restrict__ arow, int S) {
-    double acc = 0.0;
-    for (int s = threadIdx.x; s < S; s += blockDim.x) acc += (double)brow[s] * (double)arow[s];
-    return acc;
+    const int stride = blockDim.x;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int s = threadIdx.x;
+    for (; s + 3 * stride < S; s += 4 * stride) {
+        acc0 += (double)brow[s] * (double)arow[s];
+        acc1 += (double)brow[s + stride] * (double)arow[s + stride];
+        acc2 += (double)brow[s + 2 * stride] * (double)arow[s + 2 * stride];
+        acc3 += (double)brow[s + 3 * stride] * (double)arow[s + 3 * stride];
+    }
+    for (; s < S; s += stride) acc0 += (double)brow[s] * (double)arow[s];
+    return (acc0 + acc1) + (acc2 + acc3);
 }
 
 // ------------------------------------------------------------------------- //
@@ -229,35 +257,38 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
         return;
     }
     const int64_t col0 = (int64_t)g * V;
-    T m = -std::numeric_limits<T>::infinity();
+    // one pass: running maximum (first index) and runner-up value per lane, merged across the wave
+    T m = -std::numeric_limits<T>::infinity(), m2 = -std::numeric_limits<T>::infinity();
     int idx = 0x7fffffff;
     for (int v = lane; v < V; v += 64) {
         const T sc = sv.at(b, col0 + v);
         if (sc > m || idx == 0x7fffffff) {
+            m2 = (idx == 0x7fffffff) ? m2 : m;
             m = sc;
             idx = v;
+        } else if (sc > m2) {
+            m2 = sc;                                        // includes sc == m (a later exact tie)
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const T om = __shfl_xor(m, off, 64);
+        const T om = __shfl_xor(m, off, 64), om2 = __shfl_xor(m2, off, 64);
         const int oi = __shfl_xor(idx, off, 64);
+        const T lo = om < m ? om : m;                       // the loser of the two maxima is a runner-up
+        T n2 = m2 > om2 ? m2 : om2;
+        if (oi != 0x7fffffff && idx != 0x7fffffff) n2 = lo > n2 ? lo : n2;
         if (om > m || (om == m && oi < idx)) {
             m = om;
             idx = oi;
         }
+        m2 = n2;
     }
     double E = 0.0;
     int push = 0;
     if (queue != nullptr) {
         const double mag = fmax(fabs((double)m), fabs((double)sv.at(b, (int64_t)G * V + g)));
         E = tol_rel * mag + tol_abs;
-        const double thr = (double)m - 2.0 * E;
-        int cnt = 0;
-        for (int v = lane; v < V; v += 64) cnt += ((double)sv.at(b, col0 + v) >= thr) ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-        push = (flag_all || cnt > 1) ? 1 : 0;
+        push = (flag_all || (double)m2 >= (double)m - 2.0 * E) ? 1 : 0;
     }
     if (lane == 0) {
         best_v[gw] = idx;

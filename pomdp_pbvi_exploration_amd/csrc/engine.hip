@@ -459,12 +459,6 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)N * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
 
     HIPCHK(hipEventRecord(ev_[0], stream_));
-    // Belief-only work (dead triples, b.ER) on the side stream, overlapping projection + GEMM.
-    HIPCHK(hipEventRecord(ev_fork_, stream_));
-    HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
-    if (kF32) HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, dead_.as<uint8_t>(), stream2_));
-    HIPCHK(launch_rdot<T>(bel_.as<T>(), S_pad_, (int)B_, mv, rdot_.as<double>(), stream2_));
-    HIPCHK(hipEventRecord(ev_join_, stream2_));
     // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
     const int k_tiles = S_pad_ / GEMM_BK;
     const uint8_t* need = nullptr;
@@ -476,6 +470,13 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     }
     HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_));
     HIPCHK(hipEventRecord(ev_[1], stream_));
+    // Belief-only work (dead triples, b.ER) goes to the side stream so it runs beside the MFMA-bound
+    // score GEMM (it needs memory bandwidth, the GEMM does not) rather than beside the projection.
+    HIPCHK(hipEventRecord(ev_fork_, stream_));
+    HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+    if (kF32) HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, dead_.as<uint8_t>(), stream2_));
+    HIPCHK(launch_rdot<T>(bel_.as<T>(), S_pad_, (int)B_, mv, rdot_.as<double>(), stream2_));
+    HIPCHK(hipEventRecord(ev_join_, stream2_));
     // K2: scores
     SlabView<T> sv;
     if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv))) return rc;
