@@ -60,6 +60,9 @@ def main():
     ap.add_argument('--reach', type=int, default=1, choices=[1, 5], help='reachable states per (s,a)')
     ap.add_argument('--cpu-sample', type=int, default=1024, help='beliefs in the CPU baseline sample (0 = skip)')
     ap.add_argument('--grid', type=str, default='75x400')
+    ap.add_argument('--mode', type=str, default='sparse', choices=['sparse', 'dense'],
+                    help="projection: reachable-sparse ELL SpMM (BASELINE config 3, the reference's path) or dense "
+                         "|A||O| MFMA GEMMs over densified T.O (config 2; 65 GB of matrices at S=30000)")
     args = ap.parse_args()
 
     import torch
@@ -86,7 +89,8 @@ def main():
     B = args.beliefs
     beliefs = synth.belief_points(m, B, start=rank * B)            # this rank's block of the global set
 
-    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32', device=local_rank)
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32', device=local_rank,
+                 mode=args.mode)
     eng.set_alpha(alpha)
     eng.set_beliefs(beliefs)
     shard = EngineShard(eng, m.gamma)
@@ -137,7 +141,7 @@ def main():
             'metric': 'alpha-vector backups/sec', 'value': B * world * K / elapsed, 'unit': 'backups/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'olfactory-{m.S} reachable-sparse R={m.R} backup (S={m.S}, A={m.A}, O={m.O}), '
+            'config': {'workload': f'olfactory-{m.S} {"reachable-sparse" if args.mode == "sparse" else "dense-projection"} R={m.R} backup (S={m.S}, A={m.A}, O={m.O}), '
                                    f'V={args.alphas} alpha-vectors, B={B} beliefs per GPU',
                        'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': args.alphas, 'B_per_gpu': B,
                        'parallelism': f'belief-sharded x{world}, 1 all-gather of alpha rows' if distributed else 'single GPU'},
@@ -153,6 +157,14 @@ def main():
             'refined_pairs': int(stats[-1]['n_refined']), 'dead_pairs': int(stats[-1]['n_dead']),
             'refined_actions': int(stats[-1]['n_refined_actions']), 'pairs': int(stats[-1]['n_pairs']), 'split_k': int(stats[-1]['split_k']),
         }
+        if args.mode == 'dense':   # the projection GEMMs dominate: report them as the roofline kernel
+            ms_proj = float(np.mean([s['ms_project'] for s in stats]))
+            pf, pfe = stats[0]['project_flops'], stats[0]['project_flops_executed']
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'k_gemm_nt_f32_mfma (dense projection, batched over (a,o))',
+                               'achieved': pfe / (ms_proj * 1e-3) / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': pfe / (ms_proj * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                               'flops_per_launch': pfe, 'ms_per_launch': ms_proj, 'dense_flops_per_launch': pf,
+                               'note': 'ms_project also holds the memset / scale-copy passes around the GEMM'}
         if host_ms is not None:
             out['pcie_inclusive'] = {'ms_per_step': host_ms, 'value': B / (host_ms * 1e-3), 'unit': 'backups/s'}
         if world == 1 and args.cpu_sample > 0:

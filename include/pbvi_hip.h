@@ -72,6 +72,8 @@ typedef struct pbvi_stats {
     int64_t score_flops_executed; /* MFMA flops actually issued (zero tiles skipped, pad tiles included) */
     int64_t score_tiles_dense;    /* 256x256x32 tile steps a dense GEMM of the padded shape would run */
     int64_t score_tiles_run;      /* tile steps actually run */
+    int64_t project_flops;          /* dense mode: algorithmic 2*A*O*V*S*S of the projection GEMMs, else 0 */
+    int64_t project_flops_executed; /* dense mode: MFMA flops issued by the projection GEMMs */
     int32_t split_k;        /* max K-chunks (partial slabs) per tile pair */
     int32_t reserved;
 } pbvi_stats_t;

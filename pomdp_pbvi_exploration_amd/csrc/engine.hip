@@ -83,6 +83,41 @@ __global__ void k_col_absmax(const T* __restrict__ alpha, int lda, int V, int S_
     out[s] = m;
 }
 
+// Dense projection mode: D[ao][s][s'] = sum_{r: rs[s,a,r] = s'} RTO[s,a,o,r]  (one thread per row, no races)
+template <typename T>
+__global__ void k_densify(ModelView<T> mv, T* __restrict__ D, int64_t rows_pad) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int ao = blockIdx.y;
+    if (s >= mv.S) return;
+    const int a = ao / mv.O;
+    T* row = D + ((int64_t)ao * rows_pad + s) * mv.S_pad;
+    for (int r = 0; r < mv.R; ++r)
+        row[mv.rs[((int64_t)a * mv.R + r) * mv.S_pad + s]] += mv.rto[((int64_t)ao * mv.R + r) * mv.S_pad + s];
+}
+
+// Gamma rows <- gamma * (alpha . D_ao^T) rows: product row v of batch ao goes to Gamma row ao*V+v.
+template <typename T>
+__global__ void k_scale_rows(const T* __restrict__ prod, int64_t batch_stride, int ld_prod, int V, T gamma,
+                             T* __restrict__ gam, int ldg, int width) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y, ao = blockIdx.z;
+    if (s >= width) return;
+    gam[((int64_t)ao * V + v) * ldg + s] = gamma * prod[(int64_t)ao * batch_stride + (int64_t)v * ld_prod + s];
+}
+
+// The A*O magnitude rows (tail of Gamma) from the ELL tables: one row each, not worth a GEMM tile row.
+template <typename T>
+__global__ void k_project_mag(const T* __restrict__ amax, ModelView<T> mv, T gamma, T* __restrict__ gam_tail, int ldg) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int ao = blockIdx.y;
+    if (s >= mv.S_pad) return;
+    const int a = ao / mv.O;
+    T acc = T(0);
+    for (int r = 0; r < mv.R; ++r)
+        acc += mv.rto[((int64_t)ao * mv.R + r) * mv.S_pad + s] * amax[mv.rs[((int64_t)a * mv.R + r) * mv.S_pad + s]];
+    gam_tail[(int64_t)ao * ldg + s] = gamma * acc;
+}
+
 class EngineBase {
    public:
     virtual ~EngineBase() {}
@@ -118,6 +153,9 @@ class EngineT : public EngineBase {
     DevBuf gam_, slabs_, best_v_, best_score_, err_, dead_, queue_, counters_, rdot_, action_, aqueue_, out_, keep_;
     DevBuf bv2_, bs2_, err2_, queue2_, prune_cnt_;
     DevBuf nzB_, nzA_, klist_, kcount_, nchunks_, need_;   // zero-tile bookkeeping of the f32 score GEMM
+    DevBuf dense_, nzD_, nzAlpha_, prod_, klistD_, kcountD_, nchunksD_;   // dense projection mode
+    int64_t rows_pad_s_ = 0, dense_pairs_ = 0;
+    std::vector<int> h_kcountD_;
     hipStream_t stream2_ = nullptr;                  // belief-only kernels run beside projection + GEMM
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     GemmPlan plan_ = {};
@@ -129,7 +167,8 @@ class EngineT : public EngineBase {
         (void)hipSetDevice(device_);
         DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
-                         &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_};
+                         &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_,
+                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
             if (e) (void)hipEventDestroy(e);
@@ -209,6 +248,24 @@ class EngineT : public EngineBase {
                         if (h_rto[((size_t)ao * R + r) * S_pad_ + s] != T(0)) h_nz[(size_t)ao * k_tiles + s / GEMM_BK] = 1;
             if ((rc = nzB_.ensure(h_nz.size(), &bytes_))) return rc;
             HIPCHK(hipMemcpyAsync(nzB_.p, h_nz.data(), h_nz.size(), hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+        }
+        if (mode_ == PBVI_DENSE) {   // D[ao] = dense |S| x |S| transition-observation matrices
+            rows_pad_s_ = round_up(S, GEMM_BN);
+            const size_t n = (size_t)A * O * rows_pad_s_ * S_pad_;
+            if ((rc = dense_.ensure(n * sizeof(T), &bytes_))) return rc;
+            HIPCHK(hipMemsetAsync(dense_.p, 0, n * sizeof(T), stream_));
+            hipLaunchKernelGGL(k_densify<T>, dim3((S + 255) / 256, A * O), dim3(256), 0, stream_, view(), dense_.as<T>(),
+                               rows_pad_s_);
+            HIPCHK(hipGetLastError());
+            if (kF32) {
+                const int k_tiles = S_pad_ / GEMM_BK;
+                const size_t per = (size_t)(rows_pad_s_ / GEMM_BN) * k_tiles;
+                if ((rc = nzD_.ensure((size_t)A * O * per, &bytes_))) return rc;
+                for (int ao = 0; ao < A * O; ++ao)
+                    HIPCHK(launch_tile_nonzero_f32((const float*)dense_.p + (size_t)ao * rows_pad_s_ * S_pad_, S_pad_,
+                                                   (int)rows_pad_s_, k_tiles, nzD_.as<uint8_t>() + ao * per, stream_));
+            }
             HIPCHK(hipStreamSynchronize(stream_));
         }
         HIPCHK(hipStreamSynchronize(stream_));
@@ -309,6 +366,7 @@ class EngineT : public EngineBase {
     // G row groups of v_group rows with support nzB (nullptr = dense Y).
     int score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv);
 
+    int project_dense(double gamma);   // K1-dense: Gamma = gamma * alpha . D_ao^T as A*O (batched) GEMMs
     int backup_run(double gamma, int flags, pbvi_stats_t* st) override;
 
     int backup_fetch(void* out_alpha, int32_t* out_action, int32_t* out_best, uint8_t* out_keep) override {
@@ -403,6 +461,48 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
 }
 
 template <typename T>
+int EngineT<T>::project_dense(double gamma) {
+    int rc;
+    const int AO = A_ * O_;
+    const int64_t Vt = V_, Vt_pad = round_up(Vt, GEMM_BM);   // the magnitude row is projected separately below
+    int64_t ld_prod, batch_stride;
+    if constexpr (kF32) {
+        const int64_t n_pad = rows_pad_s_;
+        GemmPlan pl = make_gemm_plan((int)Vt_pad, (int)n_pad, S_pad_, /*single_chunk=*/true);
+        const size_t pairs = (size_t)pl.tiles_m * pl.tiles_n;
+        ld_prod = n_pad;
+        batch_stride = Vt_pad * n_pad;
+        if ((rc = prod_.ensure((size_t)AO * batch_stride * sizeof(float), &bytes_))) return rc;
+        if ((rc = nzAlpha_.ensure((size_t)pl.tiles_m * pl.k_tiles, &bytes_))) return rc;
+        if ((rc = klistD_.ensure((size_t)AO * pairs * pl.k_tiles * sizeof(int), &bytes_))) return rc;
+        if ((rc = kcountD_.ensure((size_t)AO * pairs * sizeof(int), &bytes_))) return rc;
+        if ((rc = nchunksD_.ensure((size_t)AO * pairs * sizeof(int), &bytes_))) return rc;
+        dense_pairs_ = (int64_t)AO * pairs;
+        HIPCHK(hipMemsetAsync(prod_.p, 0, (size_t)AO * batch_stride * sizeof(float), stream_));   // pairs with empty lists
+        HIPCHK(launch_tile_nonzero_f32((const float*)alpha_.p, S_pad_, (int)Vt_pad, pl.k_tiles, nzAlpha_.as<uint8_t>(), stream_));
+        HIPCHK(launch_gemm_nt_f32((const float*)alpha_.p, S_pad_, (const float*)dense_.p, S_pad_, prod_.as<float>(), pl,
+                                  nzAlpha_.as<uint8_t>(), nzD_.as<uint8_t>(), 0, 0, S_, klistD_.as<int>(),
+                                  kcountD_.as<int>(), nchunksD_.as<int>(), stream_, AO, rows_pad_s_ * (int64_t)S_pad_,
+                                  batch_stride));
+    } else {
+        ld_prod = S_;
+        batch_stride = Vt * S_;
+        if ((rc = prod_.ensure((size_t)AO * batch_stride * sizeof(T), &bytes_))) return rc;
+        for (int ao = 0; ao < AO; ++ao)
+            HIPCHK(launch_gemm_nt_simple<T>(alpha_.as<T>(), S_pad_, dense_.as<T>() + (size_t)ao * rows_pad_s_ * S_pad_, S_pad_,
+                                            prod_.as<T>() + (size_t)ao * batch_stride, (int)ld_prod, (int)Vt, S_, S_, stream_));
+    }
+    dim3 grid((S_ + 255) / 256, (unsigned)Vt, AO);
+    hipLaunchKernelGGL(k_scale_rows<T>, grid, dim3(256), 0, stream_, prod_.as<T>(), batch_stride, (int)ld_prod, (int)V_,
+                       (T)gamma, gam_.as<T>(), S_pad_, S_);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_project_mag<T>, dim3((S_pad_ + 255) / 256, AO), dim3(256), 0, stream_,
+                       alpha_.as<T>() + (size_t)V_ * S_pad_, view(), (T)gamma, gam_.as<T>() + (size_t)AO * V_ * S_pad_, S_pad_);
+    HIPCHK(hipGetLastError());
+    return PBVI_OK;
+}
+
+template <typename T>
 int EngineT<T>::value_max_device() {
     int rc;
     const int64_t Vt = V_ + 1;   // + magnitude row
@@ -430,7 +530,6 @@ template <typename T>
 int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     if (V_ <= 0) FAIL(PBVI_EINVAL, "backup_run: no alpha set resident (call pbvi_alpha_set)");
     if (B_ <= 0) FAIL(PBVI_EINVAL, "backup_run: no belief block resident (call pbvi_beliefs_set)");
-    if (mode_ != PBVI_SPARSE) FAIL(PBVI_EUNSUPPORTED, "backup_run: dense projection mode is not built yet");
     HIPCHK(hipSetDevice(device_));
     int rc;
     const int AO = A_ * O_;
@@ -468,7 +567,18 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
                                  need_.as<uint8_t>(), stream_));
         need = need_.as<uint8_t>();
     }
-    HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_));
+    if (mode_ == PBVI_DENSE) {
+        if (Vt > 65535) FAIL(PBVI_EUNSUPPORTED, "dense mode: at most 65534 alpha-vectors");
+        // pad columns s >= S of the Gamma rows stay zero: clear them once per run (cheap) -- k_scale_rows writes s < S
+        HIPCHK(hipMemsetAsync(gam_.p, 0, (size_t)N * S_pad_ * sizeof(T), stream_));
+        if ((rc = project_dense(gamma))) return rc;
+        if (kF32 && st) {
+            h_kcountD_.resize(kcountD_.cap / sizeof(int));
+            HIPCHK(hipMemcpyAsync(h_kcountD_.data(), kcountD_.p, kcountD_.cap, hipMemcpyDeviceToHost, stream_));
+        }
+    } else {
+        HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_));
+    }
     HIPCHK(hipEventRecord(ev_[1], stream_));
     // Belief-only work (dead triples, b.ER) goes to the side stream so it runs beside the MFMA-bound
     // score GEMM (it needs memory bandwidth, the GEMM does not) rather than beside the projection.
@@ -552,6 +662,15 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
             for (uint8_t d : hd) nd += d;
             st->n_dead = nd;
         }
+        if (mode_ == PBVI_DENSE) {
+            st->project_flops = 2LL * AO * V_ * (int64_t)S_ * S_;
+            st->project_flops_executed = st->project_flops;
+            if (kF32) {
+                int64_t kt_sum = 0;
+                for (int64_t i = 0; i < dense_pairs_ && i < (int64_t)h_kcountD_.size(); ++i) kt_sum += h_kcountD_[(size_t)i];
+                st->project_flops_executed = kt_sum * 2LL * GEMM_BM * GEMM_BN * GEMM_BK;
+            }
+        }
         st->score_flops = 2 * B_ * (int64_t)S_ * AO * V_;
         if (kF32) {
             int64_t kt_sum = 0;
@@ -601,7 +720,6 @@ int pbvi_engine_create(pbvi_engine_t** out, int device, int32_t S, int32_t A, in
     if (!reach_states || !rto || !exp_reward) FAIL(PBVI_EINVAL, "engine_create: NULL table");
     if (dtype != PBVI_F32 && dtype != PBVI_F64) FAIL(PBVI_EINVAL, "engine_create: dtype must be PBVI_F32 or PBVI_F64");
     if (mode != PBVI_SPARSE && mode != PBVI_DENSE) FAIL(PBVI_EINVAL, "engine_create: unknown mode");
-    if (mode == PBVI_DENSE) FAIL(PBVI_EUNSUPPORTED, "engine_create: dense projection mode is not built yet");
     int ndev = pbvi_device_count();
     if (ndev <= 0) FAIL(PBVI_ERUNTIME, "engine_create: no HIP device visible");
     if (device < 0 || device >= ndev) FAIL(PBVI_EINVAL, "engine_create: device index out of range");

@@ -39,7 +39,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 __global__ __launch_bounds__(512) void k_gemm_nt_f32_mfma(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
     int ldc, int64_t slab_stride, int tiles_m, int tiles_n, int k_tiles, int chunk_len, int max_chunks,
-    const int* __restrict__ klist, const int* __restrict__ kcount) {
+    const int* __restrict__ klist, const int* __restrict__ kcount, int64_t batch_stride_b, int64_t batch_stride_c) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
@@ -59,7 +59,12 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_mfma(
     // K-tile list of this (m-tile, n-tile) pair: only tiles where both operands are non-zero.
     // Chunk z of the pair covers list entries [z*chunk_len, (z+1)*chunk_len); a chunk past the
     // end of the list does not exist (its slab is never read: consumers use the same count).
-    const int pair = tn * tiles_m + tm;
+    // blockIdx.y = batch entry (dense projection: one (action, observation) matrix each); the A
+    // operand is shared, B / C / the tile lists advance per entry.
+    const int batch = blockIdx.y;
+    B += batch * batch_stride_b;
+    C += batch * batch_stride_c;
+    const int pair = (batch * tiles_n + tn) * tiles_m + tm;
     const int cnt = kcount[pair];
     const int kt0 = z * chunk_len;
     const int kt1 = (kt0 + chunk_len < cnt) ? kt0 + chunk_len : cnt;
@@ -194,14 +199,16 @@ __global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* _
                                int* __restrict__ klist, int* __restrict__ kcount, int* __restrict__ nchunks) {
     __shared__ int wcount[4];
     __shared__ int total;
-    const int pair = blockIdx.x;
-    const int tm = pair % tiles_m, tn = pair / tiles_m;
+    const int tiles_n = gridDim.x / tiles_m;
+    const int batch = blockIdx.y;
+    const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+    const int pair = (batch * tiles_n + tn) * tiles_m + tm;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r0 = tn * 256;
     int r1 = r0 + 255;
     if (r1 >= n_rows) r1 = n_rows - 1;
     int g0 = 0, g1 = -1;                                // group range touched by this n-tile
-    if (nzB != nullptr && r0 < n_rows) {
+    if (nzB != nullptr && G > 0 && r0 < n_rows) {
         if (r1 >= G * v_group) {
             g0 = 0;
             g1 = G - 1;
@@ -220,6 +227,8 @@ __global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* _
         } else if (kt < k_tiles && r0 < n_rows && nzA[(int64_t)tm * k_tiles + kt]) {
             if (nzB == nullptr) {
                 f = 1;
+            } else if (G == 0) {                        // per-n-tile flags [batch][tiles_n][k_tiles]
+                f = nzB[((int64_t)batch * tiles_n + tn) * k_tiles + kt];
             } else {
                 for (int g = g0; g <= g1; ++g) f |= nzB[(int64_t)g * k_tiles + kt];
             }
@@ -265,7 +274,8 @@ hipError_t launch_tile_nonzero_f32(const float* X, int ld, int rows_pad, int k_t
 
 hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, const GemmPlan& pl,
                               const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
-                              int* kcount, int* nchunks, hipStream_t stream) {
+                              int* kcount, int* nchunks, hipStream_t stream, int batch, int64_t batch_stride_b,
+                              int64_t batch_stride_c) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nt_f32_mfma,
@@ -275,25 +285,26 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
     }
     const int pairs = pl.tiles_m * pl.tiles_n;
     static const int force_dense = getenv("PBVI_GEMM_DENSE") ? atoi(getenv("PBVI_GEMM_DENSE")) : 0;   // debug / A-B only
-    hipLaunchKernelGGL(k_build_klists, dim3(pairs), dim3(256), 0, stream, nzA, nzB, G, v_group, n_rows, pl.tiles_m,
-                       pl.k_tiles, pl.chunk_len, force_dense, klist, kcount, nchunks);
+    hipLaunchKernelGGL(k_build_klists, dim3(pairs, batch), dim3(256), 0, stream, nzA, nzB, G, v_group, n_rows,
+                       pl.tiles_m, pl.k_tiles, pl.chunk_len, force_dense, klist, kcount, nchunks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int64_t groups = ((int64_t)pl.tiles_n * pl.max_chunks + 7) / 8 * 8;
     const int64_t total = groups * pl.tiles_m;
     if (total <= 0 || total > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_gemm_nt_f32_mfma, dim3((unsigned)total), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B, ldb, C,
-                       pl.ldc, pl.slab_stride, pl.tiles_m, pl.tiles_n, pl.k_tiles, pl.chunk_len, pl.max_chunks, klist,
-                       kcount);
+    if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_gemm_nt_f32_mfma, dim3((unsigned)total, batch), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B,
+                       ldb, C, pl.ldc, pl.slab_stride, pl.tiles_m, pl.tiles_n, pl.k_tiles, pl.chunk_len, pl.max_chunks,
+                       klist, kcount, batch_stride_b, batch_stride_c);
     return hipGetLastError();
 }
 
-GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad) {
+GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad, bool single_chunk) {
     GemmPlan pl;
     pl.tiles_m = M_pad / GEMM_BM;
     pl.tiles_n = N_pad / GEMM_BN;
     pl.k_tiles = K_pad / GEMM_BK;
-    pl.chunk_len = choose_chunk_len(pl.tiles_m * pl.tiles_n, pl.k_tiles);
+    pl.chunk_len = single_chunk ? pl.k_tiles : choose_chunk_len(pl.tiles_m * pl.tiles_n, pl.k_tiles);
     pl.max_chunks = (pl.k_tiles + pl.chunk_len - 1) / pl.chunk_len;
     pl.ldc = N_pad;
     pl.slab_stride = (int64_t)M_pad * N_pad;

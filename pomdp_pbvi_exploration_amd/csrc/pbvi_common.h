@@ -29,11 +29,15 @@ struct GemmPlan {
     int tiles_m, tiles_n, k_tiles, chunk_len, max_chunks, ldc;
     int64_t slab_stride;
 };
-GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad);
+// single_chunk: one K chunk per pair, i.e. slab 0 is the finished product (no split-K).
+GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad, bool single_chunk = false);
 hipError_t launch_tile_nonzero_f32(const float* X, int ld, int rows_pad, int k_tiles, uint8_t* nz, hipStream_t stream);
+// nzB: G > 0 -> per row group [G][k_tiles]; G == 0 -> per n-tile [batch][tiles_n][k_tiles]; nullptr -> dense.
+// batch > 1 runs `batch` GEMMs sharing A (B, C and the tile lists advance by the batch strides).
 hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, const GemmPlan& pl,
                               const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
-                              int* kcount, int* nchunks, hipStream_t stream);
+                              int* kcount, int* nchunks, hipStream_t stream, int batch = 1,
+                              int64_t batch_stride_b = 0, int64_t batch_stride_c = 0);
 // Any-size reference GEMM (used for f64 engines): C[m][n], no padding requirements.
 template <typename T>
 hipError_t launch_gemm_nt_simple(const T* A, int lda, const T* B, int ldb, T* C, int ldc,

@@ -37,7 +37,8 @@ class PbviStats(C.Structure):
                 ('ms_assemble', C.c_double), ('ms_dominance', C.c_double), ('n_pairs', C.c_int64),
                 ('n_dead', C.c_int64), ('n_refined', C.c_int64), ('n_refined_actions', C.c_int64),
                 ('score_flops', C.c_int64), ('score_flops_executed', C.c_int64), ('score_tiles_dense', C.c_int64),
-                ('score_tiles_run', C.c_int64), ('split_k', C.c_int32), ('reserved', C.c_int32)]
+                ('score_tiles_run', C.c_int64), ('project_flops', C.c_int64), ('project_flops_executed', C.c_int64),
+                ('split_k', C.c_int32), ('reserved', C.c_int32)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_ if name != 'reserved'}

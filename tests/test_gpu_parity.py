@@ -55,6 +55,32 @@ def test_small_olfactory_matches_reference(R, dtype):
     eng.close()
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_dense_projection_mode(dtype):
+    """BASELINE config 2 path (K1 as batched MFMA GEMMs over densified T.O matrices) on the small
+    olfactory model and on a random model with repeated successors and multi-tile shapes."""
+    z, rs, rto, er = small(5)
+    eng = Engine(600, 6, 3, 5, rs, rto, er, dtype=dtype, mode='dense')
+    res = eng.backup_full(z['alpha'], z['beliefs'], float(z['gamma']), belief_dominance_prune=True)
+    assert np.array_equal(res.best_alpha_ind, z['core_best']) and np.array_equal(res.actions, z['core_actions'])
+    assert_alpha_close(res.alpha, z['core_alpha'], F32_RTOL if dtype == 'f32' else F64_RTOL)
+    assert res.stats['project_flops'] == 2 * 18 * 48 * 600 * 600
+    eng.close()
+    rng = np.random.default_rng(11)
+    S, A, O, R, V, B = (700, 2, 3, 4, 300, 70) if dtype == 'f32' else (90, 2, 3, 4, 40, 30)
+    rs, rto, er = random_model(rng, S, A, O, R)
+    alpha = rng.normal(scale=3.0, size=(V, S)).astype(np.float32).astype(np.float64)
+    b = rng.random((B, S)) * (rng.random((B, S)) < 0.4)
+    b[:, 1] += 1e-3
+    b = (b / b.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    new, act, best = orc.backup_core(alpha, b, rs, rto, er, 0.95)
+    eng = Engine(S, A, O, R, rs, rto, er, dtype=dtype, mode='dense')
+    res = eng.backup_full(alpha, b, 0.95)
+    assert np.array_equal(res.best_alpha_ind, best) and np.array_equal(res.actions, act)
+    assert_alpha_close(res.alpha, new, F32_RTOL if dtype == 'f32' else F64_RTOL)
+    eng.close()
+
+
 def test_grid4x3_every_reference_call_f64():
     """BASELINE config 1: 4x3 grid, fp64, every backup call of the reference's seeded FSVI run."""
     z = load_npz('grid4x3_fsvi.npz')
