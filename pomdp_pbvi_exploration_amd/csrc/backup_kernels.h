@@ -54,13 +54,15 @@ hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB
 
 // dead[b][ao] = 1 iff supp(b) and supp(RTO[:,a,o,:]) are disjoint (P(o|b,a) == 0 exactly)
 template <typename T>
-hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, uint8_t* dead, hipStream_t st);
+hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const uint8_t* nzB /* [A*O][k_tiles] */,
+                       int k_tiles, uint8_t* dead, hipStream_t st);
 
 // first-max argmax over the V columns [g*V, (g+1)*V) of each (row b, group g) of the score matrix;
 // column G*V + g holds the magnitude score (b . Gamma of the max|alpha| row) that scales the tie
 // window.
 template <typename T>
 hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dead, double tol_rel, double tol_abs,
+                         const int* chain_steps /* device: K-tile steps of the longest f32 chain; used when tol_rel < 0 */,
                          int flag_all, int32_t* best_v, double* best_score, double* err, int32_t* queue, int* qcount,
                          hipStream_t st);
 

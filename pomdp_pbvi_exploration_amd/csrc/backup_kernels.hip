@@ -197,42 +197,55 @@ hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB
 // ------------------------------------------------------------------------- //
 // dead triples: supp(b) disjoint from supp(RTO[:,a,o,:])  <=>  every score is exactly 0
 // ------------------------------------------------------------------------- //
-constexpr int DEAD_CHUNK = 16384;
-
+// Two levels: a belief's non-zero K tiles (32 states) are flagged first; element-level overlap with
+// supp(RTO[:,a,o,:]) is then checked only in tiles where both the belief and the (a,o) support tile map
+// nzB are non-zero -- for the "goal" observation that is one tile instead of |S| states.
 template <typename T>
-__global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, uint8_t* __restrict__ dead) {
+__global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, const uint8_t* __restrict__ nzB,
+                       int k_tiles, uint8_t* __restrict__ dead) {
     extern __shared__ uint8_t dsm[];
-    uint8_t* nz = dsm;                                  // [DEAD_CHUNK]
-    int* hit = (int*)(dsm + DEAD_CHUNK);                // [AO]
+    uint8_t* tz = dsm;                                  // [k_tiles] belief has a non-zero in tile
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int AO = mv.A * mv.O;
-    for (int i = tid; i < AO; i += 256) hit[i] = 0;
     const T* brow = bel + (int64_t)b * ldb;
-    for (int s0 = 0; s0 < mv.S; s0 += DEAD_CHUNK) {
-        const int len = (mv.S - s0) < DEAD_CHUNK ? (mv.S - s0) : DEAD_CHUNK;
-        __syncthreads();
-        for (int i = tid; i < len; i += 256) nz[i] = (brow[s0 + i] != T(0)) ? 1 : 0;
-        __syncthreads();
-        for (int ao = wid; ao < AO; ao += 4) {
-            if (hit[ao]) continue;                      // wave-uniform (own entries only)
-            const uint8_t* sp = mv.sup + (int64_t)ao * mv.S_pad + s0;
-            int found = 0;
-            for (int i = lane; i < len && !found; i += 64) {
-                const int f = nz[i] & sp[i];
-                found = __any(f);
-            }
-            if (found && lane == 0) hit[ao] = 1;
+    // tile flags: 8 lanes x 4 states per tile
+    for (int kt0 = 0; kt0 < k_tiles; kt0 += 32) {
+        const int kt = kt0 + (tid >> 3);
+        int f = 0;
+        if (kt < k_tiles) {
+            const int s = kt * 32 + (tid & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f |= (s + j < mv.S && brow[s + j] != T(0)) ? 1 : 0;
         }
+        f |= __shfl_xor(f, 1, 64);
+        f |= __shfl_xor(f, 2, 64);
+        f |= __shfl_xor(f, 4, 64);
+        if (kt < k_tiles && (tid & 7) == 0) tz[kt] = (uint8_t)f;
     }
     __syncthreads();
-    for (int i = tid; i < AO; i += 256) dead[(int64_t)b * AO + i] = hit[i] ? 0 : 1;
+    for (int ao = wid; ao < AO; ao += 4) {                // one wave per (a,o)
+        const uint8_t* zb = nzB + (int64_t)ao * k_tiles;
+        const uint8_t* sp = mv.sup + (int64_t)ao * mv.S_pad;
+        int found = 0;
+        for (int kt0 = 0; kt0 < k_tiles && !found; kt0 += 64) {
+            const int kt = kt0 + lane;
+            int f = 0;
+            if (kt < k_tiles && tz[kt] && zb[kt]) {      // candidate tile: check its 32 states
+                const int s0 = kt * 32;
+                for (int j = 0; j < 32 && !f; ++j)
+                    f = (s0 + j < mv.S && sp[s0 + j] && brow[s0 + j] != T(0)) ? 1 : 0;
+            }
+            found = __any(f);
+        }
+        if (lane == 0) dead[(int64_t)b * AO + ao] = found ? 0 : 1;
+    }
 }
 
 template <typename T>
-hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, uint8_t* dead, hipStream_t st) {
+hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const uint8_t* nzB, int k_tiles, uint8_t* dead,
+                       hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    const size_t lds = DEAD_CHUNK + (size_t)mv.A * mv.O * sizeof(int);
-    hipLaunchKernelGGL(k_dead<T>, dim3(B), dim3(256), lds, st, bel, ldb, mv, dead);
+    hipLaunchKernelGGL(k_dead<T>, dim3(B), dim3(256), (size_t)k_tiles, st, bel, ldb, mv, nzB, k_tiles, dead);
     return hipGetLastError();
 }
 
@@ -242,7 +255,7 @@ hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, uint8_t* d
 // ------------------------------------------------------------------------- //
 template <typename T>
 __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __restrict__ dead, double tol_rel,
-                         double tol_abs, int flag_all, int32_t* __restrict__ best_v, double* __restrict__ best_score,
+                         double tol_abs, const int* __restrict__ chain_steps, int flag_all, int32_t* __restrict__ best_v, double* __restrict__ best_score,
                          double* __restrict__ err, int32_t* __restrict__ queue, int* __restrict__ qcount) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -287,7 +300,12 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
     int push = 0;
     if (queue != nullptr) {
         const double mag = fmax(fabs((double)m), fabs((double)sv.at(b, (int64_t)G * V + g)));
-        E = tol_rel * mag + tol_abs;
+        // f32 error model: 8 * 2^-24 * sqrt(longest fma chain) (+ slab sums); the chain length is the
+        // stream-K share size, known only on the device
+        double tr = tol_rel;
+        if (chain_steps != nullptr && tol_rel < 0.0)
+            tr = 8.0 * 5.9604644775390625e-08 * (sqrt((double)chain_steps[0] * 32.0) + 1.0);
+        E = tr * mag + tol_abs;
         push = (flag_all || (double)m2 >= (double)m - 2.0 * E) ? 1 : 0;
     }
     if (lane == 0) {
@@ -303,12 +321,12 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
 
 template <typename T>
 hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dead, double tol_rel, double tol_abs,
-                         int flag_all, int32_t* best_v, double* best_score, double* err, int32_t* queue, int* qcount,
-                         hipStream_t st) {
+                         const int* chain_steps, int flag_all, int32_t* best_v, double* best_score, double* err,
+                         int32_t* queue, int* qcount, hipStream_t st) {
     const int64_t rows = (int64_t)B * G;
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_argmax<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sv, V, G, B, dead, tol_rel,
-                       tol_abs, flag_all, best_v, best_score, err, queue, qcount);
+                       tol_abs, chain_steps, flag_all, best_v, best_score, err, queue, qcount);
     return hipGetLastError();
 }
 
@@ -388,29 +406,28 @@ hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entrie
 // K4: action values and first-max action.  src/pomdp.py:1502-1505 via the identity
 //   b . alpha_a[b,a,:] = b . ER[:,a] + sum_o max_v score[b,a,o,v]
 // ------------------------------------------------------------------------- //
-// rdot[b][a] = b . ER[:,a] in f64 (depends on the beliefs only: runs beside the score GEMM)
+// rdot[b][a] = b . ER[:,a] in f64 (depends on the beliefs only: runs beside the score GEMM).
+// Four beliefs per block share every ER load.
 template <typename T>
-__global__ void k_rdot(const T* __restrict__ bel, int ldb, ModelView<T> mv, double* __restrict__ rdot) {
+__global__ void k_rdot(const T* __restrict__ bel, int ldb, int B, ModelView<T> mv, double* __restrict__ rdot) {
     __shared__ double red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const T* brow = bel + (int64_t)b * ldb;
-    for (int a0 = 0; a0 < mv.A; a0 += 4) {
-        const int na = (mv.A - a0) < 4 ? (mv.A - a0) : 4;
+    const int b0 = blockIdx.x * 4, tid = threadIdx.x;
+    const int nb = (B - b0) < 4 ? (B - b0) : 4;
+    const T* br[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) br[j] = bel + (int64_t)(b0 + (j < nb ? j : 0)) * ldb;
+    for (int a = 0; a < mv.A; ++a) {
+        const T* er = mv.er + (int64_t)a * mv.S_pad;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int s = tid; s < mv.S; s += 256) {
-            const double bs = (double)brow[s];
-            if (bs != 0.0) {
+            const double e = (double)er[s];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < na) acc[j] += bs * (double)mv.er[(int64_t)(a0 + j) * mv.S_pad + s];
-            }
+            for (int j = 0; j < 4; ++j) acc[j] += (double)br[j][s] * e;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (j < na) {                                   // block-uniform
-                const double t = block_sum(acc[j], red);
-                if (tid == 0) rdot[(int64_t)b * mv.A + a0 + j] = t;
-            }
+            const double t = block_sum(acc[j], red);
+            if (tid == 0 && j < nb) rdot[(int64_t)(b0 + j) * mv.A + a] = t;
         }
     }
 }
@@ -459,7 +476,7 @@ __global__ void k_action_select(int B, ModelView<T> mv, const double* __restrict
 template <typename T>
 hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, double* rdot, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rdot<T>, dim3(B), dim3(256), 0, st, bel, ldb, mv, rdot);
+    hipLaunchKernelGGL(k_rdot<T>, dim3((B + 3) / 4), dim3(256), 0, st, bel, ldb, B, mv, rdot);
     return hipGetLastError();
 }
 
@@ -634,9 +651,9 @@ hipError_t launch_dominated(const T* alpha, int lda, int V, int S, int* cnt, hip
     template hipError_t launch_project<T>(const T*, int, int, ModelView<T>, T, T*, int, const uint8_t*, int,           \
                                           hipStream_t);                                                                \
     template hipError_t launch_rdot<T>(const T*, int, int, ModelView<T>, double*, hipStream_t);                        \
-    template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, uint8_t*, hipStream_t);                       \
-    template hipError_t launch_argmax<T>(SlabView<T>, int, int, int, const uint8_t*, double, double, int, int32_t*,    \
-                                         double*, double*, int32_t*, int*, hipStream_t);                               \
+    template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const uint8_t*, int, uint8_t*, hipStream_t);  \
+    template hipError_t launch_argmax<T>(SlabView<T>, int, int, int, const uint8_t*, double, double, const int*, int,  \
+                                         int32_t*, double*, double*, int32_t*, int*, hipStream_t);                     \
     template hipError_t launch_refine<T>(bool, SlabView<T>, int, int, int, const int32_t*, const int*, const T*, int,  \
                                          const T*, int, ModelView<T>, double, int32_t*, double*, double*, hipStream_t); \
     template hipError_t launch_action<T>(int, ModelView<T>, const double*, const double*, const double*, int32_t*,     \

@@ -11,6 +11,7 @@
 //   results : out_alpha [B][S], action [B], best_v [B][A][O], keep [B]
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -152,7 +153,7 @@ class EngineT : public EngineBase {
     int64_t B_ = 0, B_pad_ = 0;
     DevBuf gam_, slabs_, best_v_, best_score_, err_, dead_, queue_, counters_, rdot_, action_, aqueue_, out_, keep_;
     DevBuf bv2_, bs2_, err2_, queue2_, prune_cnt_;
-    DevBuf nzB_, nzA_, klist_, kcount_, nchunks_, need_;   // zero-tile bookkeeping of the f32 score GEMM
+    DevBuf nzB_, nzA_, klist_, kcount_, nchunks_, need_, skws_;   // zero-tile bookkeeping of the f32 score GEMM
     DevBuf dense_, nzD_, nzAlpha_, prod_, klistD_, kcountD_, nchunksD_;   // dense projection mode
     int64_t rows_pad_s_ = 0, dense_pairs_ = 0;
     std::vector<int> h_kcountD_;
@@ -167,7 +168,7 @@ class EngineT : public EngineBase {
         (void)hipSetDevice(device_);
         DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
-                         &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_,
+                         &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
@@ -355,9 +356,16 @@ class EngineT : public EngineBase {
         return PBVI_OK;
     }
 
+    // device pointer to the stream-K share size (K-tile steps of the longest f32 chain) or nullptr
+    const int* chain_steps() const {
+        if (!kF32 || !plan_.streamk) return nullptr;
+        const size_t pairs = (size_t)plan_.tiles_m * plan_.tiles_n;
+        return skws_.as<int>() + (pairs + 1) + plan_.nblocks + pairs;
+    }
     double tie_window(int k_chunk) const {
         if (!kF32) return 0.0;
         if (tie_rel_user_ > 0.0) return tie_rel_user_;
+        if (plan_.streamk) return -1.0;            // computed on the device from the stream-K share size
         const double u = 5.9604644775390625e-08;   // 2^-24
         return 8.0 * u * std::sqrt((double)std::max(k_chunk, 1)) + 8.0 * u;
     }
@@ -437,9 +445,10 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
         if ((rc = klist_.ensure(pairs * plan_.k_tiles * sizeof(int), &bytes_))) return rc;
         if ((rc = kcount_.ensure(pairs * sizeof(int), &bytes_))) return rc;
         if ((rc = nchunks_.ensure(pairs * sizeof(int), &bytes_))) return rc;
+        if ((rc = skws_.ensure(streamk_workspace_ints(plan_) * sizeof(int), &bytes_))) return rc;
         HIPCHK(launch_gemm_nt_f32((const float*)bel_.p, S_pad_, (const float*)Y, S_pad_, slabs_.as<float>(), plan_,
                                   nzA_.as<uint8_t>(), nzB, G, v_group, (int)rows_y, klist_.as<int>(), kcount_.as<int>(),
-                                  nchunks_.as<int>(), stream_));
+                                  nchunks_.as<int>(), stream_, 1, 0, 0, skws_.as<int>()));
         sv->slabs = slabs_.as<T>();
         sv->slab_stride = plan_.slab_stride;
         sv->ldc = plan_.ldc;
@@ -517,7 +526,7 @@ int EngineT<T>::value_max_device() {
     const int k_chunk = kF32 ? plan_.chunk_len * GEMM_BK : S_pad_;
     // every belief is re-scored exactly in f32 engines (flag_all): the comparison that
     // follows (new value > old best value) is strict and must not see GEMM rounding
-    HIPCHK(launch_argmax<T>(sv, (int)V_, 1, (int)B_, nullptr, tie_window(k_chunk), 0.0, 1, bv2_.as<int32_t>(),
+    HIPCHK(launch_argmax<T>(sv, (int)V_, 1, (int)B_, nullptr, tie_window(k_chunk), 0.0, chain_steps(), 1, bv2_.as<int32_t>(),
                             bs2_.as<double>(), err2_.as<double>(), kF32 ? queue2_.as<int32_t>() : nullptr, qc, stream_));
     if (kF32)
         HIPCHK(launch_refine<T>(false, sv, (int)V_, 1, (int)B_, queue2_.as<int32_t>(), qc, bel_.as<T>(), S_pad_,
@@ -558,8 +567,17 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)N * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
 
     HIPCHK(hipEventRecord(ev_[0], stream_));
-    // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
+    // Belief-only work (dead triples, b.ER: ~0.1 ms each) on the side stream, beside the projection.
+    // (Beside the persistent stream-K GEMM they starve: k_rdot took 3.1 ms there instead of 0.1.)
+    static const bool no_side = getenv("PBVI_NO_SIDE_STREAM") != nullptr;      // debug / A-B only
+    hipStream_t side = no_side ? stream_ : stream2_;
     const int k_tiles = S_pad_ / GEMM_BK;
+    HIPCHK(hipEventRecord(ev_fork_, stream_));
+    HIPCHK(hipStreamWaitEvent(side, ev_fork_, 0));
+    if (kF32) HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(), side));
+    HIPCHK(launch_rdot<T>(bel_.as<T>(), S_pad_, (int)B_, mv, rdot_.as<double>(), side));
+    HIPCHK(hipEventRecord(ev_join_, side));
+    // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
     const uint8_t* need = nullptr;
     if (kF32) {
         if ((rc = need_.ensure((size_t)AO * k_tiles, &bytes_))) return rc;
@@ -580,13 +598,6 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_));
     }
     HIPCHK(hipEventRecord(ev_[1], stream_));
-    // Belief-only work (dead triples, b.ER) goes to the side stream so it runs beside the MFMA-bound
-    // score GEMM (it needs memory bandwidth, the GEMM does not) rather than beside the projection.
-    HIPCHK(hipEventRecord(ev_fork_, stream_));
-    HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
-    if (kF32) HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, dead_.as<uint8_t>(), stream2_));
-    HIPCHK(launch_rdot<T>(bel_.as<T>(), S_pad_, (int)B_, mv, rdot_.as<double>(), stream2_));
-    HIPCHK(hipEventRecord(ev_join_, stream2_));
     // K2: scores
     SlabView<T> sv;
     if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv))) return rc;
@@ -594,7 +605,8 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));       // dead flags + rdot ready
     const GemmPlan plan = plan_;    // value_max_device (K5) re-plans; keep this GEMM's for the stats
     const int k_chunk = kF32 ? plan.chunk_len * GEMM_BK : S_pad_;
-    HIPCHK(launch_argmax<T>(sv, (int)V_, AO, (int)B_, kF32 ? dead_.as<uint8_t>() : nullptr, tie_window(k_chunk), 0.0, 0,
+    HIPCHK(launch_argmax<T>(sv, (int)V_, AO, (int)B_, kF32 ? dead_.as<uint8_t>() : nullptr, tie_window(k_chunk), 0.0,
+                            chain_steps(), 0,
                             best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(),
                             kF32 ? queue_.as<int32_t>() : nullptr, qcount, stream_));
     HIPCHK(hipEventRecord(ev_[3], stream_));

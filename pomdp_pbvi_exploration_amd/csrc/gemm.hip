@@ -1,24 +1,30 @@
-// Score GEMM for the PBVI backup on gfx950 (CDNA4).
+// Score / projection GEMM for the PBVI backup on gfx950 (CDNA4).
 //
-//   C[z][m][n] = sum_{k in chunk z} A[m][k] * B[n][k]
+//   C[z][m][n] = sum over (a chunk of) the pair's K-tile list of A[m][k] * B[n][k]
 //
 // In the backup A = belief block [B][S], B = Gamma [(a,o,v)][S] (reference:
-// xp.tensordot(belief_array, gamma_a_o_t, (1,3)), src/pomdp.py:1495).  Both operands
-// are K-contiguous, exactly the layouts the reference keeps them in, so no transpose
-// copy is ever made (NumPy's tensordot makes one internally).
+// xp.tensordot(belief_array, gamma_a_o_t, (1,3)), src/pomdp.py:1495).  Both operands are
+// K-contiguous, exactly the layouts the reference keeps them in, so no transpose copy is ever made
+// (NumPy's tensordot makes one internally).
 //
-// f32 kernel: v_mfma_f32_32x32x2_f32 (exact f32 fma chains, 64 FLOP/clk/SIMD = the
-// 157 TFLOP/s fp32 matrix peak).  256x256x32 tiles, 8 waves (2 per SIMD) laid out
-// 2(M) x 4(N), each wave a 128x64 sub-tile = 4x2 MFMA blocks = 128 accumulator VGPRs.
-// Operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double buffer;
-// the 128-byte LDS rows are XOR-swizzled on the SOURCE address so the ds_read_b128
-// fragment reads are bank-conflict free.  K is permuted inside each 8-wide group
-// (lane half h takes k = 8g+4h+j for MFMA step j) so one ds_read_b128 feeds four
-// MFMAs; the permutation is applied to both operands, so the sum is unchanged.
-// Split-K partial slabs keep 256 CUs evenly loaded when the tile count is not a
-// multiple of 256 and shorten the f32 accumulation chains; the consumer reduces the
-// slabs in a fixed order (deterministic).  Workgroup ids are remapped so the M-tiles
-// that share one Gamma tile run on the same XCD (one L2 fill per Gamma tile).
+// Tile engine: v_mfma_f32_32x32x2_f32 (exact f32 fma chains, 64 FLOP/clk/SIMD = the 157 TFLOP/s fp32
+// matrix peak).  256x256x32 tiles, 8 waves (2 per SIMD) laid out 2(M) x 4(N), each wave a 128x64
+// sub-tile = 4x2 MFMA blocks = 128 accumulator VGPRs.  Operands go HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4) into a double buffer; the 128-byte LDS rows are XOR-swizzled on the SOURCE
+// address so the ds_read_b128 fragment reads are bank-conflict free.  K is permuted inside each 8-wide
+// group (lane half h takes k = 8g+4h+j for MFMA step j) so one ds_read_b128 feeds four MFMAs; the
+// permutation is applied to both operands, so the sum is unchanged.
+//
+// Zero-tile skipping (exact): for every (m-tile, n-tile) pair only the K tiles where both operands have
+// a non-zero are listed and multiplied; a skipped tile could only have added +0 products.
+//
+// Two schedulers over the same tile engine:
+//  * k_gemm_nt_f32_mfma   -- one block per (pair, chunk of the list), optionally batched.  Used with a
+//    single chunk per pair for the dense projection (slab 0 is the finished product).
+//  * k_gemm_nt_f32_streamk -- persistent, one block per CU, each owning an equal contiguous share of the
+//    concatenated tile lists (stream-K): per-pair list lengths differ by 1000x under zero-tile skipping,
+//    so equal shares of listed tile-steps is what balances the chip.  A pair split over several blocks
+//    leaves one partial slab per block; the consumer sums them in a fixed order (deterministic).
 #include "pbvi_common.h"
 
 #include <cstdlib>
@@ -36,19 +42,125 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// Per-thread constants of the tile engine.
+struct TileThread {
+    int lane, wid, i, h, wr, wc;
+    int srow[4], scol[4];      // staging: row and (swizzled) first column of this thread's 4 chunks
+    int a_row[4], b_row[2];    // fragment rows
+    __device__ __forceinline__ void init() {
+        const int tid = threadIdx.x;
+        lane = tid & 63;
+        wid = tid >> 6;
+        i = lane & 31;
+        h = lane >> 5;
+        wr = wid >> 2;
+        wc = wid & 3;
+        // 2048 16-byte chunks per operand tile, 4 per thread.  LDS image is lane-linear (chunk c at byte
+        // 16c); physical chunk p of row r holds logical chunk p ^ ((r>>1)&7).
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = it * 512 + tid;
+            const int row = c >> 3, pc = c & 7;
+            srow[it] = row;
+            scol[it] = (pc ^ ((row >> 1) & 7)) * 4;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a_row[mi] = wr * 128 + mi * 32 + i;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b_row[ni] = wc * 64 + ni * 32 + i;
+    }
+};
+
+__device__ __forceinline__ void tile_stage(const TileThread& t, float* lds, int buf, const float* Ablk, int lda,
+                                           const float* Bblk, int ldb, int kt) {
+    float* la = lds + buf * 2 * TILE_FLOATS;
+    float* lb = la + TILE_FLOATS;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int wave_chunk = it * 512 + t.wid * 64;        // wave-uniform LDS base (M0)
+        glds16(Ablk + (int64_t)t.srow[it] * lda + kt * GEMM_BK + t.scol[it], la + wave_chunk * 4);
+        glds16(Bblk + (int64_t)t.srow[it] * ldb + kt * GEMM_BK + t.scol[it], lb + wave_chunk * 4);
+    }
+}
+
+__device__ __forceinline__ void tile_compute(const TileThread& t, const float* lds, int buf, f32x16 (&acc)[4][2]) {
+    const float* la = lds + buf * 2 * TILE_FLOATS;
+    const float* lb = la + TILE_FLOATS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 af[4], bf[2];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int pc = (2 * g + t.h) ^ ((t.a_row[mi] >> 1) & 7);
+            af[mi] = *(const f32x4*)(la + t.a_row[mi] * GEMM_BK + pc * 4);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int pc = (2 * g + t.h) ^ ((t.b_row[ni] >> 1) & 7);
+            bf[ni] = *(const f32x4*)(lb + t.b_row[ni] * GEMM_BK + pc * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+// Multiply list entries [i0, i1) of one pair into acc (double-buffered LDS-DMA pipeline).
+__device__ __forceinline__ void tile_run(const TileThread& t, float* lds, const float* Ablk, int lda, const float* Bblk,
+                                         int ldb, const int* __restrict__ kl, int i0, int i1, f32x16 (&acc)[4][2]) {
+    tile_stage(t, lds, 0, Ablk, lda, Bblk, ldb, kl[i0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int it = i0; it < i1; ++it) {
+        if (it + 1 < i1) tile_stage(t, lds, buf ^ 1, Ablk, lda, Bblk, ldb, kl[it + 1]);
+        tile_compute(t, lds, buf, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+__device__ __forceinline__ void tile_zero(f32x16 (&acc)[4][2]) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+}
+
+// lane holds column (lane&31); register e holds row (e&3) + 8*(e>>2) + 4*(lane>>5)
+__device__ __forceinline__ void tile_store(const TileThread& t, float* Cz, int ldc, int tm, int tn,
+                                           const f32x16 (&acc)[4][2]) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = tn * 256 + t.wc * 64 + ni * 32 + t.i;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = tm * 256 + t.wr * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * t.h;
+                Cz[(int64_t)row * ldc + col] = acc[mi][ni][e];
+            }
+        }
+}
+
+// --------------------------------------------------------------------------- //
+// scheduler 1: one block per (pair, chunk), batched
+// --------------------------------------------------------------------------- //
 __global__ __launch_bounds__(512) void k_gemm_nt_f32_mfma(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
     int ldc, int64_t slab_stride, int tiles_m, int tiles_n, int k_tiles, int chunk_len, int max_chunks,
     const int* __restrict__ klist, const int* __restrict__ kcount, int64_t batch_stride_b, int64_t batch_stride_c) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-
-    // Work-item map.  Blocks b and b+8 share an XCD (round-robin dispatch), and the dispatcher
-    // hands blocks out in id order.  A group = the tiles_m M-tiles of one (n-tile, chunk): they
-    // read the same Gamma tile rows, so a group stays on ONE XCD (one L2 fill), while groups are
-    // dealt round-robin over the 8 XCDs with the chunk index slowest -- every XCD gets the same
-    // share of each chunk level, and the chunks that do not exist (short K lists) sit at the end
-    // of the grid where they exit at once.  Placement affects speed only.
+    // Work-item map.  Blocks b and b+8 share an XCD (round-robin dispatch).  A group = the tiles_m
+    // M-tiles of one (n-tile, chunk): they read the same B tile rows, so a group stays on ONE XCD (one L2
+    // fill), while groups are dealt round-robin over the 8 XCDs with the chunk index slowest.
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int tm = slot % tiles_m;
@@ -56,120 +168,121 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_mfma(
     const int tn = q % tiles_n;
     const int z = q / tiles_n;
     if (z >= max_chunks) return;                        // grid is padded to a multiple of 8 groups
-    // K-tile list of this (m-tile, n-tile) pair: only tiles where both operands are non-zero.
-    // Chunk z of the pair covers list entries [z*chunk_len, (z+1)*chunk_len); a chunk past the
-    // end of the list does not exist (its slab is never read: consumers use the same count).
-    // blockIdx.y = batch entry (dense projection: one (action, observation) matrix each); the A
-    // operand is shared, B / C / the tile lists advance per entry.
     const int batch = blockIdx.y;
     B += batch * batch_stride_b;
     C += batch * batch_stride_c;
     const int pair = (batch * tiles_n + tn) * tiles_m + tm;
     const int cnt = kcount[pair];
-    const int kt0 = z * chunk_len;
-    const int kt1 = (kt0 + chunk_len < cnt) ? kt0 + chunk_len : cnt;
-    if (kt0 >= kt1) return;
-    const int* __restrict__ kl = klist + (int64_t)pair * k_tiles;
-
-    const float* Ablk = A + (int64_t)tm * 256 * lda;
-    const float* Bblk = B + (int64_t)tn * 256 * ldb;
-
-    // staging: 2048 16-byte chunks per operand tile, 4 per thread.  LDS image is
-    // lane-linear (chunk c at byte 16c); physical chunk p of row r holds logical
-    // chunk p ^ ((r>>1)&7).
-    int srow[4], scol[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int c = it * 512 + tid;
-        const int row = c >> 3, pc = c & 7;
-        srow[it] = row;
-        scol[it] = (pc ^ ((row >> 1) & 7)) * 4;
-    }
-    auto stage = [&](int buf, int kt) {
-        float* la = lds + buf * 2 * TILE_FLOATS;
-        float* lb = la + TILE_FLOATS;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int wave_chunk = it * 512 + wid * 64;        // wave-uniform LDS base (M0)
-            glds16(Ablk + (int64_t)srow[it] * lda + kt * GEMM_BK + scol[it], la + wave_chunk * 4);
-            glds16(Bblk + (int64_t)srow[it] * ldb + kt * GEMM_BK + scol[it], lb + wave_chunk * 4);
-        }
-    };
-
-    const int i = lane & 31, h = lane >> 5;
-    const int wr = wid >> 2, wc = wid & 3;
+    const int i0 = z * chunk_len;
+    const int i1 = (i0 + chunk_len < cnt) ? i0 + chunk_len : cnt;
+    if (i0 >= i1) return;                               // this chunk does not exist
+    TileThread t;
+    t.init();
     f32x16 acc[4][2];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
-    // fragment addresses (floats) for g = 0; chunk index is XORed per g below
-    int a_row[4], b_row[2];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) a_row[mi] = wr * 128 + mi * 32 + i;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) b_row[ni] = wc * 64 + ni * 32 + i;
-
-    auto compute = [&](int buf) {
-        const float* la = lds + buf * 2 * TILE_FLOATS;
-        const float* lb = la + TILE_FLOATS;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 af[4], bf[2];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int pc = (2 * g + h) ^ ((a_row[mi] >> 1) & 7);
-                af[mi] = *(const f32x4*)(la + a_row[mi] * GEMM_BK + pc * 4);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int pc = (2 * g + h) ^ ((b_row[ni] >> 1) & 7);
-                bf[ni] = *(const f32x4*)(lb + b_row[ni] * GEMM_BK + pc * 4);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
-        }
-    };
-
-    {
-        stage(0, kl[kt0]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int buf = 0;
-        for (int it = kt0; it < kt1; ++it) {
-            if (it + 1 < kt1) stage(buf ^ 1, kl[it + 1]);
-            compute(buf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            buf ^= 1;
-        }
-    }
-
-    // epilogue: lane holds column (lane&31); register e holds row (e&3) + 8*(e>>2) + 4*(lane>>5)
-    float* Cz = C + (int64_t)z * slab_stride;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = tn * 256 + wc * 64 + ni * 32 + i;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = tm * 256 + wr * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                Cz[(int64_t)row * ldc + col] = acc[mi][ni][e];
-            }
-        }
+    tile_zero(acc);
+    tile_run(t, lds, A + (int64_t)tm * 256 * lda, lda, B + (int64_t)tn * 256 * ldb, ldb,
+             klist + (int64_t)pair * k_tiles, i0, i1, acc);
+    tile_store(t, C + (int64_t)z * slab_stride, ldc, tm, tn, acc);
 }
 
 // --------------------------------------------------------------------------- //
-// Zero-tile bookkeeping (exact: a skipped tile contributes only +0 products)
+// scheduler 2: stream-K, persistent
+// --------------------------------------------------------------------------- //
+// plan[0] = q (tile-steps per block), plan[1] = T (total listed tile-steps)
+__global__ void k_streamk_plan(const int* __restrict__ kcount, int pairs, int nblocks, int k_tiles, int max_split,
+                               int* __restrict__ prefix, int* __restrict__ start_pair, int* __restrict__ first_block,
+                               int* __restrict__ nchunks, int* __restrict__ plan) {
+    __shared__ int part[256];
+    __shared__ int q_sh;
+    const int tid = threadIdx.x;
+    const int per = (pairs + 255) / 256;
+    const int p0 = (tid * per < pairs) ? tid * per : pairs;
+    const int p1 = (p0 + per < pairs) ? p0 + per : pairs;
+    int sum = 0;
+    for (int p = p0; p < p1; ++p) sum += kcount[p];
+    part[tid] = sum;
+    for (int i = tid; i < nblocks; i += 256) start_pair[i] = -1;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        int q = (run + nblocks - 1) / nblocks;
+        const int qmin = (k_tiles + max_split - 1) / max_split;   // a pair spans at most max_split+1 blocks
+        if (q < qmin) q = qmin;
+        if (q < 1) q = 1;
+        q_sh = q;
+        plan[0] = q;
+        plan[1] = run;
+        prefix[pairs] = run;
+    }
+    __syncthreads();
+    const int q = q_sh;
+    int run = part[tid];
+    for (int p = p0; p < p1; ++p) {
+        const int cnt = kcount[p];
+        prefix[p] = run;
+        if (cnt > 0) {
+            const int fb = run / q, lb = (run + cnt - 1) / q;
+            first_block[p] = fb;
+            nchunks[p] = lb - fb + 1;
+            for (int i = fb; i <= lb; ++i)
+                if ((int64_t)i * q >= run) start_pair[i] = p;          // block i's share begins inside pair p
+        } else {
+            first_block[p] = 0;
+            nchunks[p] = 0;
+        }
+        run += cnt;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+    int64_t slab_stride, int tiles_m, int pairs, int k_tiles, const int* __restrict__ klist,
+    const int* __restrict__ kcount, const int* __restrict__ prefix, const int* __restrict__ start_pair,
+    const int* __restrict__ first_block, const int* __restrict__ plan) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // XCD-contiguous logical ids: consecutive shares (which walk the same n-tile's pairs) on one XCD.
+    const int nb = gridDim.x;
+    int L;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, qq = nb >> 3, r = nb & 7;
+        const int base = (xcd < r) ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq;
+        L = base + (bid >> 3);
+    }
+    const int q = plan[0], T = plan[1];
+    int64_t pos = (int64_t)L * q;
+    if (pos >= T) return;
+    const int64_t end = (pos + q < T) ? pos + q : T;
+    int p = start_pair[L];
+    if (p < 0) return;                                   // cannot happen when pos < T; defensive
+    TileThread t;
+    t.init();
+    while (pos < end && p < pairs) {
+        const int cnt = kcount[p];
+        if (cnt == 0) {                                  // block-uniform
+            ++p;
+            continue;
+        }
+        const int lo = (int)(pos - prefix[p]);
+        const int64_t room = end - pos;
+        const int hi = (lo + room < cnt) ? (int)(lo + room) : cnt;
+        const int tm = p % tiles_m, tn = p / tiles_m;
+        f32x16 acc[4][2];
+        tile_zero(acc);
+        tile_run(t, lds, A + (int64_t)tm * 256 * lda, lda, B + (int64_t)tn * 256 * ldb, ldb,
+                 klist + (int64_t)p * k_tiles, lo, hi, acc);
+        tile_store(t, C + (int64_t)(L - first_block[p]) * slab_stride, ldc, tm, tn, acc);
+        pos += hi - lo;
+        ++p;
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// Zero-tile bookkeeping
 // --------------------------------------------------------------------------- //
 // nz[tile][kt] = 1 iff the 256-row x 32-column block of X has a non-zero entry.
 __global__ void k_tile_nonzero(const float* __restrict__ X, int ld, int k_tiles, uint8_t* __restrict__ nz) {
@@ -190,10 +303,10 @@ __global__ void k_tile_nonzero(const float* __restrict__ X, int ld, int k_tiles,
     }
 }
 
-// One block per (m-tile, n-tile) pair: compact the K tiles where both operands are non-zero.
-// The B operand's zero structure is per row group: rows [g*v_group, (g+1)*v_group) share the
-// support nzB[g][kt] (Gamma rows of one (action, observation)); rows >= G*v_group (the magnitude
-// rows) may touch any group.  nzB == nullptr means a dense B operand.
+// One block per (m-tile, n-tile[, batch]) pair: compact the K tiles where both operands are non-zero.
+// B's zero structure: G > 0 -> per row group, rows [g*v_group, (g+1)*v_group) share nzB[g][kt] (Gamma rows of
+// one (action, observation)) and rows >= G*v_group (the magnitude rows) may touch any group; G == 0 -> per
+// n-tile flags nzB[batch][tn][kt]; nzB == nullptr -> dense.
 __global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* __restrict__ nzB, int G,
                                int v_group, int n_rows, int tiles_m, int k_tiles, int chunk_len, int force_dense,
                                int* __restrict__ klist, int* __restrict__ kcount, int* __restrict__ nchunks) {
@@ -227,7 +340,7 @@ __global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* _
         } else if (kt < k_tiles && r0 < n_rows && nzA[(int64_t)tm * k_tiles + kt]) {
             if (nzB == nullptr) {
                 f = 1;
-            } else if (G == 0) {                        // per-n-tile flags [batch][tiles_n][k_tiles]
+            } else if (G == 0) {
                 f = nzB[((int64_t)batch * tiles_n + tn) * k_tiles + kt];
             } else {
                 for (int g = g0; g <= g1; ++g) f |= nzB[(int64_t)g * k_tiles + kt];
@@ -245,15 +358,11 @@ __global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* _
     }
     if (tid == 0) {
         kcount[pair] = total;
-        nchunks[pair] = (total + chunk_len - 1) / chunk_len;
+        nchunks[pair] = (total + chunk_len - 1) / chunk_len;    // stream-K overwrites this in k_streamk_plan
     }
 }
 
 int choose_chunk_len(int tiles_mn, int k_tiles) {
-    // Work items are (pair, chunk of <= chunk_len listed K tiles).  Aim at ~8 items per CU when
-    // every tile is non-zero; sparse inputs only make items fewer / shorter.  Longer chunks mean
-    // fewer partial slabs for the argmax to reduce (measured at C4: 96 -> 5.41 ms/step, 32 -> 5.86).
-    // Override with PBVI_GEMM_CHUNK for tuning.
     if (const char* env = getenv("PBVI_GEMM_CHUNK")) {
         const int v = atoi(env);
         if (v > 0) return v < k_tiles ? v : k_tiles;
@@ -266,33 +375,68 @@ int choose_chunk_len(int tiles_mn, int k_tiles) {
     return (int)len;
 }
 
+static int device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 hipError_t launch_tile_nonzero_f32(const float* X, int ld, int rows_pad, int k_tiles, uint8_t* nz, hipStream_t stream) {
     dim3 grid((k_tiles + 7) / 8, rows_pad / 256);
     hipLaunchKernelGGL(k_tile_nonzero, grid, dim3(256), 0, stream, X, ld, k_tiles, nz);
     return hipGetLastError();
 }
 
+static hipError_t set_lds_attr() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nt_f32_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_gemm_nt_f32_streamk, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    done = true;
+    return hipSuccess;
+}
+
 hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, const GemmPlan& pl,
                               const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
                               int* kcount, int* nchunks, hipStream_t stream, int batch, int64_t batch_stride_b,
-                              int64_t batch_stride_c) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nt_f32_mfma,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+                              int64_t batch_stride_c, int* streamk_ws) {
+    hipError_t e = set_lds_attr();
+    if (e != hipSuccess) return e;
+    if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
     const int pairs = pl.tiles_m * pl.tiles_n;
     static const int force_dense = getenv("PBVI_GEMM_DENSE") ? atoi(getenv("PBVI_GEMM_DENSE")) : 0;   // debug / A-B only
     hipLaunchKernelGGL(k_build_klists, dim3(pairs, batch), dim3(256), 0, stream, nzA, nzB, G, v_group, n_rows,
                        pl.tiles_m, pl.k_tiles, pl.chunk_len, force_dense, klist, kcount, nchunks);
-    hipError_t e = hipGetLastError();
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (pl.streamk) {
+        if (batch != 1 || streamk_ws == nullptr) return hipErrorInvalidValue;
+        int* prefix = streamk_ws;                        // [pairs+1]
+        int* start_pair = prefix + pairs + 1;            // [nblocks]
+        int* first_block = start_pair + pl.nblocks;      // [pairs]
+        int* plan = first_block + pairs;                 // [2]
+        hipLaunchKernelGGL(k_streamk_plan, dim3(1), dim3(256), 0, stream, kcount, pairs, pl.nblocks, pl.k_tiles,
+                           pl.max_chunks - 1, prefix, start_pair, first_block, nchunks, plan);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gemm_nt_f32_streamk, dim3(pl.nblocks), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B, ldb, C,
+                           pl.ldc, pl.slab_stride, pl.tiles_m, pairs, pl.k_tiles, klist, kcount, prefix, start_pair,
+                           first_block, plan);
+        return hipGetLastError();
+    }
     const int64_t groups = ((int64_t)pl.tiles_n * pl.max_chunks + 7) / 8 * 8;
     const int64_t total = groups * pl.tiles_m;
     if (total <= 0 || total > 0x7fffffff) return hipErrorInvalidValue;
-    if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_gemm_nt_f32_mfma, dim3((unsigned)total, batch), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B,
                        ldb, C, pl.ldc, pl.slab_stride, pl.tiles_m, pl.tiles_n, pl.k_tiles, pl.chunk_len, pl.max_chunks,
                        klist, kcount, batch_stride_b, batch_stride_c);
@@ -304,11 +448,29 @@ GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad, bool single_chunk) {
     pl.tiles_m = M_pad / GEMM_BM;
     pl.tiles_n = N_pad / GEMM_BN;
     pl.k_tiles = K_pad / GEMM_BK;
-    pl.chunk_len = single_chunk ? pl.k_tiles : choose_chunk_len(pl.tiles_m * pl.tiles_n, pl.k_tiles);
-    pl.max_chunks = (pl.k_tiles + pl.chunk_len - 1) / pl.chunk_len;
     pl.ldc = N_pad;
     pl.slab_stride = (int64_t)M_pad * N_pad;
+    static const int no_streamk = getenv("PBVI_GEMM_NO_STREAMK") ? atoi(getenv("PBVI_GEMM_NO_STREAMK")) : 0;
+    pl.streamk = !single_chunk && !no_streamk;
+    pl.nblocks = device_cu_count();
+    if (single_chunk) {
+        pl.chunk_len = pl.k_tiles;
+        pl.max_chunks = 1;
+    } else if (pl.streamk) {
+        // a pair's list (<= k_tiles steps) is split over at most max_split+1 consecutive blocks
+        const int max_split = 8;
+        pl.chunk_len = pl.k_tiles;          // only used for the (overwritten) provisional nchunks
+        pl.max_chunks = max_split + 1;
+    } else {
+        pl.chunk_len = choose_chunk_len(pl.tiles_m * pl.tiles_n, pl.k_tiles);
+        pl.max_chunks = (pl.k_tiles + pl.chunk_len - 1) / pl.chunk_len;
+    }
     return pl;
+}
+
+size_t streamk_workspace_ints(const GemmPlan& pl) {
+    const size_t pairs = (size_t)pl.tiles_m * pl.tiles_n;
+    return (pairs + 1) + (size_t)pl.nblocks + pairs + 2;
 }
 
 // --------------------------------------------------------------------------- //

@@ -28,7 +28,10 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 struct GemmPlan {
     int tiles_m, tiles_n, k_tiles, chunk_len, max_chunks, ldc;
     int64_t slab_stride;
+    bool streamk;      // persistent stream-K scheduler (score GEMMs); else one block per (pair, chunk)
+    int nblocks;       // stream-K grid = CUs of the device
 };
+size_t streamk_workspace_ints(const GemmPlan& pl);   // ints of device workspace the stream-K plan needs
 // single_chunk: one K chunk per pair, i.e. slab 0 is the finished product (no split-K).
 GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad, bool single_chunk = false);
 hipError_t launch_tile_nonzero_f32(const float* X, int ld, int rows_pad, int k_tiles, uint8_t* nz, hipStream_t stream);
@@ -37,7 +40,8 @@ hipError_t launch_tile_nonzero_f32(const float* X, int ld, int rows_pad, int k_t
 hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, const GemmPlan& pl,
                               const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
                               int* kcount, int* nchunks, hipStream_t stream, int batch = 1,
-                              int64_t batch_stride_b = 0, int64_t batch_stride_c = 0);
+                              int64_t batch_stride_b = 0, int64_t batch_stride_c = 0, int* streamk_ws = nullptr);
+// streamk_ws layout: prefix[pairs+1], start_pair[nblocks], first_block[pairs], plan[2] = {steps per block, total steps}
 // Any-size reference GEMM (used for f64 engines): C[m][n], no padding requirements.
 template <typename T>
 hipError_t launch_gemm_nt_simple(const T* A, int lda, const T* B, int ldb, T* C, int ldc,
