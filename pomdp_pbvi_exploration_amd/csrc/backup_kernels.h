@@ -73,16 +73,17 @@ hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entrie
                          double gamma, int32_t* best_v, double* best_score, double* err, hipStream_t st);
 
 // K4: val[b][a] = b.ER[:,a] + sum_o best_score[b][a][o]; action = first max; near-ties queued
+// Gamma tail rows [A*O*V + A*O, +2A): ER[:,a] and |ER[:,a]|, so the score GEMM also yields b.ER[:,a]
 template <typename T>
-hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, double* rdot, hipStream_t st);
+hipError_t launch_tail_rows(ModelView<T> mv, T* gam_tail, int ldg, hipStream_t st);
 template <typename T>
-hipError_t launch_action(int B, ModelView<T> mv, const double* rdot, const double* best_score, const double* err,
-                         int32_t* action, int32_t* aqueue, int* aqcount, hipStream_t st);
+hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, const int* chain_steps,
+                         const double* best_score, const double* err, double* rdot, double* rdot_err, int32_t* action,
+                         int32_t* aqueue, int* aqcount, hipStream_t st);
 template <typename T>
-hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv,
-                                double gamma, const int32_t* aqueue, const int* aqcount, const double* rdot,
-                                const int32_t* best_v, double* best_score, double* err, int32_t* action,
-                                hipStream_t st);
+hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv, double gamma,
+                                const int32_t* aqueue, const int* aqcount, const double* rdot, const double* rdot_err,
+                                const int32_t* best_v, double* best_score, double* err, int32_t* action, hipStream_t st);
 
 // K3: out[b][s] = ER[s,a*] + sum_o gamma * sum_r rto[a*][o][r][s] * alpha[v*[b,a*,o]][rs[a*][r][s]]
 template <typename T>

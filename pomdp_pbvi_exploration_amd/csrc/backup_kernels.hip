@@ -114,14 +114,18 @@ template <typename T>
 __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView<T> mv, T gamma,
                           T* __restrict__ gam, int ldg, const uint8_t* __restrict__ need, int k_tiles) {
 #pragma clang fp contract(off)   // einsum then scale: sum_r (rto*alpha), one rounding per op, as the reference
-    const int s = blockIdx.x * 256 + threadIdx.x;
+    // 4 consecutive states per thread (16-byte table loads and Gamma stores; S_pad is a multiple of 32),
+    // 4 alpha-vectors x up to 4 observations per pass.
+    const int s = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (s >= mv.S_pad) return;
     const int v0 = blockIdx.y * 4;
     const int a = blockIdx.z;
     const int nv = (V - v0) < 4 ? (V - v0) : 4;
-    const int kt = s >> 5;                                  // GEMM K tile of this state (32 states per tile)
+    const int kt = s >> 5;                                  // GEMM K tile of these states (32 states per tile)
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    typedef int I4 __attribute__((ext_vector_type(4)));
     for (int o0 = 0; o0 < mv.O; o0 += 4) {
-        int no = (mv.O - o0) < 4 ? (mv.O - o0) : 4;
+        const int no = (mv.O - o0) < 4 ? (mv.O - o0) : 4;
         // Gamma tiles the score GEMM never reads (no RTO support, or no belief mass in any row
         // block) are not computed or written: `need` is exactly the GEMM's tile-list criterion.
         bool want[4] = {true, true, true, true};
@@ -134,21 +138,23 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
             }
             if (!any) continue;
         }
-        T acc[4][4];
+        T4 acc[4][4];
 #pragma unroll
         for (int vj = 0; vj < 4; ++vj)
 #pragma unroll
-            for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = T(0);
+            for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = T4{T(0), T(0), T(0), T(0)};
         for (int r = 0; r < mv.R; ++r) {
-            const int idx = mv.rs[((int64_t)a * mv.R + r) * mv.S_pad + s];
-            T w[4];
+            const I4 idx = *(const I4*)(mv.rs + ((int64_t)a * mv.R + r) * mv.S_pad + s);
+            T4 w[4];
 #pragma unroll
             for (int oj = 0; oj < 4; ++oj)
-                w[oj] = (oj < no) ? mv.rto[(((int64_t)a * mv.O + o0 + oj) * mv.R + r) * mv.S_pad + s] : T(0);
+                w[oj] = (oj < no && want[oj]) ? *(const T4*)(mv.rto + (((int64_t)a * mv.O + o0 + oj) * mv.R + r) * mv.S_pad + s)
+                                               : T4{T(0), T(0), T(0), T(0)};
 #pragma unroll
             for (int vj = 0; vj < 4; ++vj) {
                 if (vj < nv) {
-                    const T av = alpha[(int64_t)(v0 + vj) * lda + idx];
+                    const T* arow = alpha + (int64_t)(v0 + vj) * lda;
+                    const T4 av = T4{arow[idx[0]], arow[idx[1]], arow[idx[2]], arow[idx[3]]};
 #pragma unroll
                     for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = acc[vj][oj] + w[oj] * av;
                 }
@@ -163,7 +169,7 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
                     const int v = v0 + vj;
                     // alpha rows -> group-major rows; the magnitude row (v == V-1 of the Vt rows) -> tail
                     const int64_t row = (v < V - 1) ? ao * (V - 1) + v : (int64_t)mv.A * mv.O * (V - 1) + ao;
-                    gam[row * ldg + s] = gamma * acc[vj][oj];
+                    *(T4*)(gam + row * ldg + s) = gamma * acc[vj][oj];
                 }
     }
 }
@@ -172,7 +178,7 @@ template <typename T>
 hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg,
                           const uint8_t* need, int k_tiles, hipStream_t st) {
     if (V <= 0) return hipSuccess;
-    dim3 grid((mv.S_pad + 255) / 256, (V + 3) / 4, mv.A);
+    dim3 grid((mv.S_pad / 4 + 255) / 256, (V + 3) / 4, mv.A);
     if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_project<T>, grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles);
     return hipGetLastError();
@@ -406,43 +412,43 @@ hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entrie
 // K4: action values and first-max action.  src/pomdp.py:1502-1505 via the identity
 //   b . alpha_a[b,a,:] = b . ER[:,a] + sum_o max_v score[b,a,o,v]
 // ------------------------------------------------------------------------- //
-// rdot[b][a] = b . ER[:,a] in f64 (depends on the beliefs only: runs beside the score GEMM).
-// Four beliefs per block share every ER load.
+// Tail rows of Gamma that let the score GEMM produce the reward term of the action values:
+//   row j <  A : ER[:, j]         -> score column = b . ER[:,a]      (rdot)
+//   row j >= A : |ER[:, j-A]|     -> score column = b . |ER[:,a]|    (scales rdot's f32 error bound)
 template <typename T>
-__global__ void k_rdot(const T* __restrict__ bel, int ldb, int B, ModelView<T> mv, double* __restrict__ rdot) {
-    __shared__ double red[4];
-    const int b0 = blockIdx.x * 4, tid = threadIdx.x;
-    const int nb = (B - b0) < 4 ? (B - b0) : 4;
-    const T* br[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) br[j] = bel + (int64_t)(b0 + (j < nb ? j : 0)) * ldb;
-    for (int a = 0; a < mv.A; ++a) {
-        const T* er = mv.er + (int64_t)a * mv.S_pad;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int s = tid; s < mv.S; s += 256) {
-            const double e = (double)er[s];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += (double)br[j][s] * e;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double t = block_sum(acc[j], red);
-            if (tid == 0 && j < nb) rdot[(int64_t)(b0 + j) * mv.A + a] = t;
-        }
-    }
+__global__ void k_tail_rows(ModelView<T> mv, T* __restrict__ gam_tail, int ldg) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (s >= mv.S_pad) return;
+    const T e = mv.er[(int64_t)(j % mv.A) * mv.S_pad + s];
+    gam_tail[(int64_t)j * ldg + s] = (j < mv.A) ? e : (e < T(0) ? -e : e);
 }
 
-// one thread per belief: val[a] = rdot[b][a] + sum_o best_score[b][a][o]; first max; near-ties queued
 template <typename T>
-__global__ void k_action_select(int B, ModelView<T> mv, const double* __restrict__ rdot,
-                                const double* __restrict__ best_score, const double* __restrict__ err,
+hipError_t launch_tail_rows(ModelView<T> mv, T* gam_tail, int ldg, hipStream_t st) {
+    hipLaunchKernelGGL(k_tail_rows<T>, dim3((mv.S_pad + 255) / 256, 2 * mv.A), dim3(256), 0, st, mv, gam_tail, ldg);
+    return hipGetLastError();
+}
+
+// K4, one thread per belief: val[a] = b.ER[:,a] + sum_o best_score[b][a][o]; first max; near-ties queued.
+// rdot comes from the score matrix (column rd_col0 + a, f32 engines: with error bound tol * b.|ER_a|).
+template <typename T>
+__global__ void k_action_select(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel,
+                                const int* __restrict__ chain_steps, const double* __restrict__ best_score,
+                                const double* __restrict__ err, double* __restrict__ rdot, double* __restrict__ rdot_err,
                                 int32_t* __restrict__ action, int32_t* __restrict__ aqueue, int* __restrict__ aqcount) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
+    double tr = tol_rel;
+    if (chain_steps != nullptr && tol_rel < 0.0) tr = 8.0 * 5.9604644775390625e-08 * (sqrt((double)chain_steps[0] * 32.0) + 1.0);
     int best = 0;
     double bv = -std::numeric_limits<double>::infinity(), lo = bv;
     for (int a = 0; a < mv.A; ++a) {
-        double v = rdot[(int64_t)b * mv.A + a], E = 0.0;
+        const double rd = (double)sv.at(b, rd_col0 + a);
+        double E = (aqueue != nullptr) ? tr * fmax(fabs(rd), fabs((double)sv.at(b, rd_col0 + mv.A + a))) : 0.0;
+        rdot[(int64_t)b * mv.A + a] = rd;
+        rdot_err[(int64_t)b * mv.A + a] = E;
+        double v = rd;
         for (int o = 0; o < mv.O; ++o) {
             const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
             v += best_score[e];
@@ -458,7 +464,7 @@ __global__ void k_action_select(int B, ModelView<T> mv, const double* __restrict
     if (aqueue != nullptr) {
         int ncand = 0, anyerr = 0;
         for (int a = 0; a < mv.A; ++a) {
-            double v = rdot[(int64_t)b * mv.A + a], E = 0.0;
+            double v = rdot[(int64_t)b * mv.A + a], E = rdot_err[(int64_t)b * mv.A + a];
             for (int o = 0; o < mv.O; ++o) {
                 const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
                 v += best_score[e];
@@ -474,18 +480,12 @@ __global__ void k_action_select(int B, ModelView<T> mv, const double* __restrict
 }
 
 template <typename T>
-hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, double* rdot, hipStream_t st) {
+hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, const int* chain_steps,
+                         const double* best_score, const double* err, double* rdot, double* rdot_err, int32_t* action,
+                         int32_t* aqueue, int* aqcount, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rdot<T>, dim3((B + 3) / 4), dim3(256), 0, st, bel, ldb, B, mv, rdot);
-    return hipGetLastError();
-}
-
-template <typename T>
-hipError_t launch_action(int B, ModelView<T> mv, const double* rdot, const double* best_score, const double* err,
-                         int32_t* action, int32_t* aqueue, int* aqcount, hipStream_t st) {
-    if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_action_select<T>, dim3((B + 255) / 256), dim3(256), 0, st, B, mv, rdot, best_score, err, action,
-                       aqueue, aqcount);
+    hipLaunchKernelGGL(k_action_select<T>, dim3((B + 255) / 256), dim3(256), 0, st, B, mv, sv, rd_col0, tol_rel,
+                       chain_steps, best_score, err, rdot, rdot_err, action, aqueue, aqcount);
     return hipGetLastError();
 }
 
@@ -493,8 +493,8 @@ template <typename T>
 __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
                                 ModelView<T> mv, double gamma, const int32_t* __restrict__ aqueue,
                                 const int* __restrict__ aqcount, const double* __restrict__ rdot,
-                                const int32_t* __restrict__ best_v, double* __restrict__ best_score,
-                                double* __restrict__ err, int32_t* __restrict__ action) {
+                                const double* __restrict__ rdot_err, const int32_t* __restrict__ best_v,
+                                double* __restrict__ best_score, double* __restrict__ err, int32_t* __restrict__ action) {
     extern __shared__ double asm_[];
     double* val = asm_;
     double* Eb = asm_ + mv.A;
@@ -506,7 +506,7 @@ __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __r
     if (tid == 0) {
         double lo = -std::numeric_limits<double>::infinity();
         for (int a = 0; a < mv.A; ++a) {
-            double v = rdot[(int64_t)b * mv.A + a], E = 0.0;
+            double v = rdot[(int64_t)b * mv.A + a], E = rdot_err[(int64_t)b * mv.A + a];
             for (int o = 0; o < mv.O; ++o) {
                 const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
                 v += best_score[e];
@@ -524,7 +524,8 @@ __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __r
     int best = 0;
     for (int a = 0; a < mv.A; ++a) {
         if (!(val[a] + Eb[a] >= lo)) continue;                 // block-uniform
-        double v = rdot[(int64_t)b * mv.A + a];
+        // exact (f64) value of this candidate action: b.ER[:,a] + sum_o b.Gamma[a,o,v*[b,a,o],:]
+        double v = block_sum(plain_dot_partial(brow, mv.er + (int64_t)a * mv.S_pad, mv.S), red);
         for (int o = 0; o < mv.O; ++o) {
             const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
             double sc = best_score[e];
@@ -549,11 +550,11 @@ __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __r
 
 template <typename T>
 hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv, double gamma,
-                                const int32_t* aqueue, const int* aqcount, const double* rdot, const int32_t* best_v,
-                                double* best_score, double* err, int32_t* action, hipStream_t st) {
+                                const int32_t* aqueue, const int* aqcount, const double* rdot, const double* rdot_err,
+                                const int32_t* best_v, double* best_score, double* err, int32_t* action, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_refine_action<T>, dim3(B), dim3(256), 2 * mv.A * sizeof(double), st, bel, ldb, alpha, lda, mv,
-                       gamma, aqueue, aqcount, rdot, best_v, best_score, err, action);
+                       gamma, aqueue, aqcount, rdot, rdot_err, best_v, best_score, err, action);
     return hipGetLastError();
 }
 
@@ -650,17 +651,17 @@ hipError_t launch_dominated(const T* alpha, int lda, int V, int S, int* cnt, hip
     template hipError_t launch_support<T>(ModelView<T>, uint8_t*, hipStream_t);                                        \
     template hipError_t launch_project<T>(const T*, int, int, ModelView<T>, T, T*, int, const uint8_t*, int,           \
                                           hipStream_t);                                                                \
-    template hipError_t launch_rdot<T>(const T*, int, int, ModelView<T>, double*, hipStream_t);                        \
+    template hipError_t launch_tail_rows<T>(ModelView<T>, T*, int, hipStream_t);                                       \
     template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const uint8_t*, int, uint8_t*, hipStream_t);  \
     template hipError_t launch_argmax<T>(SlabView<T>, int, int, int, const uint8_t*, double, double, const int*, int,  \
                                          int32_t*, double*, double*, int32_t*, int*, hipStream_t);                     \
     template hipError_t launch_refine<T>(bool, SlabView<T>, int, int, int, const int32_t*, const int*, const T*, int,  \
                                          const T*, int, ModelView<T>, double, int32_t*, double*, double*, hipStream_t); \
-    template hipError_t launch_action<T>(int, ModelView<T>, const double*, const double*, const double*, int32_t*,     \
-                                         int32_t*, int*, hipStream_t);                                                 \
+    template hipError_t launch_action<T>(int, ModelView<T>, SlabView<T>, int64_t, double, const int*, const double*,   \
+                                         const double*, double*, double*, int32_t*, int32_t*, int*, hipStream_t);      \
     template hipError_t launch_refine_action<T>(const T*, int, int, const T*, int, ModelView<T>, double,               \
-                                                const int32_t*, const int*, const double*, const int32_t*, double*,    \
-                                                double*, int32_t*, hipStream_t);                                       \
+                                                const int32_t*, const int*, const double*, const double*,              \
+                                                const int32_t*, double*, double*, int32_t*, hipStream_t);              \
     template hipError_t launch_assemble<T>(const T*, int, ModelView<T>, double, const int32_t*, const int32_t*, int,   \
                                            T*, int, hipStream_t);                                                      \
     template hipError_t launch_keep<T>(const T*, int, const T*, int, int, int, const double*, uint8_t*, hipStream_t);  \

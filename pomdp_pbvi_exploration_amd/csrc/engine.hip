@@ -242,11 +242,15 @@ class EngineT : public EngineBase {
         if ((rc = counters_.ensure(4 * sizeof(int), &bytes_))) return rc;
         {   // nzB[(a,o)][kt] = 1 iff RTO[:,a,o,:] has support inside K tile kt (32 states)
             const int k_tiles = S_pad_ / GEMM_BK;
-            std::vector<uint8_t> h_nz((size_t)A * O * k_tiles, 0);
+            // ... plus one extra row [A*O] for the support of ER (the reward rows in Gamma's tail tile)
+            std::vector<uint8_t> h_nz((size_t)(A * O + 1) * k_tiles, 0);
             for (int ao = 0; ao < A * O; ++ao)
                 for (int r = 0; r < R; ++r)
                     for (int s = 0; s < S; ++s)
                         if (h_rto[((size_t)ao * R + r) * S_pad_ + s] != T(0)) h_nz[(size_t)ao * k_tiles + s / GEMM_BK] = 1;
+            for (int a = 0; a < A; ++a)
+                for (int s = 0; s < S; ++s)
+                    if (h_er[(size_t)a * S_pad_ + s] != T(0)) h_nz[(size_t)A * O * k_tiles + s / GEMM_BK] = 1;
             if ((rc = nzB_.ensure(h_nz.size(), &bytes_))) return rc;
             HIPCHK(hipMemcpyAsync(nzB_.p, h_nz.data(), h_nz.size(), hipMemcpyHostToDevice, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
@@ -543,7 +547,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     int rc;
     const int AO = A_ * O_;
     const int64_t Vt = V_ + 1;                 // alpha rows + magnitude row
-    const int64_t N = (int64_t)AO * Vt;        // Gamma rows
+    const int64_t N = (int64_t)AO * Vt + 2 * A_;   // Gamma rows: alpha groups, A*O magnitude rows, A reward + A |reward| rows
     const int64_t pairs = B_ * AO;
     if (N > 0x7fffffff || pairs > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "backup_run: A*O*(V+1) or B*A*O exceeds int32");
     const ModelView<T> mv = view();
@@ -555,7 +559,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     if ((rc = err_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
     if ((rc = queue_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc;
     if ((rc = dead_.ensure((size_t)pairs, &bytes_))) return rc;
-    if ((rc = rdot_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
+    if ((rc = rdot_.ensure((size_t)B_ * A_ * 2 * sizeof(double), &bytes_))) return rc;
     if ((rc = action_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
     if ((rc = aqueue_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
     if ((rc = out_.ensure((size_t)B_ * S_ * sizeof(T), &bytes_))) return rc;
@@ -575,7 +579,6 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     HIPCHK(hipEventRecord(ev_fork_, stream_));
     HIPCHK(hipStreamWaitEvent(side, ev_fork_, 0));
     if (kF32) HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(), side));
-    HIPCHK(launch_rdot<T>(bel_.as<T>(), S_pad_, (int)B_, mv, rdot_.as<double>(), side));
     HIPCHK(hipEventRecord(ev_join_, side));
     // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
     const uint8_t* need = nullptr;
@@ -597,6 +600,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     } else {
         HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_));
     }
+    HIPCHK(launch_tail_rows<T>(mv, gam_.as<T>() + (size_t)(AO * Vt) * S_pad_, S_pad_, stream_));
     HIPCHK(hipEventRecord(ev_[1], stream_));
     // K2: scores
     SlabView<T> sv;
@@ -621,11 +625,13 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
                                 err_.as<double>(), stream_));
     HIPCHK(hipEventRecord(ev_[4], stream_));
     // K4: action
-    HIPCHK(launch_action<T>((int)B_, mv, rdot_.as<double>(), best_score_.as<double>(), err_.as<double>(),
-                            action_.as<int32_t>(), kF32 ? aqueue_.as<int32_t>() : nullptr, aqcount, stream_));
+    double* rdot_err = rdot_.as<double>() + (size_t)B_ * A_;
+    HIPCHK(launch_action<T>((int)B_, mv, sv, (int64_t)AO * Vt, tie_window(k_chunk), chain_steps(), best_score_.as<double>(),
+                            err_.as<double>(), rdot_.as<double>(), rdot_err, action_.as<int32_t>(),
+                            kF32 ? aqueue_.as<int32_t>() : nullptr, aqcount, stream_));
     if (kF32)
         HIPCHK(launch_refine_action<T>(bel_.as<T>(), S_pad_, (int)B_, alpha_.as<T>(), S_pad_, mv, gamma,
-                                       aqueue_.as<int32_t>(), aqcount, rdot_.as<double>(), best_v_.as<int32_t>(),
+                                       aqueue_.as<int32_t>(), aqcount, rdot_.as<double>(), rdot_err, best_v_.as<int32_t>(),
                                        best_score_.as<double>(), err_.as<double>(), action_.as<int32_t>(), stream_));
     HIPCHK(hipEventRecord(ev_[5], stream_));
     // K3: alpha' rows

@@ -305,8 +305,9 @@ __global__ void k_tile_nonzero(const float* __restrict__ X, int ld, int k_tiles,
 
 // One block per (m-tile, n-tile[, batch]) pair: compact the K tiles where both operands are non-zero.
 // B's zero structure: G > 0 -> per row group, rows [g*v_group, (g+1)*v_group) share nzB[g][kt] (Gamma rows of
-// one (action, observation)) and rows >= G*v_group (the magnitude rows) may touch any group; G == 0 -> per
-// n-tile flags nzB[batch][tn][kt]; nzB == nullptr -> dense.
+// one (action, observation)); rows >= G*v_group (magnitude and reward rows) may touch any group or the extra
+// support row nzB[G] (so nzB is [G+1][k_tiles]); G == 0 -> per n-tile flags nzB[batch][tn][kt]; nzB == nullptr
+// -> dense.
 __global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* __restrict__ nzB, int G,
                                int v_group, int n_rows, int tiles_m, int k_tiles, int chunk_len, int force_dense,
                                int* __restrict__ klist, int* __restrict__ kcount, int* __restrict__ nchunks) {
@@ -322,9 +323,9 @@ __global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* _
     if (r1 >= n_rows) r1 = n_rows - 1;
     int g0 = 0, g1 = -1;                                // group range touched by this n-tile
     if (nzB != nullptr && G > 0 && r0 < n_rows) {
-        if (r1 >= G * v_group) {
-            g0 = 0;
-            g1 = G - 1;
+        if (r1 >= G * v_group) {                        // tail tile: magnitude + reward rows; nzB has a G-th row
+            g0 = 0;                                     // for the reward rows' support
+            g1 = G;
         } else {
             g0 = r0 / v_group;
             g1 = r1 / v_group;
