@@ -88,12 +88,13 @@ hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, in
 // K3: out[b][s] = ER[s,a*] + sum_o gamma * sum_r rto[a*][o][r][s] * alpha[v*[b,a*,o]][rs[a*][r][s]]
 template <typename T>
 hipError_t launch_assemble(const T* alpha, int lda, ModelView<T> mv, double gamma, const int32_t* action,
-                           const int32_t* best_v, int B, T* out, int ldo, hipStream_t st);
+                           const int32_t* best_v, int B, T* out, int ldo,
+                           const int32_t* perm /* out row = perm[b]; nullptr = identity */, hipStream_t st);
 
 // K5: keep[b] = (b . out[b]) > oldmax[b]
 template <typename T>
 hipError_t launch_keep(const T* bel, int ldb, const T* out, int ldo, int B, int S, const double* oldmax,
-                       uint8_t* keep, hipStream_t st);
+                       uint8_t* keep, const int32_t* perm, hipStream_t st);
 
 // prune level 2: cnt[i] = #{j : alpha[j][s] >= alpha[i][s] for all s}
 template <typename T>

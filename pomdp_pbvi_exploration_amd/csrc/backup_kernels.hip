@@ -566,10 +566,10 @@ hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, in
 template <typename T>
 __global__ void k_assemble(const T* __restrict__ alpha, int lda, ModelView<T> mv, double gamma,
                            const int32_t* __restrict__ action, const int32_t* __restrict__ best_v,
-                           T* __restrict__ out, int ldo) {
+                           T* __restrict__ out, int ldo, const int32_t* __restrict__ perm) {
 #pragma clang fp contract(off)
     const int s = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y;                               // row in the engine's (possibly sorted) belief order
     if (s >= mv.S) return;
     const int a = action[b];
     const int32_t* rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
@@ -584,16 +584,17 @@ __global__ void k_assemble(const T* __restrict__ alpha, int lda, ModelView<T> mv
         const double go = gamma * g;
         total = (o == 0) ? go : total + go;
     }
-    out[(int64_t)b * ldo + s] = (T)((double)mv.er[(int64_t)a * mv.S_pad + s] + total);
+    const int64_t orow = perm ? perm[b] : b;               // result row in the caller's order
+    out[orow * ldo + s] = (T)((double)mv.er[(int64_t)a * mv.S_pad + s] + total);
 }
 
 template <typename T>
 hipError_t launch_assemble(const T* alpha, int lda, ModelView<T> mv, double gamma, const int32_t* action,
-                           const int32_t* best_v, int B, T* out, int ldo, hipStream_t st) {
+                           const int32_t* best_v, int B, T* out, int ldo, const int32_t* perm, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     if (B > 65535) return hipErrorInvalidValue;
     dim3 grid((mv.S + 255) / 256, B);
-    hipLaunchKernelGGL(k_assemble<T>, grid, dim3(256), 0, st, alpha, lda, mv, gamma, action, best_v, out, ldo);
+    hipLaunchKernelGGL(k_assemble<T>, grid, dim3(256), 0, st, alpha, lda, mv, gamma, action, best_v, out, ldo, perm);
     return hipGetLastError();
 }
 
@@ -602,18 +603,19 @@ hipError_t launch_assemble(const T* alpha, int lda, ModelView<T> mv, double gamm
 // ------------------------------------------------------------------------- //
 template <typename T>
 __global__ void k_keep(const T* __restrict__ bel, int ldb, const T* __restrict__ out, int ldo, int S,
-                       const double* __restrict__ oldmax, uint8_t* __restrict__ keep) {
+                       const double* __restrict__ oldmax, uint8_t* __restrict__ keep, const int32_t* __restrict__ perm) {
     __shared__ double red[4];
     const int b = blockIdx.x;
-    const double nv = block_sum(plain_dot_partial(bel + (int64_t)b * ldb, out + (int64_t)b * ldo, S), red);
+    const int64_t orow = perm ? perm[b] : b;
+    const double nv = block_sum(plain_dot_partial(bel + (int64_t)b * ldb, out + orow * ldo, S), red);
     if (threadIdx.x == 0) keep[b] = (nv > oldmax[b]) ? 1 : 0;
 }
 
 template <typename T>
 hipError_t launch_keep(const T* bel, int ldb, const T* out, int ldo, int B, int S, const double* oldmax, uint8_t* keep,
-                       hipStream_t st) {
+                       const int32_t* perm, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_keep<T>, dim3(B), dim3(256), 0, st, bel, ldb, out, ldo, S, oldmax, keep);
+    hipLaunchKernelGGL(k_keep<T>, dim3(B), dim3(256), 0, st, bel, ldb, out, ldo, S, oldmax, keep, perm);
     return hipGetLastError();
 }
 
@@ -663,8 +665,9 @@ hipError_t launch_dominated(const T* alpha, int lda, int V, int S, int* cnt, hip
                                                 const int32_t*, const int*, const double*, const double*,              \
                                                 const int32_t*, double*, double*, int32_t*, hipStream_t);              \
     template hipError_t launch_assemble<T>(const T*, int, ModelView<T>, double, const int32_t*, const int32_t*, int,   \
-                                           T*, int, hipStream_t);                                                      \
-    template hipError_t launch_keep<T>(const T*, int, const T*, int, int, int, const double*, uint8_t*, hipStream_t);  \
+                                           T*, int, const int32_t*, hipStream_t);                                      \
+    template hipError_t launch_keep<T>(const T*, int, const T*, int, int, int, const double*, uint8_t*,                \
+                                       const int32_t*, hipStream_t);                                                   \
     template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
 PBVI_INST(float)
 PBVI_INST(double)

@@ -119,6 +119,52 @@ __global__ void k_project_mag(const T* __restrict__ amax, ModelView<T> mv, T gam
     gam_tail[(int64_t)ao * ldg + s] = gamma * acc;
 }
 
+// Belief reordering (f32 engines): rows are sorted by the first K tile that holds belief mass, so the
+// 256-row blocks of the score GEMM have tighter joint supports and more zero tiles to skip.
+template <typename T>
+__global__ void k_first_tile(const T* __restrict__ bel, int ldb, int S, int32_t* __restrict__ key) {
+    __shared__ int red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const T* row = bel + (int64_t)b * ldb;
+    int first = 0x7fffffff;
+    for (int s = tid; s < S; s += 256)
+        if (row[s] != T(0)) {
+            first = s;
+            break;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(first, off, 64);
+        first = o < first ? o : first;
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = first;
+    __syncthreads();
+    if (tid == 0) {
+        int m = red[0];
+        for (int w = 1; w < 4; ++w) m = red[w] < m ? red[w] : m;
+        key[b] = (m == 0x7fffffff) ? 0x7fffffff : m / GEMM_BK;
+    }
+}
+
+template <typename T>
+__global__ void k_gather_rows(const T* __restrict__ src, T* __restrict__ dst, int ld, const int32_t* __restrict__ perm) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= ld) return;
+    dst[(int64_t)blockIdx.y * ld + s] = src[(int64_t)perm[blockIdx.y] * ld + s];
+}
+
+__global__ void k_unpermute(int B, int AO, const int32_t* __restrict__ perm, const int32_t* __restrict__ action,
+                            const int32_t* __restrict__ best_v, const uint8_t* __restrict__ keep,
+                            int32_t* __restrict__ action_o, int32_t* __restrict__ best_o, uint8_t* __restrict__ keep_o) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int d = perm[b];
+    if (tid == 0) {
+        action_o[d] = action[b];
+        keep_o[d] = keep[b];
+    }
+    for (int j = tid; j < AO; j += blockDim.x) best_o[(int64_t)d * AO + j] = best_v[(int64_t)b * AO + j];
+}
+
 class EngineBase {
    public:
     virtual ~EngineBase() {}
@@ -153,6 +199,9 @@ class EngineT : public EngineBase {
     int64_t B_ = 0, B_pad_ = 0;
     DevBuf gam_, slabs_, best_v_, best_score_, err_, dead_, queue_, counters_, rdot_, action_, aqueue_, out_, keep_;
     DevBuf bv2_, bs2_, err2_, queue2_, prune_cnt_;
+    DevBuf stage_, keys_, perm_, action_res_, best_res_, keep_res_;   // belief reordering (f32, B > 256)
+    std::vector<int32_t> h_perm_;
+    bool sorted_ = false;
     DevBuf nzB_, nzA_, klist_, kcount_, nchunks_, need_, skws_;   // zero-tile bookkeeping of the f32 score GEMM
     DevBuf dense_, nzD_, nzAlpha_, prod_, klistD_, kcountD_, nchunksD_;   // dense projection mode
     int64_t rows_pad_s_ = 0, dense_pairs_ = 0;
@@ -161,14 +210,15 @@ class EngineT : public EngineBase {
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     GemmPlan plan_ = {};
     hipEvent_t ev_[9] = {};
-    bool have_result_ = false;
+    bool have_result_ = false, res_sorted_ = false;
     int64_t res_B_ = 0;
 
     ~EngineT() override {
         (void)hipSetDevice(device_);
         DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
-                         &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_,
+                         &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
+                         &action_res_, &best_res_, &keep_res_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
@@ -346,8 +396,32 @@ class EngineT : public EngineBase {
         int rc = bel_.ensure((size_t)Bp * S_pad_ * sizeof(T), &bytes_);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(bel_.p, 0, (size_t)Bp * S_pad_ * sizeof(T), stream_));
-        HIPCHK(hipMemcpy2DAsync(bel_.p, (size_t)S_pad_ * sizeof(T), bel, (size_t)S_ * sizeof(T), (size_t)S_ * sizeof(T),
-                                (size_t)B, hipMemcpyHostToDevice, stream_));
+        static const bool no_sort = getenv("PBVI_NO_BELIEF_SORT") != nullptr;     // debug / A-B only
+        sorted_ = kF32 && B > GEMM_BM && !no_sort;
+        if (sorted_) {
+            if ((rc = stage_.ensure((size_t)B * S_pad_ * sizeof(T), &bytes_))) return rc;
+            if ((rc = keys_.ensure((size_t)B * sizeof(int32_t), &bytes_))) return rc;
+            if ((rc = perm_.ensure((size_t)B * sizeof(int32_t), &bytes_))) return rc;
+            HIPCHK(hipMemsetAsync(stage_.p, 0, (size_t)B * S_pad_ * sizeof(T), stream_));
+            HIPCHK(hipMemcpy2DAsync(stage_.p, (size_t)S_pad_ * sizeof(T), bel, (size_t)S_ * sizeof(T),
+                                    (size_t)S_ * sizeof(T), (size_t)B, hipMemcpyHostToDevice, stream_));
+            hipLaunchKernelGGL(k_first_tile<T>, dim3((unsigned)B), dim3(256), 0, stream_, stage_.as<T>(), S_pad_, S_,
+                               keys_.as<int32_t>());
+            HIPCHK(hipGetLastError());
+            std::vector<int32_t> key((size_t)B);
+            HIPCHK(hipMemcpyAsync(key.data(), keys_.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            h_perm_.resize((size_t)B);
+            for (int64_t i = 0; i < B; ++i) h_perm_[(size_t)i] = (int32_t)i;
+            std::stable_sort(h_perm_.begin(), h_perm_.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
+            HIPCHK(hipMemcpyAsync(perm_.p, h_perm_.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+            hipLaunchKernelGGL(k_gather_rows<T>, dim3((S_pad_ + 255) / 256, (unsigned)B), dim3(256), 0, stream_,
+                               stage_.as<T>(), bel_.as<T>(), S_pad_, perm_.as<int32_t>());
+            HIPCHK(hipGetLastError());
+        } else {
+            HIPCHK(hipMemcpy2DAsync(bel_.p, (size_t)S_pad_ * sizeof(T), bel, (size_t)S_ * sizeof(T),
+                                    (size_t)S_ * sizeof(T), (size_t)B, hipMemcpyHostToDevice, stream_));
+        }
         if (kF32) {   // which 256x32 belief tiles hold a non-zero (A-operand side of zero-tile skipping)
             const int k_tiles = S_pad_ / GEMM_BK;
             if ((rc = nzA_.ensure((size_t)(Bp / GEMM_BM) * k_tiles, &bytes_))) return rc;
@@ -386,10 +460,12 @@ class EngineT : public EngineBase {
         HIPCHK(hipSetDevice(device_));
         const size_t B = (size_t)res_B_;
         if (out_alpha) HIPCHK(hipMemcpyAsync(out_alpha, out_.p, B * S_ * sizeof(T), hipMemcpyDefault, stream_));
-        if (out_action) HIPCHK(hipMemcpyAsync(out_action, action_.p, B * sizeof(int32_t), hipMemcpyDefault, stream_));
-        if (out_best)
-            HIPCHK(hipMemcpyAsync(out_best, best_v_.p, B * A_ * O_ * sizeof(int32_t), hipMemcpyDefault, stream_));
-        if (out_keep) HIPCHK(hipMemcpyAsync(out_keep, keep_.p, B, hipMemcpyDefault, stream_));
+        const void* act = res_sorted_ ? action_res_.p : action_.p;
+        const void* bst = res_sorted_ ? best_res_.p : best_v_.p;
+        const void* kp = res_sorted_ ? keep_res_.p : keep_.p;
+        if (out_action) HIPCHK(hipMemcpyAsync(out_action, act, B * sizeof(int32_t), hipMemcpyDefault, stream_));
+        if (out_best) HIPCHK(hipMemcpyAsync(out_best, bst, B * A_ * O_ * sizeof(int32_t), hipMemcpyDefault, stream_));
+        if (out_keep) HIPCHK(hipMemcpyAsync(out_keep, kp, B, hipMemcpyDefault, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
         return PBVI_OK;
     }
@@ -397,8 +473,8 @@ class EngineT : public EngineBase {
     int device_results(void** d_alpha, int32_t** d_action, uint8_t** d_keep) override {
         if (!have_result_) FAIL(PBVI_EINVAL, "no backup result resident");
         if (d_alpha) *d_alpha = out_.p;
-        if (d_action) *d_action = action_.as<int32_t>();
-        if (d_keep) *d_keep = keep_.as<uint8_t>();
+        if (d_action) *d_action = res_sorted_ ? action_res_.as<int32_t>() : action_.as<int32_t>();
+        if (d_keep) *d_keep = res_sorted_ ? keep_res_.as<uint8_t>() : keep_.as<uint8_t>();
         return PBVI_OK;
     }
 
@@ -425,9 +501,24 @@ class EngineT : public EngineBase {
         HIPCHK(hipSetDevice(device_));
         int rc = value_max_device();
         if (rc) return rc;
-        if (out_value) HIPCHK(hipMemcpyAsync(out_value, bs2_.p, (size_t)B_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        if (out_index) HIPCHK(hipMemcpyAsync(out_index, bv2_.p, (size_t)B_ * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        std::vector<double> tv;
+        std::vector<int32_t> ti;
+        double* dv = out_value;
+        int32_t* di = out_index;
+        if (sorted_) {                      // device results are in sorted belief order
+            tv.resize((size_t)B_);
+            ti.resize((size_t)B_);
+            dv = tv.data();
+            di = ti.data();
+        }
+        if (out_value) HIPCHK(hipMemcpyAsync(dv, bs2_.p, (size_t)B_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        if (out_index) HIPCHK(hipMemcpyAsync(di, bv2_.p, (size_t)B_ * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
+        if (sorted_)
+            for (int64_t i = 0; i < B_; ++i) {
+                if (out_value) out_value[h_perm_[(size_t)i]] = tv[(size_t)i];
+                if (out_index) out_index[h_perm_[(size_t)i]] = ti[(size_t)i];
+            }
         return PBVI_OK;
     }
 
@@ -635,17 +726,28 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
                                        best_score_.as<double>(), err_.as<double>(), action_.as<int32_t>(), stream_));
     HIPCHK(hipEventRecord(ev_[5], stream_));
     // K3: alpha' rows
+    const int32_t* perm = sorted_ ? perm_.as<int32_t>() : nullptr;
     HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, mv, gamma, action_.as<int32_t>(), best_v_.as<int32_t>(), (int)B_,
-                              out_.as<T>(), S_, stream_));
+                              out_.as<T>(), S_, perm, stream_));
     HIPCHK(hipEventRecord(ev_[6], stream_));
     // K5: belief dominance
     if (flags & PBVI_BELIEF_DOMINANCE) {
         if ((rc = value_max_device())) return rc;
         HIPCHK(launch_keep<T>(bel_.as<T>(), S_pad_, out_.as<T>(), S_, (int)B_, S_, bs2_.as<double>(), keep_.as<uint8_t>(),
-                              stream_));
+                              perm, stream_));
     } else {
         HIPCHK(hipMemsetAsync(keep_.p, 1, (size_t)B_, stream_));
     }
+    if (sorted_) {   // results back to the caller's belief order
+        if ((rc = action_res_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = best_res_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = keep_res_.ensure((size_t)B_, &bytes_))) return rc;
+        hipLaunchKernelGGL(k_unpermute, dim3((unsigned)B_), dim3(64), 0, stream_, (int)B_, AO, perm, action_.as<int32_t>(),
+                           best_v_.as<int32_t>(), keep_.as<uint8_t>(), action_res_.as<int32_t>(), best_res_.as<int32_t>(),
+                           keep_res_.as<uint8_t>());
+        HIPCHK(hipGetLastError());
+    }
+    res_sorted_ = sorted_;
     HIPCHK(hipEventRecord(ev_[7], stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     have_result_ = true;
