@@ -157,6 +157,17 @@ def main():
             'refined_pairs': int(stats[-1]['n_refined']), 'dead_pairs': int(stats[-1]['n_dead']),
             'refined_actions': int(stats[-1]['n_refined_actions']), 'pairs': int(stats[-1]['n_pairs']), 'split_k': int(stats[-1]['split_k']),
         }
+        # HBM-side bytes per launch of the roofline kernel come from a separate rocprofv3 --pmc run
+        # (FETCH_SIZE / WRITE_SIZE cannot be read inside this process); reported only for the exact
+        # workload they were measured on.
+        try:
+            with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')) as fh:
+                pmc = json.load(fh)
+            if (args.mode == 'sparse' and m.S == 30000 and m.R == 1 and args.alphas == 1024 and B == 1024):
+                out['roofline']['traffic'] = pmc['traffic_bytes']
+                out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes)'
+        except (OSError, KeyError, ValueError):
+            pass
         if args.mode == 'dense':   # the projection GEMMs dominate: report them as the roofline kernel
             ms_proj = float(np.mean([s['ms_project'] for s in stats]))
             pf, pfe = stats[0]['project_flops'], stats[0]['project_flops_executed']
