@@ -68,6 +68,7 @@ typedef struct pbvi_stats {
     int64_t n_dead;         /* triples with P(o|b,a) == 0 (all scores exactly 0) */
     int64_t n_refined;      /* triples whose argmax was re-decided in fp64 */
     int64_t n_refined_actions; /* beliefs whose action argmax was re-decided in fp64 */
+    int64_t n_unique;       /* distinct (action, best_alpha_ind[action]) keys = alpha' rows actually assembled */
     int64_t score_flops;    /* algorithmic 2*B*S*A*O*V of the score GEMM */
     int64_t score_flops_executed; /* MFMA flops actually issued (zero tiles skipped, pad tiles included) */
     int64_t score_tiles_dense;    /* 256x256x32 tile steps a dense GEMM of the padded shape would run */
@@ -128,6 +129,18 @@ int pbvi_backup_run(pbvi_engine_t* e, double gamma, int flags, pbvi_stats_t* sta
  */
 int pbvi_backup_fetch(pbvi_engine_t* e, void* out_alpha, int32_t* out_action,
                       int32_t* out_best_alpha, uint8_t* out_keep);
+
+/*
+ * Deduplicated form of the same result (K6).  Beliefs with equal (best_action, best_alpha_ind[b,
+ * best_action, :]) produce byte-identical alpha' rows, so the engine assembles one row per distinct
+ * key -- a subset of the duplicates ValueFunction.__init__ removes by bytes (src/mdp.py:667-669), found
+ * before any row is computed or moved.  U = pbvi_backup_unique_count():
+ *   out_rows  [U][S] T     row u = alpha' of the first belief (in the caller's order) with that key
+ *   out_index [B] int32    alpha'[b] == out_rows[out_index[b]]
+ * Destinations may be host or device memory.  pbvi_backup_fetch(out_alpha) expands this to [B][S].
+ */
+int64_t pbvi_backup_unique_count(const pbvi_engine_t* e);
+int pbvi_backup_fetch_unique(pbvi_engine_t* e, void* out_rows, int32_t* out_index);
 
 /*
  * Device addresses of the last run's results, for the multi-GPU layer to hand to

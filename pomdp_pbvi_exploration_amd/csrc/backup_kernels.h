@@ -85,16 +85,22 @@ hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, in
                                 const int32_t* aqueue, const int* aqcount, const double* rdot, const double* rdot_err,
                                 const int32_t* best_v, double* best_score, double* err, int32_t* action, hipStream_t st);
 
-// K3: out[b][s] = ER[s,a*] + sum_o gamma * sum_r rto[a*][o][r][s] * alpha[v*[b,a*,o]][rs[a*][r][s]]
+// K3: out[u][s] = ER[s,a*] + sum_o gamma * sum_r rto[a*][o][r][s] * alpha[v*[b,a*,o]][rs[a*][r][s]], b = rows[u]
+// (rows/n_rows on the device: only the unique (a*, v*) keys are assembled; nullptr = every belief)
 template <typename T>
 hipError_t launch_assemble(const T* alpha, int lda, ModelView<T> mv, double gamma, const int32_t* action,
-                           const int32_t* best_v, int B, T* out, int ldo,
-                           const int32_t* perm /* out row = perm[b]; nullptr = identity */, hipStream_t st);
-
-// K5: keep[b] = (b . out[b]) > oldmax[b]
+                           const int32_t* best_v, const int32_t* rows, const int* n_rows, int max_rows, T* out, int ldo,
+                           hipStream_t st);
+// K6: key dedup in caller order (rep, uniq list, inverse index, count on the device)
+hipError_t launch_dedup(int B, int A, int O, const int32_t* action, const int32_t* best_v, int32_t* rep, int32_t* uniq,
+                        int32_t* inv, int32_t* slot, int* count, hipStream_t st);
 template <typename T>
-hipError_t launch_keep(const T* bel, int ldb, const T* out, int ldo, int B, int S, const double* oldmax,
-                       uint8_t* keep, const int32_t* perm, hipStream_t st);
+hipError_t launch_expand_rows(const T* uniq_rows, const int32_t* inv, T* full, int B, int S, hipStream_t st);
+
+// K5: keep[c] = (b . alpha'[b]) > oldmax[b], c = caller index of engine row b
+template <typename T>
+hipError_t launch_keep(const T* bel, int ldb, const T* uniq_rows, int ldo, int B, int S, const double* oldmax,
+                       const int32_t* inv, const int32_t* perm, uint8_t* keep, hipStream_t st);
 
 // prune level 2: cnt[i] = #{j : alpha[j][s] >= alpha[i][s] for all s}
 template <typename T>

@@ -566,11 +566,15 @@ hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, in
 template <typename T>
 __global__ void k_assemble(const T* __restrict__ alpha, int lda, ModelView<T> mv, double gamma,
                            const int32_t* __restrict__ action, const int32_t* __restrict__ best_v,
-                           T* __restrict__ out, int ldo, const int32_t* __restrict__ perm) {
+                           const int32_t* __restrict__ rows, const int* __restrict__ n_rows, T* __restrict__ out, int ldo) {
 #pragma clang fp contract(off)
+    // Output row u is the alpha' of belief rows[u] (the first belief carrying that (a*, v*) key): only
+    // unique rows are materialised.  rows == nullptr: u is the belief itself.
     const int s = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;                               // row in the engine's (possibly sorted) belief order
+    const int u = blockIdx.y;
+    if (n_rows != nullptr && u >= *n_rows) return;
     if (s >= mv.S) return;
+    const int b = rows ? rows[u] : u;
     const int a = action[b];
     const int32_t* rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
     double total = 0.0;
@@ -584,17 +588,107 @@ __global__ void k_assemble(const T* __restrict__ alpha, int lda, ModelView<T> mv
         const double go = gamma * g;
         total = (o == 0) ? go : total + go;
     }
-    const int64_t orow = perm ? perm[b] : b;               // result row in the caller's order
-    out[orow * ldo + s] = (T)((double)mv.er[(int64_t)a * mv.S_pad + s] + total);
+    out[(int64_t)u * ldo + s] = (T)((double)mv.er[(int64_t)a * mv.S_pad + s] + total);
 }
 
 template <typename T>
 hipError_t launch_assemble(const T* alpha, int lda, ModelView<T> mv, double gamma, const int32_t* action,
-                           const int32_t* best_v, int B, T* out, int ldo, const int32_t* perm, hipStream_t st) {
+                           const int32_t* best_v, const int32_t* rows, const int* n_rows, int max_rows, T* out, int ldo,
+                           hipStream_t st) {
+    if (max_rows <= 0) return hipSuccess;
+    if (max_rows > 65535) return hipErrorInvalidValue;
+    dim3 grid((mv.S + 255) / 256, max_rows);
+    hipLaunchKernelGGL(k_assemble<T>, grid, dim3(256), 0, st, alpha, lda, mv, gamma, action, best_v, rows, n_rows, out, ldo);
+    return hipGetLastError();
+}
+
+// K6: device-side dedup.  Two beliefs with the same key (a*, v*[a*, 0..O-1]) get byte-identical alpha' rows
+// (same arithmetic on the same operands), so only the first belief of each key is assembled:
+//   rep[c]  = first belief (caller order) with c's key
+//   uniq[u] = u-th belief with rep[c] == c;  inv[c] = u such that uniq[u] == rep[c]
+// This finds a subset of the reference's byte-level duplicates (src/mdp.py:667-669); rows that coincide
+// under different keys are still merged by the host-side byte dedup of the ValueFunction constructor.
+__global__ void k_dedup_rep(int B, int A, int O, const int32_t* __restrict__ action, const int32_t* __restrict__ best_v,
+                            int32_t* __restrict__ rep) {
+    // one wavefront per belief c: lanes scan the earlier beliefs d < c in parallel, lowest match wins
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= B) return;
+    const int a = action[c];
+    const int32_t* kc = best_v + ((int64_t)c * A + a) * O;
+    int r = c;
+    for (int d0 = 0; d0 < c; d0 += 64) {
+        const int d = d0 + lane;
+        int hit = 0;
+        if (d < c && action[d] == a) {
+            const int32_t* kd = best_v + ((int64_t)d * A + a) * O;
+            hit = 1;
+            for (int o = 0; o < O; ++o) hit &= (kd[o] == kc[o]);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {                                            // wave-uniform
+            r = d0 + __ffsll((long long)m) - 1;
+            break;
+        }
+    }
+    if (lane == 0) rep[c] = r;
+}
+
+__global__ void k_dedup_compact(int B, const int32_t* __restrict__ rep, int32_t* __restrict__ uniq,
+                                int32_t* __restrict__ inv, int32_t* __restrict__ slot, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;      // one block of 1024 threads
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < B; c0 += 1024) {
+        const int c = c0 + tid;
+        const int f = (c < B && rep[c] == c) ? 1 : 0;
+        const unsigned long long mask = __ballot(f);
+        if (lane == 0) wsum[wid] = __popcll(mask);
+        __syncthreads();
+        int off = base_sh;
+        for (int w = 0; w < wid; ++w) off += wsum[w];
+        if (f) {
+            const int u = off + __popcll(mask & ((1ull << lane) - 1ull));
+            uniq[u] = c;
+            slot[c] = u;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wsum[w];
+            base_sh += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *count = base_sh;
+    __syncthreads();
+    for (int c = tid; c < B; c += 1024) inv[c] = slot[rep[c]];        // rep[c] <= c and slot[rep] was written above
+}
+
+hipError_t launch_dedup(int B, int A, int O, const int32_t* action, const int32_t* best_v, int32_t* rep, int32_t* uniq,
+                        int32_t* inv, int32_t* slot, int* count, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    if (B > 65535) return hipErrorInvalidValue;
-    dim3 grid((mv.S + 255) / 256, B);
-    hipLaunchKernelGGL(k_assemble<T>, grid, dim3(256), 0, st, alpha, lda, mv, gamma, action, best_v, out, ldo, perm);
+    hipLaunchKernelGGL(k_dedup_rep, dim3((B + 3) / 4), dim3(256), 0, st, B, A, O, action, best_v, rep);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_dedup_compact, dim3(1), dim3(1024), 0, st, B, rep, uniq, inv, slot, count);
+    return hipGetLastError();
+}
+
+// full[c][s] = uniq_rows[inv[c]][s]   (per-belief matrix of the reference seam, built on demand)
+template <typename T>
+__global__ void k_expand_rows(const T* __restrict__ uniq_rows, const int32_t* __restrict__ inv, T* __restrict__ full, int S) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    full[(int64_t)blockIdx.y * S + s] = uniq_rows[(int64_t)inv[blockIdx.y] * S + s];
+}
+
+template <typename T>
+hipError_t launch_expand_rows(const T* uniq_rows, const int32_t* inv, T* full, int B, int S, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_expand_rows<T>, dim3((S + 255) / 256, B), dim3(256), 0, st, uniq_rows, inv, full, S);
     return hipGetLastError();
 }
 
@@ -602,20 +696,21 @@ hipError_t launch_assemble(const T* alpha, int lda, ModelView<T> mv, double gamm
 // K5: belief-dominance test.  src/pomdp.py:1510-1512
 // ------------------------------------------------------------------------- //
 template <typename T>
-__global__ void k_keep(const T* __restrict__ bel, int ldb, const T* __restrict__ out, int ldo, int S,
-                       const double* __restrict__ oldmax, uint8_t* __restrict__ keep, const int32_t* __restrict__ perm) {
+__global__ void k_keep(const T* __restrict__ bel, int ldb, const T* __restrict__ uniq_rows, int ldo, int S,
+                       const double* __restrict__ oldmax, const int32_t* __restrict__ inv,
+                       const int32_t* __restrict__ perm, uint8_t* __restrict__ keep) {
     __shared__ double red[4];
-    const int b = blockIdx.x;
-    const int64_t orow = perm ? perm[b] : b;
-    const double nv = block_sum(plain_dot_partial(bel + (int64_t)b * ldb, out + orow * ldo, S), red);
-    if (threadIdx.x == 0) keep[b] = (nv > oldmax[b]) ? 1 : 0;
+    const int b = blockIdx.x;                               // engine (possibly sorted) belief order
+    const int c = perm ? perm[b] : b;                       // caller order
+    const double nv = block_sum(plain_dot_partial(bel + (int64_t)b * ldb, uniq_rows + (int64_t)inv[c] * ldo, S), red);
+    if (threadIdx.x == 0) keep[c] = (nv > oldmax[b]) ? 1 : 0;
 }
 
 template <typename T>
-hipError_t launch_keep(const T* bel, int ldb, const T* out, int ldo, int B, int S, const double* oldmax, uint8_t* keep,
-                       const int32_t* perm, hipStream_t st) {
+hipError_t launch_keep(const T* bel, int ldb, const T* uniq_rows, int ldo, int B, int S, const double* oldmax,
+                       const int32_t* inv, const int32_t* perm, uint8_t* keep, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_keep<T>, dim3(B), dim3(256), 0, st, bel, ldb, out, ldo, S, oldmax, keep, perm);
+    hipLaunchKernelGGL(k_keep<T>, dim3(B), dim3(256), 0, st, bel, ldb, uniq_rows, ldo, S, oldmax, inv, perm, keep);
     return hipGetLastError();
 }
 
@@ -664,10 +759,11 @@ hipError_t launch_dominated(const T* alpha, int lda, int V, int S, int* cnt, hip
     template hipError_t launch_refine_action<T>(const T*, int, int, const T*, int, ModelView<T>, double,               \
                                                 const int32_t*, const int*, const double*, const double*,              \
                                                 const int32_t*, double*, double*, int32_t*, hipStream_t);              \
-    template hipError_t launch_assemble<T>(const T*, int, ModelView<T>, double, const int32_t*, const int32_t*, int,   \
-                                           T*, int, const int32_t*, hipStream_t);                                      \
-    template hipError_t launch_keep<T>(const T*, int, const T*, int, int, int, const double*, uint8_t*,                \
-                                       const int32_t*, hipStream_t);                                                   \
+    template hipError_t launch_assemble<T>(const T*, int, ModelView<T>, double, const int32_t*, const int32_t*,        \
+                                           const int32_t*, const int*, int, T*, int, hipStream_t);                     \
+    template hipError_t launch_expand_rows<T>(const T*, const int32_t*, T*, int, int, hipStream_t);                    \
+    template hipError_t launch_keep<T>(const T*, int, const T*, int, int, int, const double*, const int32_t*,          \
+                                       const int32_t*, uint8_t*, hipStream_t);                                         \
     template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
 PBVI_INST(float)
 PBVI_INST(double)

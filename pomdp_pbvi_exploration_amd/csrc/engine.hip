@@ -154,14 +154,10 @@ __global__ void k_gather_rows(const T* __restrict__ src, T* __restrict__ dst, in
 }
 
 __global__ void k_unpermute(int B, int AO, const int32_t* __restrict__ perm, const int32_t* __restrict__ action,
-                            const int32_t* __restrict__ best_v, const uint8_t* __restrict__ keep,
-                            int32_t* __restrict__ action_o, int32_t* __restrict__ best_o, uint8_t* __restrict__ keep_o) {
+                            const int32_t* __restrict__ best_v, int32_t* __restrict__ action_o, int32_t* __restrict__ best_o) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int d = perm[b];
-    if (tid == 0) {
-        action_o[d] = action[b];
-        keep_o[d] = keep[b];
-    }
+    if (tid == 0) action_o[d] = action[b];
     for (int j = tid; j < AO; j += blockDim.x) best_o[(int64_t)d * AO + j] = best_v[(int64_t)b * AO + j];
 }
 
@@ -175,6 +171,8 @@ class EngineBase {
     virtual int backup_run(double gamma, int flags, pbvi_stats_t* st) = 0;
     virtual int backup_fetch(void* out_alpha, int32_t* out_action, int32_t* out_best, uint8_t* out_keep) = 0;
     virtual int device_results(void** d_alpha, int32_t** d_action, uint8_t** d_keep) = 0;
+    virtual int64_t unique_count() const = 0;
+    virtual int fetch_unique(void* out_rows, int32_t* out_index) = 0;
     virtual int prune_dominated(uint8_t* keep) = 0;
     virtual int value_max(double* out_value, int32_t* out_index) = 0;
     virtual int set_tie_window(double rel) = 0;
@@ -199,7 +197,12 @@ class EngineT : public EngineBase {
     int64_t B_ = 0, B_pad_ = 0;
     DevBuf gam_, slabs_, best_v_, best_score_, err_, dead_, queue_, counters_, rdot_, action_, aqueue_, out_, keep_;
     DevBuf bv2_, bs2_, err2_, queue2_, prune_cnt_;
-    DevBuf stage_, keys_, perm_, action_res_, best_res_, keep_res_;   // belief reordering (f32, B > 256)
+    DevBuf stage_, keys_, perm_, action_res_, best_res_;   // belief reordering (f32, B > 256)
+    DevBuf rep_, uniq_, inv_, slot_, out_full_;            // K6 key dedup: out_ holds the unique rows
+    const int32_t* res_action_ = nullptr;                  // results in caller order
+    const int32_t* res_best_ = nullptr;
+    int64_t res_unique_ = 0;
+    bool full_valid_ = false;
     std::vector<int32_t> h_perm_;
     bool sorted_ = false;
     DevBuf nzB_, nzA_, klist_, kcount_, nchunks_, need_, skws_;   // zero-tile bookkeeping of the f32 score GEMM
@@ -218,7 +221,7 @@ class EngineT : public EngineBase {
         DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
-                         &action_res_, &best_res_, &keep_res_,
+                         &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
@@ -455,26 +458,55 @@ class EngineT : public EngineBase {
     int project_dense(double gamma);   // K1-dense: Gamma = gamma * alpha . D_ao^T as A*O (batched) GEMMs
     int backup_run(double gamma, int flags, pbvi_stats_t* st) override;
 
+    // per-belief alpha' matrix [B][S] (the reference seam) expanded from the unique rows on first use
+    int ensure_full() {
+        if (full_valid_) return PBVI_OK;
+        int rc = out_full_.ensure((size_t)res_B_ * S_ * sizeof(T), &bytes_);
+        if (rc) return rc;
+        HIPCHK(launch_expand_rows<T>(out_.as<T>(), inv_.as<int32_t>(), out_full_.as<T>(), (int)res_B_, S_, stream_));
+        full_valid_ = true;
+        return PBVI_OK;
+    }
+
     int backup_fetch(void* out_alpha, int32_t* out_action, int32_t* out_best, uint8_t* out_keep) override {
         if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch: no backup result resident (call pbvi_backup_run first)");
         HIPCHK(hipSetDevice(device_));
         const size_t B = (size_t)res_B_;
-        if (out_alpha) HIPCHK(hipMemcpyAsync(out_alpha, out_.p, B * S_ * sizeof(T), hipMemcpyDefault, stream_));
-        const void* act = res_sorted_ ? action_res_.p : action_.p;
-        const void* bst = res_sorted_ ? best_res_.p : best_v_.p;
-        const void* kp = res_sorted_ ? keep_res_.p : keep_.p;
-        if (out_action) HIPCHK(hipMemcpyAsync(out_action, act, B * sizeof(int32_t), hipMemcpyDefault, stream_));
-        if (out_best) HIPCHK(hipMemcpyAsync(out_best, bst, B * A_ * O_ * sizeof(int32_t), hipMemcpyDefault, stream_));
-        if (out_keep) HIPCHK(hipMemcpyAsync(out_keep, kp, B, hipMemcpyDefault, stream_));
+        if (out_alpha) {
+            int rc = ensure_full();
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(out_alpha, out_full_.p, B * S_ * sizeof(T), hipMemcpyDefault, stream_));
+        }
+        if (out_action) HIPCHK(hipMemcpyAsync(out_action, res_action_, B * sizeof(int32_t), hipMemcpyDefault, stream_));
+        if (out_best) HIPCHK(hipMemcpyAsync(out_best, res_best_, B * A_ * O_ * sizeof(int32_t), hipMemcpyDefault, stream_));
+        if (out_keep) HIPCHK(hipMemcpyAsync(out_keep, keep_.p, B, hipMemcpyDefault, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        return PBVI_OK;
+    }
+
+    int64_t unique_count() const override { return have_result_ ? res_unique_ : -1; }
+
+    int fetch_unique(void* out_rows, int32_t* out_index) override {
+        if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch_unique: no backup result resident");
+        HIPCHK(hipSetDevice(device_));
+        if (out_rows)
+            HIPCHK(hipMemcpyAsync(out_rows, out_.p, (size_t)res_unique_ * S_ * sizeof(T), hipMemcpyDefault, stream_));
+        if (out_index)
+            HIPCHK(hipMemcpyAsync(out_index, inv_.p, (size_t)res_B_ * sizeof(int32_t), hipMemcpyDefault, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
         return PBVI_OK;
     }
 
     int device_results(void** d_alpha, int32_t** d_action, uint8_t** d_keep) override {
         if (!have_result_) FAIL(PBVI_EINVAL, "no backup result resident");
-        if (d_alpha) *d_alpha = out_.p;
-        if (d_action) *d_action = res_sorted_ ? action_res_.as<int32_t>() : action_.as<int32_t>();
-        if (d_keep) *d_keep = res_sorted_ ? keep_res_.as<uint8_t>() : keep_.as<uint8_t>();
+        if (d_alpha) {
+            int rc = ensure_full();
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(stream_));
+            *d_alpha = out_full_.p;
+        }
+        if (d_action) *d_action = const_cast<int32_t*>(res_action_);
+        if (d_keep) *d_keep = keep_.as<uint8_t>();
         return PBVI_OK;
     }
 
@@ -725,33 +757,48 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
                                        aqueue_.as<int32_t>(), aqcount, rdot_.as<double>(), rdot_err, best_v_.as<int32_t>(),
                                        best_score_.as<double>(), err_.as<double>(), action_.as<int32_t>(), stream_));
     HIPCHK(hipEventRecord(ev_[5], stream_));
-    // K3: alpha' rows
+    // results to the caller's belief order, then K6: dedup by (a*, v*) key
     const int32_t* perm = sorted_ ? perm_.as<int32_t>() : nullptr;
-    HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, mv, gamma, action_.as<int32_t>(), best_v_.as<int32_t>(), (int)B_,
-                              out_.as<T>(), S_, perm, stream_));
+    if (sorted_) {
+        if ((rc = action_res_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = best_res_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc;
+        hipLaunchKernelGGL(k_unpermute, dim3((unsigned)B_), dim3(64), 0, stream_, (int)B_, AO, perm, action_.as<int32_t>(),
+                           best_v_.as<int32_t>(), action_res_.as<int32_t>(), best_res_.as<int32_t>());
+        HIPCHK(hipGetLastError());
+        res_action_ = action_res_.as<int32_t>();
+        res_best_ = best_res_.as<int32_t>();
+    } else {
+        res_action_ = action_.as<int32_t>();
+        res_best_ = best_v_.as<int32_t>();
+    }
+    if ((rc = rep_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+    if ((rc = uniq_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+    if ((rc = inv_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+    if ((rc = slot_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+    int* ucount = counters_.as<int>() + 3;
+    HIPCHK(launch_dedup((int)B_, A_, O_, res_action_, res_best_, rep_.as<int32_t>(), uniq_.as<int32_t>(),
+                        inv_.as<int32_t>(), slot_.as<int32_t>(), ucount, stream_));
+    // K3: alpha' rows of the unique keys only
+    HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, mv, gamma, res_action_, res_best_, uniq_.as<int32_t>(), ucount,
+                              (int)B_, out_.as<T>(), S_, stream_));
     HIPCHK(hipEventRecord(ev_[6], stream_));
-    // K5: belief dominance
+    // K5: belief dominance (keep is written in caller order)
     if (flags & PBVI_BELIEF_DOMINANCE) {
         if ((rc = value_max_device())) return rc;
-        HIPCHK(launch_keep<T>(bel_.as<T>(), S_pad_, out_.as<T>(), S_, (int)B_, S_, bs2_.as<double>(), keep_.as<uint8_t>(),
-                              perm, stream_));
+        HIPCHK(launch_keep<T>(bel_.as<T>(), S_pad_, out_.as<T>(), S_, (int)B_, S_, bs2_.as<double>(), inv_.as<int32_t>(),
+                              perm, keep_.as<uint8_t>(), stream_));
     } else {
         HIPCHK(hipMemsetAsync(keep_.p, 1, (size_t)B_, stream_));
     }
-    if (sorted_) {   // results back to the caller's belief order
-        if ((rc = action_res_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
-        if ((rc = best_res_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc;
-        if ((rc = keep_res_.ensure((size_t)B_, &bytes_))) return rc;
-        hipLaunchKernelGGL(k_unpermute, dim3((unsigned)B_), dim3(64), 0, stream_, (int)B_, AO, perm, action_.as<int32_t>(),
-                           best_v_.as<int32_t>(), keep_.as<uint8_t>(), action_res_.as<int32_t>(), best_res_.as<int32_t>(),
-                           keep_res_.as<uint8_t>());
-        HIPCHK(hipGetLastError());
-    }
+    int h_ucount = 0;
+    HIPCHK(hipMemcpyAsync(&h_ucount, ucount, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    full_valid_ = false;
     res_sorted_ = sorted_;
     HIPCHK(hipEventRecord(ev_[7], stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     have_result_ = true;
     res_B_ = B_;
+    res_unique_ = h_ucount;
 
     if (st) {
         std::memset(st, 0, sizeof(*st));
@@ -775,6 +822,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         HIPCHK(hipMemcpy(h, counters_.p, sizeof(h), hipMemcpyDeviceToHost));
         st->n_refined = h[0];
         st->n_refined_actions = h[1];
+        st->n_unique = h_ucount;
         if (kF32) {
             std::vector<uint8_t> hd((size_t)pairs);
             HIPCHK(hipMemcpy(hd.data(), dead_.p, (size_t)pairs, hipMemcpyDeviceToHost));
@@ -907,6 +955,11 @@ int pbvi_backup_fetch(pbvi_engine_t* e, void* out_alpha, int32_t* out_action, in
 int pbvi_backup_device_results(pbvi_engine_t* e, void** d_alpha, int32_t** d_action, uint8_t** d_keep) {
     NEED(e);
     return e->impl->device_results(d_alpha, d_action, d_keep);
+}
+int64_t pbvi_backup_unique_count(const pbvi_engine_t* e) { return (e && e->impl) ? e->impl->unique_count() : -1; }
+int pbvi_backup_fetch_unique(pbvi_engine_t* e, void* out_rows, int32_t* out_index) {
+    NEED(e);
+    return e->impl->fetch_unique(out_rows, out_index);
 }
 int pbvi_backup(pbvi_engine_t* e, const void* beliefs, int64_t B, double gamma, int flags, void* out_alpha,
                 int32_t* out_action, int32_t* out_best_alpha, uint8_t* out_keep, pbvi_stats_t* stats) {

@@ -74,6 +74,41 @@ class ShardedBackup:
         return self.gather_rows(rows, acts, keep, n)
 
 
+def gather_unique(dist, group, rows, count: int, index, actions, keep, n_total: int):
+    """All-gather of deduplicated per-rank results.  Each rank contributes ``count`` unique alpha' rows
+    (``rows[:count]``), its per-belief ``index`` into them, ``actions`` and ``keep``; blocks are padded to
+    the largest count so one ``all_gather_into_tensor`` per array suffices.  Returns the concatenated
+    unique rows ``[sum U_r, S]``, the global index ``[B]`` (offset per rank), actions and keep in belief
+    order."""
+    import torch
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = rows.device
+    S = rows.shape[1]
+    per = index.shape[0]
+    cnt = torch.tensor([count], dtype=torch.int64, device=dev)
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, cnt, group=group)
+    counts_h = counts.tolist()
+    umax = max(max(counts_h), 1)
+    send = torch.zeros((umax, S), dtype=rows.dtype, device=dev)
+    send[:count] = rows[:count]
+    all_rows = torch.empty((world * umax, S), dtype=rows.dtype, device=dev)
+    all_idx = torch.empty((world * per,), dtype=index.dtype, device=dev)
+    all_act = torch.empty((world * per,), dtype=actions.dtype, device=dev)
+    all_keep = torch.empty((world * per,), dtype=keep.dtype, device=dev)
+    dist.all_gather_into_tensor(all_rows, send, group=group)
+    dist.all_gather_into_tensor(all_idx, index.contiguous(), group=group)
+    dist.all_gather_into_tensor(all_act, actions.contiguous(), group=group)
+    dist.all_gather_into_tensor(all_keep, keep.contiguous(), group=group)
+    offs = [0]
+    for c in counts_h[:-1]:
+        offs.append(offs[-1] + c)
+    uniq = torch.cat([all_rows[r * umax: r * umax + counts_h[r]] for r in range(world)], dim=0)
+    gidx = all_idx.view(world, per).to(torch.int64) + torch.tensor(offs, dtype=torch.int64, device=dev)[:, None]
+    return uniq, gidx.reshape(-1)[:n_total], all_act[:n_total], all_keep[:n_total]
+
+
 class EngineShard:
     """Per-rank adapter: HIP engine results copied device-to-device into torch CUDA
     tensors that RCCL can send (torch is only the carrier of device memory here)."""
@@ -93,15 +128,24 @@ class EngineShard:
             dt = t.float32 if self.engine.dtype == 'f32' else t.float64
             self._bufs = (t.empty((b, self.engine.S), dtype=dt, device=self.device),
                           t.empty((b,), dtype=t.int32, device=self.device),
-                          t.empty((b,), dtype=t.uint8, device=self.device))
+                          t.empty((b,), dtype=t.uint8, device=self.device),
+                          t.empty((b,), dtype=t.int32, device=self.device))
         return self._bufs
 
     def run_resident(self):
-        """Backup of the belief block already resident on this rank's engine."""
+        """Backup of the belief block already resident on this rank's engine; full per-belief rows."""
         stats = self.engine.run(self.gamma, self.prune)
-        rows, acts, keep = self.buffers(self.engine.B)
+        rows, acts, keep, _ = self.buffers(self.engine.B)
         self.engine.fetch_into(rows.data_ptr(), acts.data_ptr(), keep.data_ptr())
         return rows, acts, keep, stats
+
+    def run_resident_unique(self):
+        """Same, deduplicated: ``(rows[B,S] (first U valid), U, index[B], actions[B], keep[B], stats)``."""
+        stats = self.engine.run(self.gamma, self.prune)
+        rows, acts, keep, idx = self.buffers(self.engine.B)
+        self.engine.fetch_into(0, acts.data_ptr(), keep.data_ptr())
+        self.engine.fetch_unique_into(rows.data_ptr(), idx.data_ptr())
+        return rows, self.engine.unique_count, idx, acts, keep, stats
 
     def __call__(self, beliefs_local: np.ndarray):
         self.engine.set_beliefs(beliefs_local)

@@ -22,7 +22,8 @@ PBVI_BELIEF_DOMINANCE = 1
 EXPORTS = [
     'pbvi_version', 'pbvi_device_count', 'pbvi_last_error', 'pbvi_engine_create', 'pbvi_engine_destroy',
     'pbvi_alpha_set', 'pbvi_alpha_append', 'pbvi_alpha_count', 'pbvi_beliefs_set', 'pbvi_backup_run',
-    'pbvi_backup_fetch', 'pbvi_backup_device_results', 'pbvi_backup', 'pbvi_prune_dominated', 'pbvi_value_max',
+    'pbvi_backup_fetch', 'pbvi_backup_unique_count', 'pbvi_backup_fetch_unique', 'pbvi_backup_device_results',
+    'pbvi_backup', 'pbvi_prune_dominated', 'pbvi_value_max',
     'pbvi_set_tie_window', 'pbvi_device_bytes',
 ]
 
@@ -36,6 +37,7 @@ class PbviStats(C.Structure):
                 ('ms_argmax', C.c_double), ('ms_refine', C.c_double), ('ms_action', C.c_double),
                 ('ms_assemble', C.c_double), ('ms_dominance', C.c_double), ('n_pairs', C.c_int64),
                 ('n_dead', C.c_int64), ('n_refined', C.c_int64), ('n_refined_actions', C.c_int64),
+                ('n_unique', C.c_int64),
                 ('score_flops', C.c_int64), ('score_flops_executed', C.c_int64), ('score_tiles_dense', C.c_int64),
                 ('score_tiles_run', C.c_int64), ('project_flops', C.c_int64), ('project_flops_executed', C.c_int64),
                 ('split_k', C.c_int32), ('reserved', C.c_int32)]
@@ -73,6 +75,8 @@ def load_library(path: str = LIB_PATH):
         'pbvi_beliefs_set': (C.c_int, [vp, vp, C.c_int64]),
         'pbvi_backup_run': (C.c_int, [vp, C.c_double, C.c_int, sp]),
         'pbvi_backup_fetch': (C.c_int, [vp, vp, i32p, i32p, u8p]),
+        'pbvi_backup_unique_count': (C.c_int64, [vp]),
+        'pbvi_backup_fetch_unique': (C.c_int, [vp, vp, i32p]),
         'pbvi_backup_device_results': (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         'pbvi_backup': (C.c_int, [vp, vp, C.c_int64, C.c_double, C.c_int, vp, i32p, i32p, u8p, sp]),
         'pbvi_prune_dominated': (C.c_int, [vp, u8p]),
@@ -111,11 +115,28 @@ def _ptr(a: np.ndarray):
 
 @dataclass
 class BackupResult:
-    alpha: np.ndarray          # [B,S] engine dtype
-    actions: np.ndarray        # [B] int64
+    unique_alpha: np.ndarray    # [U,S] engine dtype: one alpha' row per distinct (a*, v*) key
+    index: np.ndarray           # [B] int64: alpha'[b] = unique_alpha[index[b]]
+    actions: np.ndarray         # [B] int64
     best_alpha_ind: np.ndarray  # [B,A,O] int64
-    keep: np.ndarray           # [B] bool
+    keep: np.ndarray            # [B] bool
     stats: dict
+
+    @property
+    def alpha(self) -> np.ndarray:
+        """Per-belief alpha' matrix [B,S] (what the reference computes before its dedup)."""
+        return self.unique_alpha[self.index]
+
+    def value_function_rows(self, use_keep: bool = False):
+        """``(rows, actions)`` to hand to ``ValueFunction``: one row per distinct key among the (kept)
+        beliefs, in order of first occurrence -- the order the reference's byte-dedup produces."""
+        idx = self.index[self.keep] if use_keep else self.index
+        act = self.actions[self.keep] if use_keep else self.actions
+        if idx.size == 0:
+            return self.unique_alpha[:0], act[:0]
+        first = np.unique(idx, return_index=True)[1]
+        first.sort()
+        return self.unique_alpha[idx[first]], act[first]
 
 
 class Engine:
@@ -206,17 +227,38 @@ class Engine:
                                          C.byref(st)))
         return st.as_dict()
 
-    def fetch(self, want_alpha: bool = True) -> BackupResult:
+    def fetch(self) -> BackupResult:
+        """Results of the last run: unique alpha' rows + per-belief index (the D2H copy moves U rows, not B)."""
         B = self.B
-        alpha = np.empty((B, self.S), dtype=self.np_dtype) if want_alpha else None
+        U = int(self._lib.pbvi_backup_unique_count(self._h))
+        if U < 0:
+            raise ValueError('no backup result resident')
+        rows = np.empty((U, self.S), dtype=self.np_dtype)
+        index = np.empty(B, dtype=np.int32)
         act = np.empty(B, dtype=np.int32)
         best = np.empty((B, self.A, self.O), dtype=np.int32)
         keep = np.empty(B, dtype=np.uint8)
-        _check(self._lib.pbvi_backup_fetch(self._h, _ptr(alpha) if want_alpha else None,
-                                           act.ctypes.data_as(C.POINTER(C.c_int32)),
+        _check(self._lib.pbvi_backup_fetch_unique(self._h, _ptr(rows), index.ctypes.data_as(C.POINTER(C.c_int32))))
+        _check(self._lib.pbvi_backup_fetch(self._h, None, act.ctypes.data_as(C.POINTER(C.c_int32)),
                                            best.ctypes.data_as(C.POINTER(C.c_int32)),
                                            keep.ctypes.data_as(C.POINTER(C.c_uint8))))
-        return BackupResult(alpha, act.astype(np.int64), best.astype(np.int64), keep.astype(bool), {})
+        return BackupResult(rows, index.astype(np.int64), act.astype(np.int64), best.astype(np.int64),
+                            keep.astype(bool), {})
+
+    def fetch_full(self) -> np.ndarray:
+        """Per-belief alpha' matrix [B,S] expanded on the device (``pbvi_backup_fetch``'s out_alpha)."""
+        alpha = np.empty((self.B, self.S), dtype=self.np_dtype)
+        _check(self._lib.pbvi_backup_fetch(self._h, _ptr(alpha), None, None, None))
+        return alpha
+
+    @property
+    def unique_count(self) -> int:
+        return int(self._lib.pbvi_backup_unique_count(self._h))
+
+    def fetch_unique_into(self, rows_ptr: int, index_ptr: int) -> None:
+        """Copy unique rows [U,S] / index [B] to raw (host or device) addresses."""
+        _check(self._lib.pbvi_backup_fetch_unique(self._h, C.c_void_p(rows_ptr) if rows_ptr else None,
+                                                  C.cast(index_ptr, C.POINTER(C.c_int32)) if index_ptr else None))
 
     def fetch_into(self, alpha_ptr: int, action_ptr: int, keep_ptr: int) -> None:
         """Copy the last run's alpha rows / actions / keep mask to raw addresses (host or
@@ -235,9 +277,10 @@ class Engine:
         return res
 
     def backup(self, alpha: np.ndarray, beliefs: np.ndarray, gamma: float, belief_dominance_prune: bool = False):
-        """``(alpha_new[B,S], actions[B], keep[B] or None)`` -- what ``PBVI_Solver.backup`` needs."""
+        """``(rows, actions)`` ready for ``ValueFunction(model, rows, actions)``: the new alpha-vectors of the
+        (dominating) beliefs, already reduced to one row per distinct key in first-occurrence order."""
         res = self.backup_full(alpha, beliefs, gamma, belief_dominance_prune)
-        return res.alpha, res.actions, (res.keep if belief_dominance_prune else None)
+        return res.value_function_rows(use_keep=belief_dominance_prune)
 
     def device_results(self):
         """Raw device addresses ``(alpha_ptr, action_ptr, keep_ptr)`` of the last run (for RCCL)."""

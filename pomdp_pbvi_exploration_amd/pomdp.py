@@ -297,10 +297,8 @@ class PBVI_Solver(Solver):
         alpha-vectors -> at most B new alpha-vectors (+ union with the old set)."""
         if value_function.is_on_gpu:
             eng = value_function.model.engine
-            alpha_new, actions, keep = eng.backup(value_function.alpha_vector_array, belief_set.belief_array,
-                                                  self.gamma, belief_dominance_prune=belief_dominance_prune)
-            if keep is not None:
-                alpha_new, actions = alpha_new[keep], actions[keep]
+            alpha_new, actions = eng.backup(value_function.alpha_vector_array, belief_set.belief_array,
+                                            self.gamma, belief_dominance_prune=belief_dominance_prune)
             new_vf = ValueFunction(value_function.model, alpha_new, actions)
         else:
             alpha_new, actions = self._backup_numpy(model, belief_set.belief_array, value_function.alpha_vector_array,

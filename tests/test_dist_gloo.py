@@ -68,3 +68,36 @@ def test_shard_bounds_cover_everything():
             spans = [shard_bounds(n, world, r) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def _worker_unique(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pomdp_pbvi_exploration_amd.dist import gather_unique
+        S, per = 7, 5
+        # rank r holds r+2 unique rows; beliefs index them cyclically
+        count = rank + 2
+        rows = torch.zeros((per, S), dtype=torch.float64)
+        rows[:count] = torch.arange(count, dtype=torch.float64)[:, None] + 100.0 * rank
+        idx = torch.arange(per, dtype=torch.int32) % count
+        acts = torch.full((per,), rank, dtype=torch.int32)
+        keep = torch.ones(per, dtype=torch.uint8)
+        uniq, gidx, a, k = gather_unique(dist, None, rows, count, idx, acts, keep, world * per - 1)
+        assert uniq.shape == (2 + 3, S) and gidx.shape == (world * per - 1,)
+        full = uniq[gidx]                                    # per-belief rows in global belief order
+        exp = torch.cat([(torch.arange(per) % (r + 2)).double() + 100.0 * r for r in range(world)])[: world * per - 1]
+        assert torch.equal(full[:, 0], exp)
+        assert a.tolist() == ([0] * per + [1] * per)[: world * per - 1] and bool(k.all())
+        open(os.path.join(out_dir, f'uok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_unique_world2(tmp_path):
+    """The dedup-aware exchange of bench.py --gpus N: ragged unique counts, offsets, trimmed tail."""
+    port = _free_port()
+    mp.spawn(_worker_unique, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / 'uok0') and os.path.exists(tmp_path / 'uok1')

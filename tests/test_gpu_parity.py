@@ -81,6 +81,33 @@ def test_dense_projection_mode(dtype):
     eng.close()
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_device_dedup_is_consistent_with_reference_dedup(dtype):
+    """K6: unique rows + index reproduce the per-belief matrix, and the rows handed to ValueFunction equal
+    the reference's byte-dedup result (first position, order of first occurrence) incl. the prune variant."""
+    z, rs, rto, er = small(1)
+    eng = Engine(600, 6, 3, 1, rs, rto, er, dtype=dtype)
+    res = eng.backup_full(z['alpha'], z['beliefs'], float(z['gamma']), belief_dominance_prune=True)
+    U = res.unique_alpha.shape[0]
+    assert U == res.stats['n_unique'] == eng.unique_count and 1 <= U <= 64
+    assert res.index.min() == 0 and res.index.max() == U - 1
+    full = eng.fetch_full()                                   # expanded on the device
+    assert np.array_equal(full, res.alpha)
+    # index[b] points at the first belief with b's key, so unique rows appear in first-occurrence order
+    first = np.array([np.flatnonzero(res.index == u)[0] for u in range(U)])
+    assert np.all(np.diff(first) > 0)
+    key = np.concatenate([res.actions[:, None], res.best_alpha_ind[np.arange(64), res.actions]], axis=1)
+    assert len({tuple(k) for k in key}) == U
+    # different keys may still give identical bytes: ValueFunction's byte dedup (oracle restatement) finishes the job
+    rows, acts = orc.dedup_rows(*res.value_function_rows(use_keep=False))
+    assert rows.shape == z['plain_alpha'].shape and np.array_equal(acts, z['plain_actions'])
+    assert_alpha_close(rows, z['plain_alpha'], F32_RTOL if dtype == 'f32' else F64_RTOL)
+    if dtype == 'f64':
+        rows, acts = orc.dedup_rows(*res.value_function_rows(use_keep=True))
+        assert rows.shape == z['prune_alpha'].shape and np.array_equal(acts, z['prune_actions'])
+    eng.close()
+
+
 def test_grid4x3_every_reference_call_f64():
     """BASELINE config 1: 4x3 grid, fp64, every backup call of the reference's seeded FSVI run."""
     z = load_npz('grid4x3_fsvi.npz')
