@@ -55,7 +55,8 @@ hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB
 // dead[b][ao] = 1 iff supp(b) and supp(RTO[:,a,o,:]) are disjoint (P(o|b,a) == 0 exactly)
 template <typename T>
 hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const uint8_t* nzB /* [A*O][k_tiles] */,
-                       int k_tiles, uint8_t* dead, hipStream_t st);
+                       int k_tiles, uint8_t* dead, int32_t* btl /* out: [B][k_tiles] non-zero tile lists */,
+                       int32_t* btc /* out: [B] list lengths */, hipStream_t st);
 
 // first-max argmax over the V columns [g*V, (g+1)*V) of each (row b, group g) of the score matrix;
 // column G*V + g holds the magnitude score (b . Gamma of the max|alpha| row) that scales the tie
@@ -70,7 +71,8 @@ hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dea
 template <typename T>
 hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entries, const int32_t* queue,
                          const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
-                         double gamma, int32_t* best_v, double* best_score, double* err, hipStream_t st);
+                         double gamma, const int32_t* btl, const int32_t* btc /* belief tile lists or nullptr */,
+                         int32_t* best_v, double* best_score, double* err, hipStream_t st);
 
 // K4: val[b][a] = b.ER[:,a] + sum_o best_score[b][a][o]; action = first max; near-ties queued
 // Gamma tail rows [A*O*V + A*O, +2A): ER[:,a] and |ER[:,a]|, so the score GEMM also yields b.ER[:,a]
@@ -82,8 +84,10 @@ hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0
                          int32_t* aqueue, int* aqcount, hipStream_t st);
 template <typename T>
 hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv, double gamma,
-                                const int32_t* aqueue, const int* aqcount, const double* rdot, const double* rdot_err,
-                                const int32_t* best_v, double* best_score, double* err, int32_t* action, hipStream_t st);
+                                const int32_t* btl, const int32_t* btc, const int32_t* aqueue, const int* aqcount,
+                                const double* rdot, const double* rdot_err, const int32_t* best_v,
+                                const double* best_score, const double* err, double* val_exact /* [B][A] scratch */,
+                                int32_t* action, hipStream_t st);
 
 // K3: out[u][s] = ER[s,a*] + sum_o gamma * sum_r rto[a*][o][r][s] * alpha[v*[b,a*,o]][rs[a*][r][s]], b = rows[u]
 // (rows/n_rows on the device: only the unique (a*, v*) keys are assembled; nullptr = every belief)

@@ -31,58 +31,64 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
-// Partial (this thread's share) of  sum_s b[s] * gamma * sum_r rto[a][o][r][s] * alpha_v[rs[a][r][s]]
-// in f64.  Four states per thread are in flight at once (independent load chains) because this
-// runs in latency-bound refinement kernels; b[s] = 0 terms are multiplied through, not branched.
+// Tile list of one belief: the K tiles (32 states) that hold belief mass; list == nullptr means every tile.
+struct TileList {
+    const int32_t* list;
+    int count;
+    __device__ __forceinline__ int at(int i) const { return list ? list[i] : i; }
+};
+
+// Partial (this thread's share) of  sum_s b[s] * gamma * sum_r rto[a][o][r][s] * alpha_v[rs[a][r][s]]  in f64,
+// over the belief's non-zero tiles only (zero tiles add exact zeros).  blockDim.x = 256 = 8 half-waves;
+// half-wave q takes list entries q, q+8, ...; four entries per half-wave are in flight at once with
+// unconditional loads (these dots run in latency-bound refinement kernels).
 template <typename T>
 __device__ __forceinline__ double proj_dot_partial(const T* __restrict__ brow, const T* __restrict__ arow,
-                                                   const ModelView<T>& mv, int a, int o, double gamma) {
+                                                   const ModelView<T>& mv, int a, int o, double gamma, TileList tl) {
     const int32_t* __restrict__ rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
     const T* __restrict__ rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
-    const int stride = blockDim.x;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    int s = threadIdx.x;
-    for (; s + 3 * stride < mv.S; s += 4 * stride) {
-        const double b0 = (double)brow[s], b1 = (double)brow[s + stride], b2 = (double)brow[s + 2 * stride],
-                     b3 = (double)brow[s + 3 * stride];
-        double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+    const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = q; i0 < tl.count; i0 += 32) {
+        int s[4];
+        double w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + 8 * j;
+            const bool ok = i < tl.count;
+            s[j] = tl.at(ok ? i : i0) * 32 + l;               // < S_pad; pads hold rs = 0, rto = 0, b = 0
+            w[j] = ok ? 1.0 : 0.0;
+        }
+        double g[4] = {0.0, 0.0, 0.0, 0.0};
         for (int r = 0; r < mv.R; ++r) {
             const int64_t ro = (int64_t)r * mv.S_pad;
-            const int i0 = rs[ro + s], i1 = rs[ro + s + stride], i2 = rs[ro + s + 2 * stride], i3 = rs[ro + s + 3 * stride];
-            const double w0 = (double)rto[ro + s], w1 = (double)rto[ro + s + stride], w2 = (double)rto[ro + s + 2 * stride],
-                         w3 = (double)rto[ro + s + 3 * stride];
-            g0 += w0 * (double)arow[i0];
-            g1 += w1 * (double)arow[i1];
-            g2 += w2 * (double)arow[i2];
-            g3 += w3 * (double)arow[i3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] += (double)rto[ro + s[j]] * (double)arow[rs[ro + s[j]]];
         }
-        acc0 += b0 * (gamma * g0);
-        acc1 += b1 * (gamma * g1);
-        acc2 += b2 * (gamma * g2);
-        acc3 += b3 * (gamma * g3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += w[j] * ((double)brow[s[j]] * (gamma * g[j]));
     }
-    for (; s < mv.S; s += stride) {
-        double g = 0.0;
-        for (int r = 0; r < mv.R; ++r)
-            g += (double)rto[(int64_t)r * mv.S_pad + s] * (double)arow[rs[(int64_t)r * mv.S_pad + s]];
-        acc0 += (double)brow[s] * (gamma * g);
-    }
-    return (acc0 + acc1) + (acc2 + acc3);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
+// brow must be padded to a multiple of 32 with zeros (engine belief rows are); arow valid for s < S.
 template <typename T>
-__device__ __forceinline__ double plain_dot_partial(const T* __restrict__ brow, const T* __restrict__ arow, int S) {
-    const int stride = blockDim.x;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    int s = threadIdx.x;
-    for (; s + 3 * stride < S; s += 4 * stride) {
-        acc0 += (double)brow[s] * (double)arow[s];
-        acc1 += (double)brow[s + stride] * (double)arow[s + stride];
-        acc2 += (double)brow[s + 2 * stride] * (double)arow[s + 2 * stride];
-        acc3 += (double)brow[s + 3 * stride] * (double)arow[s + 3 * stride];
+__device__ __forceinline__ double plain_dot_partial(const T* __restrict__ brow, const T* __restrict__ arow, int S,
+                                                    TileList tl) {
+    const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = q; i0 < tl.count; i0 += 32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + 8 * j;
+            const bool ok = i < tl.count;
+            int s = tl.at(ok ? i : i0) * 32 + l;
+            const bool in = ok && s < S;
+            s = s < S ? s : 0;
+            acc[j] += in ? (double)brow[s] * (double)arow[s] : 0.0;
+        }
     }
-    for (; s < S; s += stride) acc0 += (double)brow[s] * (double)arow[s];
-    return (acc0 + acc1) + (acc2 + acc3);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 // ------------------------------------------------------------------------- //
@@ -208,7 +214,7 @@ hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB
 // nzB are non-zero -- for the "goal" observation that is one tile instead of |S| states.
 template <typename T>
 __global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, const uint8_t* __restrict__ nzB,
-                       int k_tiles, uint8_t* __restrict__ dead) {
+                       int k_tiles, uint8_t* __restrict__ dead, int32_t* __restrict__ btl, int32_t* __restrict__ btc) {
     extern __shared__ uint8_t dsm[];
     uint8_t* tz = dsm;                                  // [k_tiles] belief has a non-zero in tile
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -229,6 +235,17 @@ __global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, cons
         if (kt < k_tiles && (tid & 7) == 0) tz[kt] = (uint8_t)f;
     }
     __syncthreads();
+    if (wid == 0) {   // compact list of this belief's non-zero tiles, kept for the refinement dots
+        int base = 0;
+        for (int kt0 = 0; kt0 < k_tiles; kt0 += 64) {
+            const int kt = kt0 + lane;
+            const int f = (kt < k_tiles) ? tz[kt] : 0;
+            const unsigned long long m = __ballot(f);
+            if (f) btl[(int64_t)b * k_tiles + base + __popcll(m & ((1ull << lane) - 1ull))] = kt;
+            base += __popcll(m);
+        }
+        if (lane == 0) btc[b] = base;
+    }
     for (int ao = wid; ao < AO; ao += 4) {                // one wave per (a,o)
         const uint8_t* zb = nzB + (int64_t)ao * k_tiles;
         const uint8_t* sp = mv.sup + (int64_t)ao * mv.S_pad;
@@ -249,9 +266,9 @@ __global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, cons
 
 template <typename T>
 hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const uint8_t* nzB, int k_tiles, uint8_t* dead,
-                       hipStream_t st) {
+                       int32_t* btl, int32_t* btc, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dead<T>, dim3(B), dim3(256), (size_t)k_tiles, st, bel, ldb, mv, nzB, k_tiles, dead);
+    hipLaunchKernelGGL(k_dead<T>, dim3(B), dim3(256), (size_t)k_tiles, st, bel, ldb, mv, nzB, k_tiles, dead, btl, btc);
     return hipGetLastError();
 }
 
@@ -345,7 +362,8 @@ template <typename T, bool PROJ>
 __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict__ queue,
                          const int* __restrict__ qcount,
                          const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
-                         ModelView<T> mv, double gamma, int32_t* __restrict__ best_v,
+                         ModelView<T> mv, double gamma, const int32_t* __restrict__ btl, const int32_t* __restrict__ btc,
+                         int32_t* __restrict__ best_v,
                          double* __restrict__ best_score, double* __restrict__ err) {
     __shared__ int cand[256];
     __shared__ int wcount[4];
@@ -359,6 +377,8 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
     const double thr = m - 2.0 * E;
     const int64_t col0 = (int64_t)g * V;
     const T* brow = bel + (int64_t)b * ldb;
+    const int k_tiles = mv.S_pad >> 5;
+    const TileList tl{btl ? btl + (int64_t)b * k_tiles : nullptr, btl ? btc[b] : k_tiles};
     double bestval = -std::numeric_limits<double>::infinity();
     int bestidx = -1;
     for (int v0 = 0; v0 < V; v0 += 256) {
@@ -377,8 +397,8 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
         for (int c = 0; c < ncand; ++c) {
             const int vv = cand[c];
             const T* arow = alpha + (int64_t)vv * lda;
-            const double part = PROJ ? proj_dot_partial(brow, arow, mv, a, o, gamma)
-                                     : plain_dot_partial(brow, arow, mv.S);
+            const double part = PROJ ? proj_dot_partial(brow, arow, mv, a, o, gamma, tl)
+                                     : plain_dot_partial(brow, arow, mv.S, tl);
             const double tot = block_sum(part, red);
             if (tot > bestval) {          // candidates ascend in v: first maximum wins
                 bestval = tot;
@@ -397,14 +417,15 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
 template <typename T>
 hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entries, const int32_t* queue,
                          const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
-                         double gamma, int32_t* best_v, double* best_score, double* err, hipStream_t st) {
+                         double gamma, const int32_t* btl, const int32_t* btc, int32_t* best_v, double* best_score,
+                         double* err, hipStream_t st) {
     if (max_entries <= 0) return hipSuccess;
     if (proj)
         hipLaunchKernelGGL((k_refine<T, true>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,
-                           alpha, lda, mv, gamma, best_v, best_score, err);
+                           alpha, lda, mv, gamma, btl, btc, best_v, best_score, err);
     else
         hipLaunchKernelGGL((k_refine<T, false>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel,
-                           ldb, alpha, lda, mv, gamma, best_v, best_score, err);
+                           ldb, alpha, lda, mv, gamma, btl, btc, best_v, best_score, err);
     return hipGetLastError();
 }
 
@@ -489,72 +510,84 @@ hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0
     return hipGetLastError();
 }
 
+// Exact (f64) value of every candidate action of a flagged belief: one block per (belief, action).
 template <typename T>
 __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
-                                ModelView<T> mv, double gamma, const int32_t* __restrict__ aqueue,
-                                const int* __restrict__ aqcount, const double* __restrict__ rdot,
-                                const double* __restrict__ rdot_err, const int32_t* __restrict__ best_v,
-                                double* __restrict__ best_score, double* __restrict__ err, int32_t* __restrict__ action) {
-    extern __shared__ double asm_[];
-    double* val = asm_;
-    double* Eb = asm_ + mv.A;
+                                ModelView<T> mv, double gamma, const int32_t* __restrict__ btl,
+                                const int32_t* __restrict__ btc, const int32_t* __restrict__ aqueue, const int* __restrict__ aqcount,
+                                const double* __restrict__ rdot, const double* __restrict__ rdot_err,
+                                const int32_t* __restrict__ best_v, const double* __restrict__ best_score,
+                                const double* __restrict__ err, double* __restrict__ val_exact) {
     __shared__ double red[4];
-    __shared__ double lo_sh;
+    __shared__ int cand_sh;
     if ((int)blockIdx.x >= *aqcount) return;
-    const int b = aqueue[blockIdx.x], tid = threadIdx.x;
-    const T* brow = bel + (int64_t)b * ldb;
-    if (tid == 0) {
-        double lo = -std::numeric_limits<double>::infinity();
-        for (int a = 0; a < mv.A; ++a) {
-            double v = rdot[(int64_t)b * mv.A + a], E = rdot_err[(int64_t)b * mv.A + a];
+    const int b = aqueue[blockIdx.x], a = blockIdx.y, tid = threadIdx.x;
+    if (tid == 0) {   // is action a within the error window of the best lower bound?
+        double lo = -std::numeric_limits<double>::infinity(), va = 0.0, Ea = 0.0;
+        for (int x = 0; x < mv.A; ++x) {
+            double v = rdot[(int64_t)b * mv.A + x], E = rdot_err[(int64_t)b * mv.A + x];
             for (int o = 0; o < mv.O; ++o) {
-                const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
+                const int64_t e = ((int64_t)b * mv.A + x) * mv.O + o;
                 v += best_score[e];
                 E += err[e];
             }
-            val[a] = v;
-            Eb[a] = E;
             lo = fmax(lo, v - E);
+            if (x == a) {
+                va = v;
+                Ea = E;
+            }
         }
-        lo_sh = lo;
+        cand_sh = (va + Ea >= lo) ? 1 : 0;
     }
     __syncthreads();
-    const double lo = lo_sh;
-    double bv = -std::numeric_limits<double>::infinity();
+    if (!cand_sh) {
+        if (tid == 0) val_exact[(int64_t)b * mv.A + a] = -std::numeric_limits<double>::infinity();
+        return;
+    }
+    const T* brow = bel + (int64_t)b * ldb;
+    const int k_tiles = mv.S_pad >> 5;
+    const TileList tl{btl ? btl + (int64_t)b * k_tiles : nullptr, btl ? btc[b] : k_tiles};
+    double v = block_sum(plain_dot_partial(brow, mv.er + (int64_t)a * mv.S_pad, mv.S, tl), red);
+    for (int o = 0; o < mv.O; ++o) {
+        const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
+        double sc = best_score[e];
+        if (err[e] > 0.0)                                       // block-uniform
+            sc = block_sum(proj_dot_partial(brow, alpha + (int64_t)best_v[e] * lda, mv, a, o, gamma, tl), red);
+        v += sc;
+    }
+    if (tid == 0) val_exact[(int64_t)b * mv.A + a] = v;
+}
+
+__global__ void k_action_final(int A, const int32_t* __restrict__ aqueue, const int* __restrict__ aqcount,
+                               const double* __restrict__ val_exact, int32_t* __restrict__ action) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= *aqcount) return;
+    const int b = aqueue[i];
     int best = 0;
-    for (int a = 0; a < mv.A; ++a) {
-        if (!(val[a] + Eb[a] >= lo)) continue;                 // block-uniform
-        // exact (f64) value of this candidate action: b.ER[:,a] + sum_o b.Gamma[a,o,v*[b,a,o],:]
-        double v = block_sum(plain_dot_partial(brow, mv.er + (int64_t)a * mv.S_pad, mv.S), red);
-        for (int o = 0; o < mv.O; ++o) {
-            const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
-            double sc = best_score[e];
-            if (err[e] > 0.0) {                                 // block-uniform
-                const T* arow = alpha + (int64_t)best_v[e] * lda;
-                sc = block_sum(proj_dot_partial(brow, arow, mv, a, o, gamma), red);
-                __syncthreads();
-                if (tid == 0) {
-                    best_score[e] = sc;
-                    err[e] = 0.0;
-                }
-            }
-            v += sc;
-        }
-        if (v > bv) {
+    double bv = -std::numeric_limits<double>::infinity();
+    for (int a = 0; a < A; ++a) {
+        const double v = val_exact[(int64_t)b * A + a];
+        if (v > bv) {                                           // first maximum among the candidates
             bv = v;
             best = a;
         }
     }
-    if (tid == 0) action[b] = best;
+    action[b] = best;
 }
 
 template <typename T>
 hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv, double gamma,
-                                const int32_t* aqueue, const int* aqcount, const double* rdot, const double* rdot_err,
-                                const int32_t* best_v, double* best_score, double* err, int32_t* action, hipStream_t st) {
+                                const int32_t* btl, const int32_t* btc, const int32_t* aqueue, const int* aqcount,
+                                const double* rdot, const double* rdot_err, const int32_t* best_v,
+                                const double* best_score, const double* err, double* val_exact, int32_t* action,
+                                hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_refine_action<T>, dim3(B), dim3(256), 2 * mv.A * sizeof(double), st, bel, ldb, alpha, lda, mv,
-                       gamma, aqueue, aqcount, rdot, rdot_err, best_v, best_score, err, action);
+    if (mv.A > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_refine_action<T>, dim3(B, mv.A), dim3(256), 0, st, bel, ldb, alpha, lda, mv, gamma, btl, btc,
+                       aqueue, aqcount, rdot, rdot_err, best_v, best_score, err, val_exact);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_action_final, dim3((B + 255) / 256), dim3(256), 0, st, mv.A, aqueue, aqcount, val_exact, action);
     return hipGetLastError();
 }
 
@@ -702,7 +735,8 @@ __global__ void k_keep(const T* __restrict__ bel, int ldb, const T* __restrict__
     __shared__ double red[4];
     const int b = blockIdx.x;                               // engine (possibly sorted) belief order
     const int c = perm ? perm[b] : b;                       // caller order
-    const double nv = block_sum(plain_dot_partial(bel + (int64_t)b * ldb, uniq_rows + (int64_t)inv[c] * ldo, S), red);
+    const double nv = block_sum(plain_dot_partial(bel + (int64_t)b * ldb, uniq_rows + (int64_t)inv[c] * ldo, S,
+                                                  TileList{nullptr, (S + 31) >> 5}), red);
     if (threadIdx.x == 0) keep[c] = (nv > oldmax[b]) ? 1 : 0;
 }
 
@@ -749,16 +783,19 @@ hipError_t launch_dominated(const T* alpha, int lda, int V, int S, int* cnt, hip
     template hipError_t launch_project<T>(const T*, int, int, ModelView<T>, T, T*, int, const uint8_t*, int,           \
                                           hipStream_t);                                                                \
     template hipError_t launch_tail_rows<T>(ModelView<T>, T*, int, hipStream_t);                                       \
-    template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const uint8_t*, int, uint8_t*, hipStream_t);  \
+    template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const uint8_t*, int, uint8_t*, int32_t*,      \
+                                       int32_t*, hipStream_t);                                                         \
     template hipError_t launch_argmax<T>(SlabView<T>, int, int, int, const uint8_t*, double, double, const int*, int,  \
                                          int32_t*, double*, double*, int32_t*, int*, hipStream_t);                     \
     template hipError_t launch_refine<T>(bool, SlabView<T>, int, int, int, const int32_t*, const int*, const T*, int,  \
-                                         const T*, int, ModelView<T>, double, int32_t*, double*, double*, hipStream_t); \
+                                         const T*, int, ModelView<T>, double, const int32_t*, const int32_t*,          \
+                                         int32_t*, double*, double*, hipStream_t);                                     \
     template hipError_t launch_action<T>(int, ModelView<T>, SlabView<T>, int64_t, double, const int*, const double*,   \
                                          const double*, double*, double*, int32_t*, int32_t*, int*, hipStream_t);      \
     template hipError_t launch_refine_action<T>(const T*, int, int, const T*, int, ModelView<T>, double,               \
-                                                const int32_t*, const int*, const double*, const double*,              \
-                                                const int32_t*, double*, double*, int32_t*, hipStream_t);              \
+                                                const int32_t*, const int32_t*, const int32_t*, const int*,            \
+                                                const double*, const double*, const int32_t*, const double*,           \
+                                                const double*, double*, int32_t*, hipStream_t);                        \
     template hipError_t launch_assemble<T>(const T*, int, ModelView<T>, double, const int32_t*, const int32_t*,        \
                                            const int32_t*, const int*, int, T*, int, hipStream_t);                     \
     template hipError_t launch_expand_rows<T>(const T*, const int32_t*, T*, int, int, hipStream_t);                    \

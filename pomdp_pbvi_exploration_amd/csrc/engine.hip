@@ -199,6 +199,7 @@ class EngineT : public EngineBase {
     DevBuf bv2_, bs2_, err2_, queue2_, prune_cnt_;
     DevBuf stage_, keys_, perm_, action_res_, best_res_;   // belief reordering (f32, B > 256)
     DevBuf rep_, uniq_, inv_, slot_, out_full_;            // K6 key dedup: out_ holds the unique rows
+    DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     const int32_t* res_action_ = nullptr;                  // results in caller order
     const int32_t* res_best_ = nullptr;
     int64_t res_unique_ = 0;
@@ -221,7 +222,7 @@ class EngineT : public EngineBase {
         DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
-                         &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_,
+                         &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
@@ -657,8 +658,8 @@ int EngineT<T>::value_max_device() {
                             bs2_.as<double>(), err2_.as<double>(), kF32 ? queue2_.as<int32_t>() : nullptr, qc, stream_));
     if (kF32)
         HIPCHK(launch_refine<T>(false, sv, (int)V_, 1, (int)B_, queue2_.as<int32_t>(), qc, bel_.as<T>(), S_pad_,
-                                alpha_.as<T>(), S_pad_, view(), 0.0, bv2_.as<int32_t>(), bs2_.as<double>(),
-                                err2_.as<double>(), stream_));
+                                alpha_.as<T>(), S_pad_, view(), 0.0, nullptr, nullptr, bv2_.as<int32_t>(),
+                                bs2_.as<double>(), err2_.as<double>(), stream_));
     return PBVI_OK;
 }
 
@@ -701,7 +702,13 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     const int k_tiles = S_pad_ / GEMM_BK;
     HIPCHK(hipEventRecord(ev_fork_, stream_));
     HIPCHK(hipStreamWaitEvent(side, ev_fork_, 0));
-    if (kF32) HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(), side));
+    if (kF32) {
+        if ((rc = btl_.ensure((size_t)B_ * k_tiles * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = btc_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = val_exact_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
+        HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(),
+                              btl_.as<int32_t>(), btc_.as<int32_t>(), side));
+    }
     HIPCHK(hipEventRecord(ev_join_, side));
     // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
     const uint8_t* need = nullptr;
@@ -744,8 +751,8 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     }
     if (kF32)
         HIPCHK(launch_refine<T>(true, sv, (int)V_, AO, (int)pairs, queue_.as<int32_t>(), qcount, bel_.as<T>(), S_pad_,
-                                alpha_.as<T>(), S_pad_, mv, gamma, best_v_.as<int32_t>(), best_score_.as<double>(),
-                                err_.as<double>(), stream_));
+                                alpha_.as<T>(), S_pad_, mv, gamma, btl_.as<int32_t>(), btc_.as<int32_t>(),
+                                best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), stream_));
     HIPCHK(hipEventRecord(ev_[4], stream_));
     // K4: action
     double* rdot_err = rdot_.as<double>() + (size_t)B_ * A_;
@@ -754,8 +761,10 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
                             kF32 ? aqueue_.as<int32_t>() : nullptr, aqcount, stream_));
     if (kF32)
         HIPCHK(launch_refine_action<T>(bel_.as<T>(), S_pad_, (int)B_, alpha_.as<T>(), S_pad_, mv, gamma,
+                                       btl_.as<int32_t>(), btc_.as<int32_t>(),
                                        aqueue_.as<int32_t>(), aqcount, rdot_.as<double>(), rdot_err, best_v_.as<int32_t>(),
-                                       best_score_.as<double>(), err_.as<double>(), action_.as<int32_t>(), stream_));
+                                       best_score_.as<double>(), err_.as<double>(), val_exact_.as<double>(),
+                                       action_.as<int32_t>(), stream_));
     HIPCHK(hipEventRecord(ev_[5], stream_));
     // results to the caller's belief order, then K6: dedup by (a*, v*) key
     const int32_t* perm = sorted_ ? perm_.as<int32_t>() : nullptr;
