@@ -151,6 +151,7 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
             for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = T4{T(0), T(0), T(0), T(0)};
         for (int r = 0; r < mv.R; ++r) {
             const I4 idx = *(const I4*)(mv.rs + ((int64_t)a * mv.R + r) * mv.S_pad + s);
+            const bool contig = (idx[1] == idx[0] + 1) && (idx[2] == idx[0] + 2) && (idx[3] == idx[0] + 3);
             T4 w[4];
 #pragma unroll
             for (int oj = 0; oj < 4; ++oj)
@@ -160,7 +161,15 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
             for (int vj = 0; vj < 4; ++vj) {
                 if (vj < nv) {
                     const T* arow = alpha + (int64_t)(v0 + vj) * lda;
-                    const T4 av = T4{arow[idx[0]], arow[idx[1]], arow[idx[2]], arow[idx[3]]};
+                    // successors of consecutive states are usually consecutive (grid moves): one 16-byte
+                    // (dword-aligned) load instead of four gathers
+                    T4 av;
+                    if (contig) {
+                        const T* p = arow + idx[0];
+                        av = T4{p[0], p[1], p[2], p[3]};
+                    } else {
+                        av = T4{arow[idx[0]], arow[idx[1]], arow[idx[2]], arow[idx[3]]};
+                    }
 #pragma unroll
                     for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = acc[vj][oj] + w[oj] * av;
                 }
