@@ -172,3 +172,21 @@ def test_synth_generator_is_deterministic():
     np.testing.assert_allclose(b.sum(axis=1), 1.0, atol=1e-6)
     # R=5 rows are proper distributions over five distinct successors
     assert all(len(set(row)) == 5 for row in m1.reachable_states.reshape(-1, 5)[:50])
+
+
+def test_backup_result_rows_for_value_function():
+    """engine.BackupResult -> rows handed to ValueFunction: one row per distinct key among the kept beliefs,
+    in first-occurrence order (what the reference's byte-dedup dict produces)."""
+    from pomdp_pbvi_exploration_amd.engine import BackupResult
+    uniq = np.array([[1., 1.], [2., 2.], [3., 3.]])
+    index = np.array([0, 1, 0, 2, 1])
+    res = BackupResult(uniq, index, np.array([5, 6, 5, 7, 6]), np.zeros((5, 1, 1), dtype=np.int64),
+                       np.array([False, True, True, False, True]), {})
+    assert res.alpha.tolist() == [[1., 1.], [2., 2.], [1., 1.], [3., 3.], [2., 2.]]
+    rows, acts = res.value_function_rows(use_keep=False)
+    assert rows.tolist() == [[1., 1.], [2., 2.], [3., 3.]] and acts.tolist() == [5, 6, 7]
+    rows, acts = res.value_function_rows(use_keep=True)        # kept beliefs 1,2,4 -> keys 1,0,1
+    assert rows.tolist() == [[2., 2.], [1., 1.]] and acts.tolist() == [6, 5]
+    res.keep[:] = False
+    rows, acts = res.value_function_rows(use_keep=True)
+    assert rows.shape == (0, 2) and acts.shape == (0,)
