@@ -112,6 +112,23 @@ int64_t pbvi_alpha_count(const pbvi_engine_t* e);
 int pbvi_beliefs_set(pbvi_engine_t* e, const void* beliefs, int64_t B);
 
 /*
+ * Device row stores.  The reference keeps every alpha-vector / belief on the GPU as its own CuPy array and
+ * re-stacks them into a matrix on demand (ValueFunction.alpha_vector_array, src/mdp.py:687-697 -- an
+ * O(V*S) copy after every extend; BeliefSet.belief_array, src/pomdp.py:541-550).  Here a row is uploaded
+ * once (store_append returns the id of the first appended row, ids are consecutive) and the working
+ * alpha set / belief block is then SELECTED by id, in the caller's order, entirely on the device.  The
+ * order matters: argmax ties go to the lowest index, and ValueFunction.extend puts new vectors first
+ * (src/mdp.py:773-774), so the selection must follow the host list order, not the upload order.
+ * store_reset forgets all stored rows (ids restart at 0).
+ */
+int64_t pbvi_alpha_store_append(pbvi_engine_t* e, const void* rows /* [n][S] T */, int64_t n);
+int pbvi_alpha_select(pbvi_engine_t* e, const int32_t* ids /* [V] */, int64_t V);
+int pbvi_alpha_store_reset(pbvi_engine_t* e);
+int64_t pbvi_belief_store_append(pbvi_engine_t* e, const void* rows /* [n][S] T */, int64_t n);
+int pbvi_beliefs_select(pbvi_engine_t* e, const int32_t* ids /* [B] */, int64_t B);
+int pbvi_belief_store_reset(pbvi_engine_t* e);
+
+/*
  * One point-based backup on the resident alpha set and belief block
  * (src/pomdp.py:1485-1515).  Results stay on the device until fetched.
  */

@@ -177,6 +177,9 @@ class EngineBase {
     virtual int value_max(double* out_value, int32_t* out_index) = 0;
     virtual int set_tie_window(double rel) = 0;
     virtual int64_t device_bytes() const = 0;
+    virtual int64_t store_append(int which, const void* rows, int64_t n) = 0;
+    virtual int store_select(int which, const int32_t* ids, int64_t n) = 0;
+    virtual int store_reset(int which) = 0;
 };
 
 template <typename T>
@@ -199,6 +202,8 @@ class EngineT : public EngineBase {
     DevBuf bv2_, bs2_, err2_, queue2_, prune_cnt_;
     DevBuf stage_, keys_, perm_, action_res_, best_res_;   // belief reordering (f32, B > 256)
     DevBuf rep_, uniq_, inv_, slot_, out_full_;            // K6 key dedup: out_ holds the unique rows
+    DevBuf store_[2], ids_;                                // device row stores: [0] alpha-vectors, [1] beliefs
+    int64_t store_rows_[2] = {0, 0};
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     const int32_t* res_action_ = nullptr;                  // results in caller order
     const int32_t* res_best_ = nullptr;
@@ -222,7 +227,7 @@ class EngineT : public EngineBase {
         DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
-                         &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_,
+                         &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
@@ -392,10 +397,9 @@ class EngineT : public EngineBase {
 
     int64_t alpha_count() const override { return V_; }
 
-    int beliefs_set(const void* bel, int64_t B) override {
-        if (B <= 0 || bel == nullptr) FAIL(PBVI_EINVAL, "beliefs_set: need B > 0 and a non-null array");
-        if (B > 65535) FAIL(PBVI_EUNSUPPORTED, "beliefs_set: at most 65535 beliefs per block");
-        HIPCHK(hipSetDevice(device_));
+    // Belief block from rows staged on the device (stage_ [B][S_pad]): optional reordering, padding to the
+    // GEMM's 256-row blocks, non-zero tile map.
+    int beliefs_finish(int64_t B) {
         const int64_t Bp = round_up(B, GEMM_BM);
         int rc = bel_.ensure((size_t)Bp * S_pad_ * sizeof(T), &bytes_);
         if (rc) return rc;
@@ -403,12 +407,8 @@ class EngineT : public EngineBase {
         static const bool no_sort = getenv("PBVI_NO_BELIEF_SORT") != nullptr;     // debug / A-B only
         sorted_ = kF32 && B > GEMM_BM && !no_sort;
         if (sorted_) {
-            if ((rc = stage_.ensure((size_t)B * S_pad_ * sizeof(T), &bytes_))) return rc;
             if ((rc = keys_.ensure((size_t)B * sizeof(int32_t), &bytes_))) return rc;
             if ((rc = perm_.ensure((size_t)B * sizeof(int32_t), &bytes_))) return rc;
-            HIPCHK(hipMemsetAsync(stage_.p, 0, (size_t)B * S_pad_ * sizeof(T), stream_));
-            HIPCHK(hipMemcpy2DAsync(stage_.p, (size_t)S_pad_ * sizeof(T), bel, (size_t)S_ * sizeof(T),
-                                    (size_t)S_ * sizeof(T), (size_t)B, hipMemcpyHostToDevice, stream_));
             hipLaunchKernelGGL(k_first_tile<T>, dim3((unsigned)B), dim3(256), 0, stream_, stage_.as<T>(), S_pad_, S_,
                                keys_.as<int32_t>());
             HIPCHK(hipGetLastError());
@@ -423,8 +423,7 @@ class EngineT : public EngineBase {
                                stage_.as<T>(), bel_.as<T>(), S_pad_, perm_.as<int32_t>());
             HIPCHK(hipGetLastError());
         } else {
-            HIPCHK(hipMemcpy2DAsync(bel_.p, (size_t)S_pad_ * sizeof(T), bel, (size_t)S_ * sizeof(T),
-                                    (size_t)S_ * sizeof(T), (size_t)B, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(bel_.p, stage_.p, (size_t)B * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
         }
         if (kF32) {   // which 256x32 belief tiles hold a non-zero (A-operand side of zero-tile skipping)
             const int k_tiles = S_pad_ / GEMM_BK;
@@ -436,6 +435,86 @@ class EngineT : public EngineBase {
         B_pad_ = Bp;
         have_result_ = false;
         return PBVI_OK;
+    }
+
+    int beliefs_set(const void* bel, int64_t B) override {
+        if (B <= 0 || bel == nullptr) FAIL(PBVI_EINVAL, "beliefs_set: need B > 0 and a non-null array");
+        if (B > 65535) FAIL(PBVI_EUNSUPPORTED, "beliefs_set: at most 65535 beliefs per block");
+        HIPCHK(hipSetDevice(device_));
+        int rc = stage_.ensure((size_t)B * S_pad_ * sizeof(T), &bytes_);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(stage_.p, 0, (size_t)B * S_pad_ * sizeof(T), stream_));
+        HIPCHK(hipMemcpy2DAsync(stage_.p, (size_t)S_pad_ * sizeof(T), bel, (size_t)S_ * sizeof(T), (size_t)S_ * sizeof(T),
+                                (size_t)B, hipMemcpyHostToDevice, stream_));
+        return beliefs_finish(B);
+    }
+
+    // ---- device row stores ------------------------------------------------ //
+    int64_t store_append(int which, const void* rows, int64_t n) override {
+        if (which < 0 || which > 1 || n < 0 || (n > 0 && rows == nullptr)) FAIL(PBVI_EINVAL, "store_append: bad arguments");
+        if (hipSetDevice(device_) != hipSuccess) FAIL(PBVI_ERUNTIME, "hipSetDevice failed");
+        DevBuf& st = store_[which];
+        const int64_t have = store_rows_[which];
+        const size_t need = (size_t)(have + n) * S_pad_ * sizeof(T);
+        if (need > st.cap) {   // grow geometrically, keep the stored rows
+            DevBuf nb;
+            int rc = nb.ensure(std::max(need, st.cap * 2), &bytes_);
+            if (rc) return rc;
+            if (have > 0 && hipMemcpyAsync(nb.p, st.p, (size_t)have * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_) != hipSuccess)
+                FAIL(PBVI_ERUNTIME, "store_append: device copy failed");
+            if (hipStreamSynchronize(stream_) != hipSuccess) FAIL(PBVI_ERUNTIME, "store_append: sync failed");
+            bytes_ -= (int64_t)st.cap;
+            st.release();
+            st = nb;
+        }
+        if (n > 0) {
+            T* dst = st.as<T>() + (size_t)have * S_pad_;
+            if (hipMemsetAsync(dst, 0, (size_t)n * S_pad_ * sizeof(T), stream_) != hipSuccess ||
+                hipMemcpy2DAsync(dst, (size_t)S_pad_ * sizeof(T), rows, (size_t)S_ * sizeof(T), (size_t)S_ * sizeof(T),
+                                 (size_t)n, hipMemcpyHostToDevice, stream_) != hipSuccess ||
+                hipStreamSynchronize(stream_) != hipSuccess)
+                FAIL(PBVI_ERUNTIME, "store_append: upload failed");
+        }
+        store_rows_[which] = have + n;
+        return have;
+    }
+
+    int store_reset(int which) override {
+        if (which < 0 || which > 1) FAIL(PBVI_EINVAL, "store_reset: bad store");
+        store_rows_[which] = 0;
+        return PBVI_OK;
+    }
+
+    int store_select(int which, const int32_t* ids, int64_t n) override {
+        if (which < 0 || which > 1 || n <= 0 || ids == nullptr) FAIL(PBVI_EINVAL, "store_select: bad arguments");
+        if (n > 65535 && which == 1) FAIL(PBVI_EUNSUPPORTED, "at most 65535 beliefs per block");
+        for (int64_t i = 0; i < n; ++i)
+            if (ids[i] < 0 || ids[i] >= store_rows_[which]) FAIL(PBVI_EINVAL, "store_select: id out of range");
+        HIPCHK(hipSetDevice(device_));
+        int rc = ids_.ensure((size_t)n * sizeof(int32_t), &bytes_);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ids_.p, ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        if (which == 0) {   // working alpha set := stored rows in the caller's order
+            const size_t rows = alpha_rows_cap(n);
+            if ((rc = alpha_.ensure(rows * S_pad_ * sizeof(T), &bytes_))) return rc;
+            HIPCHK(hipMemsetAsync(alpha_.as<T>() + (size_t)n * S_pad_, 0, (rows - (size_t)n) * S_pad_ * sizeof(T), stream_));
+            for (int64_t r0 = 0; r0 < n; r0 += 65535) {
+                const unsigned cnt = (unsigned)std::min<int64_t>(65535, n - r0);
+                hipLaunchKernelGGL(k_gather_rows<T>, dim3((S_pad_ + 255) / 256, cnt), dim3(256), 0, stream_,
+                                   store_[0].as<T>(), alpha_.as<T>() + (size_t)r0 * S_pad_, S_pad_, ids_.as<int32_t>() + r0);
+                HIPCHK(hipGetLastError());
+            }
+            V_ = n;
+            if ((rc = refresh_magnitude_row())) return rc;
+            HIPCHK(hipStreamSynchronize(stream_));
+            have_result_ = false;
+            return PBVI_OK;
+        }
+        if ((rc = stage_.ensure((size_t)n * S_pad_ * sizeof(T), &bytes_))) return rc;
+        hipLaunchKernelGGL(k_gather_rows<T>, dim3((S_pad_ + 255) / 256, (unsigned)n), dim3(256), 0, stream_,
+                           store_[1].as<T>(), stage_.as<T>(), S_pad_, ids_.as<int32_t>());
+        HIPCHK(hipGetLastError());
+        return beliefs_finish(n);
     }
 
     // device pointer to the stream-K share size (K-tile steps of the longest f32 chain) or nullptr
@@ -986,6 +1065,30 @@ int pbvi_prune_dominated(pbvi_engine_t* e, uint8_t* keep) {
 int pbvi_value_max(pbvi_engine_t* e, double* out_value, int32_t* out_index) {
     NEED(e);
     return e->impl->value_max(out_value, out_index);
+}
+int64_t pbvi_alpha_store_append(pbvi_engine_t* e, const void* rows, int64_t n) {
+    NEED(e);
+    return e->impl->store_append(0, rows, n);
+}
+int pbvi_alpha_select(pbvi_engine_t* e, const int32_t* ids, int64_t V) {
+    NEED(e);
+    return e->impl->store_select(0, ids, V);
+}
+int pbvi_alpha_store_reset(pbvi_engine_t* e) {
+    NEED(e);
+    return e->impl->store_reset(0);
+}
+int64_t pbvi_belief_store_append(pbvi_engine_t* e, const void* rows, int64_t n) {
+    NEED(e);
+    return e->impl->store_append(1, rows, n);
+}
+int pbvi_beliefs_select(pbvi_engine_t* e, const int32_t* ids, int64_t B) {
+    NEED(e);
+    return e->impl->store_select(1, ids, B);
+}
+int pbvi_belief_store_reset(pbvi_engine_t* e) {
+    NEED(e);
+    return e->impl->store_reset(1);
 }
 int pbvi_set_tie_window(pbvi_engine_t* e, double rel) {
     NEED(e);

@@ -25,6 +25,8 @@ EXPORTS = [
     'pbvi_backup_fetch', 'pbvi_backup_unique_count', 'pbvi_backup_fetch_unique', 'pbvi_backup_device_results',
     'pbvi_backup', 'pbvi_prune_dominated', 'pbvi_value_max',
     'pbvi_set_tie_window', 'pbvi_device_bytes',
+    'pbvi_alpha_store_append', 'pbvi_alpha_select', 'pbvi_alpha_store_reset',
+    'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset',
 ]
 
 
@@ -81,6 +83,12 @@ def load_library(path: str = LIB_PATH):
         'pbvi_backup': (C.c_int, [vp, vp, C.c_int64, C.c_double, C.c_int, vp, i32p, i32p, u8p, sp]),
         'pbvi_prune_dominated': (C.c_int, [vp, u8p]),
         'pbvi_value_max': (C.c_int, [vp, f64p, i32p]),
+        'pbvi_alpha_store_append': (C.c_int64, [vp, vp, C.c_int64]),
+        'pbvi_alpha_select': (C.c_int, [vp, i32p, C.c_int64]),
+        'pbvi_alpha_store_reset': (C.c_int, [vp]),
+        'pbvi_belief_store_append': (C.c_int64, [vp, vp, C.c_int64]),
+        'pbvi_beliefs_select': (C.c_int, [vp, i32p, C.c_int64]),
+        'pbvi_belief_store_reset': (C.c_int, [vp]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -167,6 +175,7 @@ class Engine:
                                       PBVI_SPARSE if mode == 'sparse' else PBVI_DENSE))
         self._lib = lib
         self._alpha_token = None
+        self._store_epoch = {'alpha': 0, 'belief': 0}
         self.B = 0
 
     @classmethod
@@ -212,6 +221,51 @@ class Engine:
         b = self._as_rows(beliefs)
         _check(self._lib.pbvi_beliefs_set(self._h, _ptr(b), b.shape[0]))
         self.B = b.shape[0]
+
+    # -- device row stores: upload once, select by id in host order ------- #
+    def store_rows(self, which: str, rows: np.ndarray) -> int:
+        """Append ``rows`` [n,S] to the alpha ('alpha') or belief ('belief') store; returns the first id."""
+        a = self._as_rows(rows)
+        fn = self._lib.pbvi_alpha_store_append if which == 'alpha' else self._lib.pbvi_belief_store_append
+        first = int(fn(self._h, _ptr(a), a.shape[0]))
+        if first < 0:
+            _check(first)
+        return first
+
+    def select_alpha(self, ids) -> None:
+        i = np.ascontiguousarray(ids, dtype=np.int32)
+        _check(self._lib.pbvi_alpha_select(self._h, i.ctypes.data_as(C.POINTER(C.c_int32)), i.shape[0]))
+
+    def select_beliefs(self, ids) -> None:
+        i = np.ascontiguousarray(ids, dtype=np.int32)
+        _check(self._lib.pbvi_beliefs_select(self._h, i.ctypes.data_as(C.POINTER(C.c_int32)), i.shape[0]))
+        self.B = i.shape[0]
+
+    def reset_store(self, which: str) -> None:
+        _check((self._lib.pbvi_alpha_store_reset if which == 'alpha' else self._lib.pbvi_belief_store_reset)(self._h))
+        self._store_epoch[which] += 1
+
+    def sync_rows(self, which: str, objects, values_of) -> None:
+        """Make ``objects`` (AlphaVector / Belief instances, in list order) the working set: rows not yet in
+        this engine's store are uploaded in one batch, then the set is selected by id.  The id lives on the
+        object (``_dev``), tagged with this engine and the store epoch."""
+        tag = (id(self), which, self._store_epoch[which])
+        missing = [o for o in objects if getattr(o, '_dev', (None, -1))[0] != tag]
+        if missing:
+            # the same object may appear twice in a list: upload it once
+            seen, todo = set(), []
+            for o in missing:
+                if id(o) not in seen:
+                    seen.add(id(o))
+                    todo.append(o)
+            first = self.store_rows(which, np.stack([np.asarray(values_of(o)) for o in todo]))
+            for k, o in enumerate(todo):
+                o._dev = (tag, first + k)
+        ids = np.fromiter((o._dev[1] for o in objects), dtype=np.int32, count=len(objects))
+        if which == 'alpha':
+            self.select_alpha(ids)
+        else:
+            self.select_beliefs(ids)
 
     def _ensure_alpha(self, alpha: np.ndarray) -> None:
         """Make ``alpha`` the resident set.  Always uploads: array identity is not a safe
@@ -299,6 +353,10 @@ class Engine:
         """``(max_v b.alpha_v [B] f64, argmax [B])`` (compute_change, ``src/pomdp.py:2165``)."""
         self._ensure_alpha(alpha)
         self.set_beliefs(beliefs)
+        return self.max_value_resident()
+
+    def max_value_resident(self):
+        """Same, for the working alpha set / belief block already selected on the device."""
         val = np.empty(self.B, dtype=np.float64)
         idx = np.empty(self.B, dtype=np.int32)
         _check(self._lib.pbvi_value_max(self._h, val.ctypes.data_as(C.POINTER(C.c_double)),

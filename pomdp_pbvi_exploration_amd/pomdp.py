@@ -296,9 +296,14 @@ class PBVI_Solver(Solver):
         """One point-based backup (``src/pomdp.py:1447-1524``): B beliefs x V
         alpha-vectors -> at most B new alpha-vectors (+ union with the old set)."""
         if value_function.is_on_gpu:
+            # Residency: every AlphaVector / Belief row is uploaded once into the engine's device stores; the
+            # working sets are selected by id in list order (tie-breaks follow the host order), the device
+            # runs the backup, and only the distinct new rows come back.
             eng = value_function.model.engine
-            alpha_new, actions = eng.backup(value_function.alpha_vector_array, belief_set.belief_array,
-                                            self.gamma, belief_dominance_prune=belief_dominance_prune)
+            eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values)
+            eng.sync_rows('belief', belief_set.belief_list, lambda b: b.values)
+            eng.run(self.gamma, belief_dominance_prune)
+            alpha_new, actions = eng.fetch().value_function_rows(use_keep=belief_dominance_prune)
             new_vf = ValueFunction(value_function.model, alpha_new, actions)
         else:
             alpha_new, actions = self._backup_numpy(model, belief_set.belief_array, value_function.alpha_vector_array,
@@ -464,8 +469,11 @@ class PBVI_Solver(Solver):
         b = belief_set.belief_array
         if value_function.is_on_gpu:
             eng = value_function.model.engine
-            old = eng.max_value(value_function.alpha_vector_array, b)[0]
-            new = eng.max_value(new_value_function.alpha_vector_array, b)[0]
+            eng.sync_rows('belief', belief_set.belief_list, lambda x: x.values)
+            eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values)
+            old = eng.max_value_resident()[0]
+            eng.sync_rows('alpha', new_value_function.alpha_vector_list, lambda v: v.values)
+            new = eng.max_value_resident()[0]
         else:
             old = np.max(np.matmul(b, value_function.alpha_vector_array.T), axis=1)
             new = np.max(np.matmul(b, new_value_function.alpha_vector_array.T), axis=1)

@@ -320,3 +320,54 @@ def test_full_size_against_reference_summary(R):
     sc = eng.backup_full(alpha * 2.0, beliefs, m.gamma)                                                           # scaling by 2 is exact
     assert np.array_equal(sc.best_alpha_ind, res.best_alpha_ind)
     eng.close()
+
+
+def test_row_stores_select_in_host_order():
+    """Device row stores: rows uploaded once, working sets selected by id in the caller's order.  The
+    selection order decides argmax ties (lowest index wins), exactly as a re-uploaded matrix would."""
+    z, rs, rto, er = small(5)
+    eng = Engine(600, 6, 3, 5, rs, rto, er, dtype='f32')
+    alpha, b, g = z['alpha'].astype(np.float64), z['beliefs'].astype(np.float64), float(z['gamma'])
+    a0 = eng.store_rows('alpha', alpha[:30])
+    a1 = eng.store_rows('alpha', alpha[30:])
+    b0 = eng.store_rows('belief', b)
+    assert (a0, a1, b0) == (0, 30, 0)
+    # host order: the later-uploaded block first (ValueFunction.extend puts new vectors first), plus a duplicate
+    order = np.concatenate([np.arange(30, 48), np.arange(0, 30), [35]])
+    eng.select_alpha(order)
+    eng.select_beliefs(np.arange(64)[::-1])
+    eng.run(g)
+    res = eng.fetch()
+    ref = eng.backup_full(alpha[order], b[::-1], g)               # same sets, re-uploaded the plain way
+    assert np.array_equal(res.best_alpha_ind, ref.best_alpha_ind) and np.array_equal(res.actions, ref.actions)
+    assert np.array_equal(res.alpha, ref.alpha)
+    new, act, best = orc.backup_core(alpha[order], b[::-1], rs, rto, er, g)
+    assert np.array_equal(res.best_alpha_ind, best) and np.array_equal(res.actions, act)
+    assert not np.any(res.best_alpha_ind == 48)                    # the duplicate (last position) never wins a tie
+    val, idx = eng.max_value_resident()
+    np.testing.assert_allclose(val, orc.max_value_per_belief(alpha[order], b[::-1]), rtol=1e-12)
+    with pytest.raises(ValueError):
+        eng.select_alpha([0, 999])
+    eng.reset_store('alpha')
+    assert eng.store_rows('alpha', alpha[:2]) == 0
+    eng.close()
+
+
+def test_solver_loop_on_gpu_keeps_rows_resident():
+    """FSVI on the 4x3 grid through the Python API with use_gpu=True: every backup goes through the row
+    stores; the trajectory equals the host NumPy path's (same seeds)."""
+    import random
+    from pomdp_pbvi_exploration_amd import FSVI_Solver
+    z = load_npz('grid4x3_fsvi.npz')
+    results = []
+    for use_gpu in (False, True):
+        model, _ = load_POMDP_file(os.path.join(GOLDEN, 'models', '4x3.95-no_loop_2_grid.POMDP'))
+        model.end_states = [3, 6]
+        np.random.seed(0)
+        random.seed(0)
+        vf, hist = FSVI_Solver(gamma=0.95, eps=1e-6).solve(model, expansions=10, max_belief_growth=10, use_gpu=use_gpu,
+                                                           print_progress=False)
+        results.append((hist.alpha_vector_counts, np.asarray(vf.alpha_vector_array, dtype=np.float64), np.asarray(vf.actions)))
+    assert results[0][0] == results[1][0] == list(z['alpha_counts'])
+    np.testing.assert_allclose(results[1][1], results[0][1], rtol=1e-10, atol=1e-12)
+    assert np.array_equal(results[0][2], results[1][2])
