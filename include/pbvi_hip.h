@@ -191,6 +191,11 @@ int pbvi_value_max(pbvi_engine_t* e, double* out_value, int32_t* out_index);
  * argmax to fp64 refinement (<= 0 restores the default derived from |S|). */
 int pbvi_set_tie_window(pbvi_engine_t* e, double rel);
 
+/* Debug aid for tests: when enabled (or PBVI_POISON is set in the environment) every fresh device
+ * allocation is filled with 0xFF bytes (NaN floats, -1 indices), so a read of memory the engine never
+ * wrote fails the parity tests instead of hiding behind zero-filled pages.  Returns the previous state. */
+int pbvi_debug_poison(int enable);
+
 /* Bytes of device memory currently held by the handle. */
 int64_t pbvi_device_bytes(const pbvi_engine_t* e);
 

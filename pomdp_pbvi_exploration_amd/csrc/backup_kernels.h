@@ -49,8 +49,8 @@ hipError_t launch_support(ModelView<T> mv, uint8_t* sup, hipStream_t st);
 template <typename T>
 hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg,
                           const uint8_t* need /* [A*O][k_tiles] or nullptr = all */, int k_tiles, hipStream_t st);
-hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB, int AO, int k_tiles, uint8_t* need,
-                             hipStream_t st);
+hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB /* [AO+1][k_tiles] */, int AO, int V,
+                             int k_tiles, uint8_t* need, hipStream_t st);
 
 // dead[b][ao] = 1 iff supp(b) and supp(RTO[:,a,o,:]) are disjoint (P(o|b,a) == 0 exactly)
 template <typename T>

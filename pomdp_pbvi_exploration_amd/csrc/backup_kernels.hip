@@ -135,8 +135,8 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
         // Gamma tiles the score GEMM never reads (no RTO support, or no belief mass in any row
         // block) are not computed or written: `need` is exactly the GEMM's tile-list criterion.
         bool want[4] = {true, true, true, true};
-        if (need != nullptr) {
-            bool any = false;
+        if (need != nullptr && v0 + nv < V) {              // the magnitude row (last of the V rows) is always written:
+            bool any = false;                               // the tail tile it lives in is listed for every group's support
 #pragma unroll
             for (int oj = 0; oj < 4; ++oj) {
                 want[oj] = (oj < no) && need[((int64_t)a * mv.O + o0 + oj) * k_tiles + kt];
@@ -199,19 +199,37 @@ hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gam
     return hipGetLastError();
 }
 
-// need[ao][kt] = nzB[ao][kt] && (some 256-row belief block has a non-zero in K tile kt)
-__global__ void k_need_tiles(const uint8_t* __restrict__ nzA, int tiles_m, const uint8_t* __restrict__ nzB, int AO,
+// need[g][kt]: must Gamma's rows of group g be computed for K tile kt?  Yes iff some 256-row belief block
+// has mass in kt AND the score GEMM can list kt for an n-tile that holds rows of g -- i.e. some group
+// sharing an n-tile with g (g itself, its neighbours when V % 256 != 0, every group + the reward rows for
+// the tail tile) has RTO/ER support in kt.  Where g's own support is empty the projection writes true
+// zeros; tiles that are not needed are never read, so they may hold stale data.
+__global__ void k_need_tiles(const uint8_t* __restrict__ nzA, int tiles_m, const uint8_t* __restrict__ nzB, int G, int V,
                              int k_tiles, uint8_t* __restrict__ need) {
     const int kt = blockIdx.x * 256 + threadIdx.x;
     if (kt >= k_tiles) return;
     int any = 0;
     for (int m = 0; m < tiles_m; ++m) any |= nzA[(int64_t)m * k_tiles + kt];
-    for (int ao = 0; ao < AO; ++ao) need[(int64_t)ao * k_tiles + kt] = (any && nzB[(int64_t)ao * k_tiles + kt]) ? 1 : 0;
+    int all = 0;                                            // support of anything in the tail tile
+    for (int g = 0; g <= G; ++g) all |= nzB[(int64_t)g * k_tiles + kt];
+    const int64_t tail0 = (int64_t)G * V;                   // first magnitude row
+    for (int g = 0; g < G; ++g) {
+        const int64_t r0 = (int64_t)g * V, r1 = r0 + V - 1;
+        const int64_t t0 = r0 >> 8, t1 = r1 >> 8;           // n-tiles holding rows of g
+        int f = 0;
+        if ((t1 << 8) + 255 >= tail0) {
+            f = all;                                        // shares a tile with the tail rows
+        } else {
+            const int g0 = (int)((t0 << 8) / V), g1 = (int)(((t1 << 8) + 255) / V);
+            for (int x = g0; x <= g1 && x < G; ++x) f |= nzB[(int64_t)x * k_tiles + kt];
+        }
+        need[(int64_t)g * k_tiles + kt] = (any && f) ? 1 : 0;
+    }
 }
 
-hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB, int AO, int k_tiles, uint8_t* need,
-                             hipStream_t st) {
-    hipLaunchKernelGGL(k_need_tiles, dim3((k_tiles + 255) / 256), dim3(256), 0, st, nzA, tiles_m, nzB, AO, k_tiles, need);
+hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB, int AO, int V, int k_tiles,
+                             uint8_t* need, hipStream_t st) {
+    hipLaunchKernelGGL(k_need_tiles, dim3((k_tiles + 255) / 256), dim3(256), 0, st, nzA, tiles_m, nzB, AO, V, k_tiles, need);
     return hipGetLastError();
 }
 

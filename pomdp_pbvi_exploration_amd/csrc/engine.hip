@@ -21,6 +21,11 @@
 namespace pbvi {
 
 static thread_local std::string g_err;
+static int g_poison = -1;   // -1: read PBVI_POISON from the environment on first use
+static bool poison_enabled() {
+    if (g_poison < 0) g_poison = getenv("PBVI_POISON") != nullptr ? 1 : 0;
+    return g_poison == 1;
+}
 void set_error(const std::string& msg) { g_err = msg; }
 
 #define HIPCHK(expr)                                                                         \
@@ -60,6 +65,12 @@ struct DevBuf {
         }
         cap = bytes;
         *total += (int64_t)bytes;
+        // Debug: fill fresh allocations with 0xFF (NaN floats, -1 ints) so any read of memory the engine did
+        // not write shows up in the parity tests instead of hiding behind zero-filled fresh pages.
+        if (poison_enabled()) {   // null-stream memset does not order against the engine's non-blocking streams: fence it
+            if (hipMemset(p, 0xFF, bytes) != hipSuccess) (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
+        }
         return PBVI_OK;
     }
     void release() {
@@ -793,7 +804,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     const uint8_t* need = nullptr;
     if (kF32) {
         if ((rc = need_.ensure((size_t)AO * k_tiles, &bytes_))) return rc;
-        HIPCHK(launch_need_tiles(nzA_.as<uint8_t>(), (int)(B_pad_ / GEMM_BM), nzB_.as<uint8_t>(), AO, k_tiles,
+        HIPCHK(launch_need_tiles(nzA_.as<uint8_t>(), (int)(B_pad_ / GEMM_BM), nzB_.as<uint8_t>(), AO, (int)V_, k_tiles,
                                  need_.as<uint8_t>(), stream_));
         need = need_.as<uint8_t>();
     }
@@ -955,6 +966,12 @@ struct pbvi_engine {
 extern "C" {
 
 int pbvi_version(void) { return 100; }
+
+int pbvi_debug_poison(int enable) {
+    const int prev = pbvi::poison_enabled() ? 1 : 0;
+    pbvi::g_poison = enable ? 1 : 0;
+    return prev;
+}
 
 int pbvi_device_count(void) {
     int n = 0;

@@ -26,7 +26,7 @@ EXPORTS = [
     'pbvi_backup', 'pbvi_prune_dominated', 'pbvi_value_max',
     'pbvi_set_tie_window', 'pbvi_device_bytes',
     'pbvi_alpha_store_append', 'pbvi_alpha_select', 'pbvi_alpha_store_reset',
-    'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset',
+    'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset', 'pbvi_debug_poison',
 ]
 
 
@@ -89,6 +89,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_belief_store_append': (C.c_int64, [vp, vp, C.c_int64]),
         'pbvi_beliefs_select': (C.c_int, [vp, i32p, C.c_int64]),
         'pbvi_belief_store_reset': (C.c_int, [vp]),
+        'pbvi_debug_poison': (C.c_int, [C.c_int]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -98,6 +99,11 @@ def load_library(path: str = LIB_PATH):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def debug_poison(enable: bool) -> bool:
+    """Fill fresh device allocations with 0xFF (tests); returns the previous setting."""
+    return bool(load_library().pbvi_debug_poison(1 if enable else 0))
 
 
 def device_count() -> int:

@@ -371,3 +371,65 @@ def test_solver_loop_on_gpu_keeps_rows_resident():
     assert results[0][0] == results[1][0] == list(z['alpha_counts'])
     np.testing.assert_allclose(results[1][1], results[0][1], rtol=1e-10, atol=1e-12)
     assert np.array_equal(results[0][2], results[1][2])
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_shapes_f32(seed):
+    """Random models / sizes through every device-side mechanism (tile lists, stream-K shares, belief
+    reordering, tail rows, key dedup): indices exact, values within 1e-6 of the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    S = int(rng.integers(40, 2500))
+    A, O, R = int(rng.integers(1, 5)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    V, B = int(rng.integers(1, 700)), int(rng.integers(1, 900))
+    rs, rto, er = random_model(rng, S, A, O, R)
+    # block-structured sparsity so zero tiles really occur on both operands
+    lo, hi = sorted(rng.integers(0, S, size=2))
+    rto[lo:hi, :, O - 1, :] = 0.0
+    alpha = rng.normal(scale=5.0, size=(V, S)).astype(np.float32).astype(np.float64)
+    b = rng.random((B, S)) * (rng.random((B, S)) < 0.2)
+    for i in range(B):                                       # each belief lives on a window of states
+        w0 = int(rng.integers(0, S))
+        mask = np.zeros(S, dtype=bool)
+        mask[w0:w0 + max(8, S // 6)] = True
+        b[i] *= mask
+        b[i, w0] += 1e-3
+    b = (b / b.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    gamma = float(rng.choice([0.5, 0.9, 0.99]))
+    new, act, best = orc.backup_core(alpha, b, rs, rto, er, gamma)
+    eng = Engine(S, A, O, R, rs, rto, er, dtype='f32')
+    res = eng.backup_full(alpha, b, gamma, belief_dominance_prune=True)
+    assert np.array_equal(res.best_alpha_ind, best), (S, A, O, R, V, B)
+    assert np.array_equal(res.actions, act)
+    assert_alpha_close(res.alpha, new, F32_RTOL)
+    assert np.array_equal(eng.fetch_full(), res.alpha)
+    keep = orc.belief_dominance_mask(alpha, b, np.asarray(res.alpha, dtype=np.float64))
+    assert np.array_equal(res.keep, keep)
+    eng.close()
+
+
+def test_no_read_of_unwritten_device_memory():
+    """Poisoned allocations (0xFF = NaN / -1): shapes where (a,o) groups share GEMM tiles with each other and
+    with the tail rows, so a projection that skipped tiles the GEMM still reads would show up."""
+    from pomdp_pbvi_exploration_amd.engine import debug_poison
+    prev = debug_poison(True)
+    try:
+        rng = np.random.default_rng(77)
+        for (S, A, O, R, V, B) in [(1828, 1, 1, 1, 136, 125), (700, 2, 3, 2, 100, 300), (333, 3, 2, 1, 257, 40)]:
+            rs, rto, er = random_model(rng, S, A, O, R)
+            lo, hi = S // 3, 2 * S // 3
+            rto[lo:hi, :, O - 1, :] = 0.0                       # one group without support where ER / others have it
+            alpha = rng.normal(scale=5.0, size=(V, S)).astype(np.float32).astype(np.float64)
+            b = rng.random((B, S)) * (rng.random((B, S)) < 0.3)
+            b[:, lo] += 1e-3
+            b = (b / b.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+            new, act, best = orc.backup_core(alpha, b, rs, rto, er, 0.95)
+            for mode in ('sparse', 'dense'):
+                eng = Engine(S, A, O, R, rs, rto, er, dtype='f32', mode=mode)
+                for V_use in (V, max(1, V // 2)):               # second run re-uses buffers with shifted row groups
+                    n2, a2, b2 = (new, act, best) if V_use == V else orc.backup_core(alpha[:V_use], b, rs, rto, er, 0.95)
+                    res = eng.backup_full(alpha[:V_use], b, 0.95, belief_dominance_prune=True)
+                    assert np.array_equal(res.best_alpha_ind, b2) and np.array_equal(res.actions, a2), (S, V_use, mode)
+                    assert_alpha_close(res.alpha, n2, F32_RTOL)
+                eng.close()
+    finally:
+        debug_poison(prev)
