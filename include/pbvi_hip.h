@@ -187,6 +187,16 @@ int pbvi_prune_dominated(pbvi_engine_t* e, uint8_t* keep /* [V] */);
  */
 int pbvi_value_max(pbvi_engine_t* e, double* out_value, int32_t* out_index);
 
+/*
+ * Batched belief update (Bayes step) of the resident belief block: the step that produces the beliefs the
+ * backup consumes.  Replaces Belief.update (src/pomdp.py:382-421) applied to B beliefs at once (the
+ * reference's own batched form lives in its simulator, src/pomdp.py:3277-3310):
+ *   out[b] = normalise( sum_{s,r} b[b,s] * RTO[s, actions[b], observations[b], r]  scattered to rs[s,a,r] )
+ *   actions, observations [B] int32 (caller's belief order); out_beliefs [B][S] T, host or device memory.
+ * A belief whose update has zero mass (impossible observation) yields NaNs, as the reference's 0/0 does.
+ */
+int pbvi_belief_update(pbvi_engine_t* e, const int32_t* actions, const int32_t* observations, void* out_beliefs);
+
 /* Tuning knob for f32 engines: relative half-width of the near-tie window that sends an
  * argmax to fp64 refinement (<= 0 restores the default derived from |S|). */
 int pbvi_set_tie_window(pbvi_engine_t* e, double rel);

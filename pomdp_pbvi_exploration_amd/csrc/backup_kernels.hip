@@ -804,6 +804,59 @@ hipError_t launch_dominated(const T* alpha, int lda, int V, int S, int* cnt, hip
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------- //
+// Batched belief update (Bayes step).  Reference: Belief.update, src/pomdp.py:405-411 (one belief at a time,
+// np.bincount scatter); batched form in the simulator, src/pomdp.py:3277-3310.
+//   u[b, s'] = sum over (s, r) with rs[s, a_b, r] == s' of  b[b, s] * RTO[s, a_b, o_b, r];   b'[b] = u[b] / sum(u[b])
+// Pull form over inverse transition lists (CSC built at engine creation, entries in ascending (s, r) order =
+// bincount's accumulation order), so the sums are deterministic and need no atomics.
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void k_belief_push(const T* __restrict__ bel, int ldb, ModelView<T> mv, const int32_t* __restrict__ in_ptr,
+                              const int32_t* __restrict__ in_src, const int32_t* __restrict__ act,
+                              const int32_t* __restrict__ obs, double* __restrict__ unnorm, double* __restrict__ mass) {
+    __shared__ double red[4];
+    const int b = blockIdx.y, sp = blockIdx.x * 256 + threadIdx.x;
+    const int a = act[b], o = obs[b];
+    double u = 0.0;
+    if (sp < mv.S) {
+        const int32_t* ptr = in_ptr + (int64_t)a * (mv.S + 1);
+        const int32_t* src = in_src + (int64_t)a * mv.S * mv.R;
+        const T* rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
+        const T* brow = bel + (int64_t)b * ldb;
+        for (int j = ptr[sp]; j < ptr[sp + 1]; ++j) {
+            const int e = src[j];                           // e = s * R + r
+            const int s = e / mv.R, r = e - s * mv.R;
+            u += (double)brow[s] * (double)rto[(int64_t)r * mv.S_pad + s];
+        }
+        unnorm[(int64_t)b * mv.S + sp] = u;
+    }
+    const double tot = block_sum(u, red);
+    if (threadIdx.x == 0) atomicAdd(&mass[b], tot);        // <= S/256 adds per belief; order only affects the last bit of the norm
+}
+
+template <typename T>
+__global__ void k_belief_norm(const double* __restrict__ unnorm, const double* __restrict__ mass, int S, T* __restrict__ out,
+                              int ldo) {
+    const int b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    out[(int64_t)b * ldo + s] = (T)(unnorm[(int64_t)b * S + s] / mass[b]);   // mass 0 -> NaN, as the reference's 0/0
+}
+
+template <typename T>
+hipError_t launch_belief_update(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* in_ptr, const int32_t* in_src,
+                                const int32_t* act, const int32_t* obs, double* unnorm, double* mass, T* out, int ldo,
+                                hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    if (B > 65535) return hipErrorInvalidValue;
+    dim3 grid((mv.S + 255) / 256, B);
+    hipLaunchKernelGGL(k_belief_push<T>, grid, dim3(256), 0, st, bel, ldb, mv, in_ptr, in_src, act, obs, unnorm, mass);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_belief_norm<T>, grid, dim3(256), 0, st, unnorm, mass, mv.S, out, ldo);
+    return hipGetLastError();
+}
+
 // explicit instantiations
 #define PBVI_INST(T)                                                                                                   \
     template hipError_t launch_support<T>(ModelView<T>, uint8_t*, hipStream_t);                                        \
@@ -828,6 +881,8 @@ hipError_t launch_dominated(const T* alpha, int lda, int V, int S, int* cnt, hip
     template hipError_t launch_expand_rows<T>(const T*, const int32_t*, T*, int, int, hipStream_t);                    \
     template hipError_t launch_keep<T>(const T*, int, const T*, int, int, int, const double*, const int32_t*,          \
                                        const int32_t*, uint8_t*, hipStream_t);                                         \
+    template hipError_t launch_belief_update<T>(const T*, int, int, ModelView<T>, const int32_t*, const int32_t*,      \
+                                                const int32_t*, const int32_t*, double*, double*, T*, int, hipStream_t); \
     template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
 PBVI_INST(float)
 PBVI_INST(double)

@@ -191,6 +191,7 @@ class EngineBase {
     virtual int64_t store_append(int which, const void* rows, int64_t n) = 0;
     virtual int store_select(int which, const int32_t* ids, int64_t n) = 0;
     virtual int store_reset(int which) = 0;
+    virtual int belief_update(const int32_t* act, const int32_t* obs, void* out) = 0;
 };
 
 template <typename T>
@@ -215,6 +216,8 @@ class EngineT : public EngineBase {
     DevBuf rep_, uniq_, inv_, slot_, out_full_;            // K6 key dedup: out_ holds the unique rows
     DevBuf store_[2], ids_;                                // device row stores: [0] alpha-vectors, [1] beliefs
     int64_t store_rows_[2] = {0, 0};
+    DevBuf in_ptr_, in_src_, bu_act_, bu_obs_, bu_unnorm_, bu_mass_, bu_out_;   // batched belief update
+    std::vector<int32_t> h_rs_;                                // host copy of rs [A][R][S_pad] for the lazy CSC build
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     const int32_t* res_action_ = nullptr;                  // results in caller order
     const int32_t* res_best_ = nullptr;
@@ -238,7 +241,8 @@ class EngineT : public EngineBase {
         DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
-                         &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_,
+                         &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
+                         &bu_unnorm_, &bu_mass_, &bu_out_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
@@ -300,6 +304,7 @@ class EngineT : public EngineBase {
                         h_rto[(((size_t)a * O + o) * R + r) * S_pad_ + s] = rto[(((size_t)s * A + a) * O + o) * R + r];
                 }
             }
+        h_rs_ = h_rs;
         int rc;
         if ((rc = rs_.ensure(n_rs * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = rto_.ensure(n_rto * sizeof(T), &bytes_))) return rc;
@@ -458,6 +463,72 @@ class EngineT : public EngineBase {
         HIPCHK(hipMemcpy2DAsync(stage_.p, (size_t)S_pad_ * sizeof(T), bel, (size_t)S_ * sizeof(T), (size_t)S_ * sizeof(T),
                                 (size_t)B, hipMemcpyHostToDevice, stream_));
         return beliefs_finish(B);
+    }
+
+    // ---- batched belief update ---------------------------------------------- //
+    int build_inverse_lists() {
+        if (in_ptr_.p) return PBVI_OK;
+        // CSC of the padded-ELL transition structure per action: for every landing state s' the (s, r) pairs with
+        // rs[s,a,r] == s', in ascending s*R+r order (the order np.bincount accumulates in, src/pomdp.py:406).
+        std::vector<int32_t> ptr((size_t)A_ * (S_ + 1), 0), src((size_t)A_ * S_ * R_);
+        for (int a = 0; a < A_; ++a) {
+            int32_t* p = ptr.data() + (size_t)a * (S_ + 1);
+            for (int s = 0; s < S_; ++s)
+                for (int r = 0; r < R_; ++r) ++p[h_rs_[((size_t)a * R_ + r) * S_pad_ + s] + 1];
+            for (int s = 0; s < S_; ++s) p[s + 1] += p[s];
+            std::vector<int32_t> fill(p, p + S_);
+            int32_t* q = src.data() + (size_t)a * S_ * R_;
+            for (int s = 0; s < S_; ++s)
+                for (int r = 0; r < R_; ++r) q[fill[h_rs_[((size_t)a * R_ + r) * S_pad_ + s]]++] = s * R_ + r;
+        }
+        int rc;
+        if ((rc = in_ptr_.ensure(ptr.size() * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = in_src_.ensure(src.size() * sizeof(int32_t), &bytes_))) return rc;
+        HIPCHK(hipMemcpy(in_ptr_.p, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(in_src_.p, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        return PBVI_OK;
+    }
+
+    // out[b] = Bayes update of the resident belief b with (act[b], obs[b]); out: [B][S] T, host or device
+    int belief_update(const int32_t* act, const int32_t* obs, void* out) override {
+        if (B_ <= 0) FAIL(PBVI_EINVAL, "belief_update: no belief block resident");
+        if (!act || !obs || !out) FAIL(PBVI_EINVAL, "belief_update: NULL argument");
+        if ((int64_t)S_ * R_ > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "belief_update: S*R exceeds int32");
+        for (int64_t b = 0; b < B_; ++b)
+            if (act[b] < 0 || act[b] >= A_ || obs[b] < 0 || obs[b] >= O_) FAIL(PBVI_EINVAL, "belief_update: action / observation out of range");
+        HIPCHK(hipSetDevice(device_));
+        int rc = build_inverse_lists();
+        if (rc) return rc;
+        if ((rc = bu_act_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = bu_obs_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = bu_unnorm_.ensure((size_t)B_ * S_ * sizeof(double), &bytes_))) return rc;
+        if ((rc = bu_mass_.ensure((size_t)B_ * sizeof(double), &bytes_))) return rc;
+        if ((rc = bu_out_.ensure((size_t)B_ * S_ * sizeof(T), &bytes_))) return rc;
+        // act/obs arrive in the caller's belief order; the resident block may be sorted
+        std::vector<int32_t> ha((size_t)B_), ho((size_t)B_);
+        for (int64_t i = 0; i < B_; ++i) {
+            const int64_t c = sorted_ ? h_perm_[(size_t)i] : i;
+            ha[(size_t)i] = act[c];
+            ho[(size_t)i] = obs[c];
+        }
+        HIPCHK(hipMemcpyAsync(bu_act_.p, ha.data(), (size_t)B_ * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemcpyAsync(bu_obs_.p, ho.data(), (size_t)B_ * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemsetAsync(bu_mass_.p, 0, (size_t)B_ * sizeof(double), stream_));
+        // results go to rows in caller order: kernel row i writes out row perm[i] via a row-pointer trick is not
+        // needed -- compute in engine order into stage, then gather back
+        HIPCHK(launch_belief_update<T>(bel_.as<T>(), S_pad_, (int)B_, view(), in_ptr_.as<int32_t>(), in_src_.as<int32_t>(),
+                                       bu_act_.as<int32_t>(), bu_obs_.as<int32_t>(), bu_unnorm_.as<double>(),
+                                       bu_mass_.as<double>(), bu_out_.as<T>(), S_, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        if (!sorted_) {
+            HIPCHK(hipMemcpy(out, bu_out_.p, (size_t)B_ * S_ * sizeof(T), hipMemcpyDefault));
+        } else {   // row i of the engine order is the caller's row perm[i]
+            for (int64_t i = 0; i < B_; ++i)
+                HIPCHK(hipMemcpyAsync((char*)out + (size_t)h_perm_[(size_t)i] * S_ * sizeof(T),
+                                      bu_out_.as<T>() + (size_t)i * S_, (size_t)S_ * sizeof(T), hipMemcpyDefault, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+        }
+        return PBVI_OK;
     }
 
     // ---- device row stores ------------------------------------------------ //
@@ -1106,6 +1177,10 @@ int pbvi_beliefs_select(pbvi_engine_t* e, const int32_t* ids, int64_t B) {
 int pbvi_belief_store_reset(pbvi_engine_t* e) {
     NEED(e);
     return e->impl->store_reset(1);
+}
+int pbvi_belief_update(pbvi_engine_t* e, const int32_t* actions, const int32_t* observations, void* out_beliefs) {
+    NEED(e);
+    return e->impl->belief_update(actions, observations, out_beliefs);
 }
 int pbvi_set_tie_window(pbvi_engine_t* e, double rel) {
     NEED(e);

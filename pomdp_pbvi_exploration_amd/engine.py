@@ -27,6 +27,7 @@ EXPORTS = [
     'pbvi_set_tie_window', 'pbvi_device_bytes',
     'pbvi_alpha_store_append', 'pbvi_alpha_select', 'pbvi_alpha_store_reset',
     'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset', 'pbvi_debug_poison',
+    'pbvi_belief_update',
 ]
 
 
@@ -90,6 +91,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_beliefs_select': (C.c_int, [vp, i32p, C.c_int64]),
         'pbvi_belief_store_reset': (C.c_int, [vp]),
         'pbvi_debug_poison': (C.c_int, [C.c_int]),
+        'pbvi_belief_update': (C.c_int, [vp, i32p, i32p, vp]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -368,6 +370,19 @@ class Engine:
         _check(self._lib.pbvi_value_max(self._h, val.ctypes.data_as(C.POINTER(C.c_double)),
                                         idx.ctypes.data_as(C.POINTER(C.c_int32))))
         return val, idx.astype(np.int64)
+
+    def belief_update(self, beliefs: np.ndarray, actions, observations) -> np.ndarray:
+        """Batched Bayes step: row b of the result is ``Belief(beliefs[b]).update(actions[b], observations[b])``
+        (``src/pomdp.py:382-421``) computed on the device."""
+        self.set_beliefs(beliefs)
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        o = np.ascontiguousarray(observations, dtype=np.int32)
+        if a.shape != (self.B,) or o.shape != (self.B,):
+            raise ValueError('actions / observations must be [B]')
+        out = np.empty((self.B, self.S), dtype=self.np_dtype)
+        _check(self._lib.pbvi_belief_update(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            o.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(out)))
+        return out
 
     def set_tie_window(self, rel: float) -> None:
         _check(self._lib.pbvi_set_tie_window(self._h, float(rel)))

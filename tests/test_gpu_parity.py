@@ -433,3 +433,31 @@ def test_no_read_of_unwritten_device_memory():
                 eng.close()
     finally:
         debug_poison(prev)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_batched_belief_update(dtype):
+    """Bayes step on the device against the oracle's restatement of Belief.update."""
+    z, rs, rto, er = small(5)
+    b = z['beliefs'].astype(np.float64)
+    rng = np.random.default_rng(3)
+    act = rng.integers(0, 6, size=64)
+    obs = rng.integers(0, 2, size=64)                      # observation 2 (goal) is impossible for most beliefs
+    eng = Engine(600, 6, 3, 5, rs, rto, er, dtype=dtype)
+    out = eng.belief_update(b, act, obs)
+    ref = np.stack([orc.belief_update(b[i], int(act[i]), int(obs[i]), rs, rto) for i in range(64)])
+    np.testing.assert_allclose(out, ref, rtol=2e-6 if dtype == 'f32' else 1e-12, atol=1e-12)
+    np.testing.assert_allclose(out.sum(axis=1), 1.0, atol=1e-5)
+    # impossible observation -> 0/0 = NaN, like the reference
+    out2 = eng.belief_update(b[:3], [0, 0, 0], [2, 2, 2])
+    with np.errstate(invalid='ignore', divide='ignore'):
+        ref2 = np.stack([orc.belief_update(b[i], 0, 2, rs, rto) for i in range(3)])
+    assert np.array_equal(np.isnan(out2), np.isnan(ref2))
+    # large enough block to be reordered internally: results must come back in the caller's order
+    m = synth.olfactory_model(H=15, W=40, R=5)
+    bb = synth.belief_points(m, 300, max_depth=16)
+    a3, o3 = rng.integers(0, 6, size=300), np.zeros(300, dtype=np.int64)
+    out3 = eng.belief_update(bb, a3, o3)
+    ref3 = np.stack([orc.belief_update(bb[i], int(a3[i]), 0, rs, rto) for i in range(300)])
+    np.testing.assert_allclose(out3, ref3, rtol=2e-6 if dtype == 'f32' else 1e-12, atol=1e-12)
+    eng.close()
