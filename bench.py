@@ -144,7 +144,7 @@ def main():
                                    f'V={args.alphas} alpha-vectors, B={B} beliefs per GPU',
                        'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': args.alphas, 'B_per_gpu': B,
                        'parallelism': f'belief-sharded x{world}, 1 all-gather of alpha rows' if distributed else 'single GPU'},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_gemm_nt_f32_mfma (belief x Gamma score GEMM)',
+            'roofline': {'bound': 'mfma', 'kernel': 'k_gemm_nt_f32_streamk (belief x Gamma score GEMM, non-zero tiles)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
                          'flops_per_launch': flops, 'ms_per_launch': ms_score,
