@@ -461,3 +461,37 @@ def test_batched_belief_update(dtype):
     ref3 = np.stack([orc.belief_update(bb[i], int(a3[i]), 0, rs, rto) for i in range(300)])
     np.testing.assert_allclose(out3, ref3, rtol=2e-6 if dtype == 'f32' else 1e-12, atol=1e-12)
     eng.close()
+
+
+@pytest.mark.parametrize('S,B', [(2000, 128), (30000, 300)])
+def test_adversarial_near_ties(S, B):
+    """alpha-vectors that differ by 1e-5 ... 1e-9 relative (far below f32 GEMM rounding for the small gaps):
+    every argmax must match the fp64 reference exactly, which only the window + fp64 refinement can deliver."""
+    rng = np.random.default_rng(42)
+    A, O, R = 2, 2, 1 if S > 5000 else 2
+    rs, rto, er = random_model(rng, S, A, O, R)
+    base = rng.random(S) * 10.0 + 1.0
+    V = 96
+    alpha = np.empty((V, S))
+    for v in range(V):
+        eps = 10.0 ** -(5 + (v % 5))                         # 1e-5 .. 1e-9
+        alpha[v] = base * (1.0 + eps * rng.standard_normal(S))
+    alpha[7] = alpha[3]                                       # and exact duplicates
+    alpha = alpha.astype(np.float32).astype(np.float64)
+    b = rng.random((B, S)) * (rng.random((B, S)) < 0.05)
+    b[:, 0] += 1e-3
+    b = (b / b.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    new, act, best = orc.backup_core(alpha, b, rs, rto, er, 0.95)
+    # sanity: the case really is adversarial for f32 (top-2 gaps below 1e-6 relative are common)
+    G = orc.gamma_projection(alpha, rs, rto, 0.95)
+    sc = np.tensordot(b[:16], G, (1, 3))
+    top2 = np.sort(sc, axis=3)[..., -2:]
+    gaps = (top2[..., 1] - top2[..., 0]) / np.maximum(np.abs(top2[..., 1]), 1e-30)
+    assert np.median(gaps) < 1e-6
+    eng = Engine(S, A, O, R, rs, rto, er, dtype='f32')
+    res = eng.backup_full(alpha, b, 0.95)
+    assert np.array_equal(res.best_alpha_ind, best), int(np.sum(res.best_alpha_ind != best))
+    assert np.array_equal(res.actions, act)
+    assert_alpha_close(res.alpha, new, F32_RTOL)
+    assert res.stats['n_refined'] > 0.5 * res.stats['n_pairs']      # refinement did the deciding
+    eng.close()
