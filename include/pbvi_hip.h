@@ -197,6 +197,23 @@ int pbvi_value_max(pbvi_engine_t* e, double* out_value, int32_t* out_index);
  */
 int pbvi_belief_update(pbvi_engine_t* e, const int32_t* actions, const int32_t* observations, void* out_beliefs);
 
+/*
+ * Policy-evaluation step of the parallel simulator (Agent.run_n_simulations_parallel, src/pomdp.py:3296-3347)
+ * on the resident belief block, which never leaves the device between steps:
+ *   1. pbvi_value_max gives out_index[b] = first argmax_v b.alpha_v  (Agent.get_best_action, :3029); the caller
+ *      maps it through ValueFunction.actions and runs its simulator (host RNG, SimulationSet.run_actions);
+ *   2. pbvi_beliefs_advance replaces every belief by its Bayes update with (actions[b], observations[b])
+ *      (:3306-3311) and drops the rows with keep[b] == 0 (:3326-3329, the done-filter); survivors keep the
+ *      caller's order.  keep may be NULL (keep all).  *out_B (may be NULL) receives the new row count; when it
+ *      is 0 no belief block is resident any more.
+ * pbvi_beliefs_fetch copies the resident block out, [B][S] T in caller order (host or device memory);
+ * pbvi_beliefs_count returns B (0 = none, -1 = NULL handle).
+ */
+int pbvi_beliefs_advance(pbvi_engine_t* e, const int32_t* actions, const int32_t* observations, const uint8_t* keep,
+                         int64_t* out_B);
+int pbvi_beliefs_fetch(pbvi_engine_t* e, void* out_beliefs);
+int64_t pbvi_beliefs_count(const pbvi_engine_t* e);
+
 /* Tuning knob for f32 engines: relative half-width of the near-tie window that sends an
  * argmax to fp64 refinement (<= 0 restores the default derived from |S|). */
 int pbvi_set_tie_window(pbvi_engine_t* e, double rel);

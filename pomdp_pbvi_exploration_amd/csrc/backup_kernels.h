@@ -108,10 +108,11 @@ hipError_t launch_keep(const T* bel, int ldb, const T* uniq_rows, int ldo, int B
 
 // Batched Bayes step: out[b] = normalise(scatter of b[b,s]*RTO[s,a_b,o_b,r] to rs[s,a_b,r]) via inverse lists
 // in_ptr [A][S+1], in_src [A][S*R] (entries s*R+r, ascending); unnorm [B][S] / mass [B] f64 scratch (mass zeroed).
+// out_row (may be null = identity): result row of belief b, -1 = drop it (the simulator's done-filter).
 template <typename T>
 hipError_t launch_belief_update(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* in_ptr, const int32_t* in_src,
-                                const int32_t* act, const int32_t* obs, double* unnorm, double* mass, T* out, int ldo,
-                                hipStream_t st);
+                                const int32_t* act, const int32_t* obs, const int32_t* out_row, double* unnorm,
+                                double* mass, T* out, int ldo, hipStream_t st);
 
 // prune level 2: cnt[i] = #{j : alpha[j][s] >= alpha[i][s] for all s}
 template <typename T>

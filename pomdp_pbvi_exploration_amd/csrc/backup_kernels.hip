@@ -814,9 +814,11 @@ hipError_t launch_dominated(const T* alpha, int lda, int V, int S, int* cnt, hip
 template <typename T>
 __global__ void k_belief_push(const T* __restrict__ bel, int ldb, ModelView<T> mv, const int32_t* __restrict__ in_ptr,
                               const int32_t* __restrict__ in_src, const int32_t* __restrict__ act,
-                              const int32_t* __restrict__ obs, double* __restrict__ unnorm, double* __restrict__ mass) {
+                              const int32_t* __restrict__ obs, const int32_t* __restrict__ out_row,
+                              double* __restrict__ unnorm, double* __restrict__ mass) {
     __shared__ double red[4];
     const int b = blockIdx.y, sp = blockIdx.x * 256 + threadIdx.x;
+    if (out_row && out_row[b] < 0) return;                 // dropped row (whole block leaves together)
     const int a = act[b], o = obs[b];
     double u = 0.0;
     if (sp < mv.S) {
@@ -836,24 +838,27 @@ __global__ void k_belief_push(const T* __restrict__ bel, int ldb, ModelView<T> m
 }
 
 template <typename T>
-__global__ void k_belief_norm(const double* __restrict__ unnorm, const double* __restrict__ mass, int S, T* __restrict__ out,
-                              int ldo) {
+__global__ void k_belief_norm(const double* __restrict__ unnorm, const double* __restrict__ mass, int S,
+                              const int32_t* __restrict__ out_row, T* __restrict__ out, int ldo) {
     const int b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
     if (s >= S) return;
-    out[(int64_t)b * ldo + s] = (T)(unnorm[(int64_t)b * S + s] / mass[b]);   // mass 0 -> NaN, as the reference's 0/0
+    const int row = out_row ? out_row[b] : b;              // compaction: surviving rows move up, -1 = dropped
+    if (row < 0) return;
+    out[(int64_t)row * ldo + s] = (T)(unnorm[(int64_t)b * S + s] / mass[b]);   // mass 0 -> NaN, as the reference's 0/0
 }
 
 template <typename T>
 hipError_t launch_belief_update(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* in_ptr, const int32_t* in_src,
-                                const int32_t* act, const int32_t* obs, double* unnorm, double* mass, T* out, int ldo,
-                                hipStream_t st) {
+                                const int32_t* act, const int32_t* obs, const int32_t* out_row, double* unnorm,
+                                double* mass, T* out, int ldo, hipStream_t st) {
     if (B <= 0) return hipSuccess;
     if (B > 65535) return hipErrorInvalidValue;
     dim3 grid((mv.S + 255) / 256, B);
-    hipLaunchKernelGGL(k_belief_push<T>, grid, dim3(256), 0, st, bel, ldb, mv, in_ptr, in_src, act, obs, unnorm, mass);
+    hipLaunchKernelGGL(k_belief_push<T>, grid, dim3(256), 0, st, bel, ldb, mv, in_ptr, in_src, act, obs, out_row, unnorm,
+                       mass);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_belief_norm<T>, grid, dim3(256), 0, st, unnorm, mass, mv.S, out, ldo);
+    hipLaunchKernelGGL(k_belief_norm<T>, grid, dim3(256), 0, st, unnorm, mass, mv.S, out_row, out, ldo);
     return hipGetLastError();
 }
 
@@ -882,7 +887,8 @@ hipError_t launch_belief_update(const T* bel, int ldb, int B, ModelView<T> mv, c
     template hipError_t launch_keep<T>(const T*, int, const T*, int, int, int, const double*, const int32_t*,          \
                                        const int32_t*, uint8_t*, hipStream_t);                                         \
     template hipError_t launch_belief_update<T>(const T*, int, int, ModelView<T>, const int32_t*, const int32_t*,      \
-                                                const int32_t*, const int32_t*, double*, double*, T*, int, hipStream_t); \
+                                                const int32_t*, const int32_t*, const int32_t*, double*, double*, T*,  \
+                                                int, hipStream_t);                                                     \
     template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
 PBVI_INST(float)
 PBVI_INST(double)

@@ -192,6 +192,9 @@ class EngineBase {
     virtual int store_select(int which, const int32_t* ids, int64_t n) = 0;
     virtual int store_reset(int which) = 0;
     virtual int belief_update(const int32_t* act, const int32_t* obs, void* out) = 0;
+    virtual int beliefs_advance(const int32_t* act, const int32_t* obs, const uint8_t* keep, int64_t* out_B) = 0;
+    virtual int beliefs_fetch(void* out) = 0;
+    virtual int64_t beliefs_count() const = 0;
 };
 
 template <typename T>
@@ -216,7 +219,7 @@ class EngineT : public EngineBase {
     DevBuf rep_, uniq_, inv_, slot_, out_full_;            // K6 key dedup: out_ holds the unique rows
     DevBuf store_[2], ids_;                                // device row stores: [0] alpha-vectors, [1] beliefs
     int64_t store_rows_[2] = {0, 0};
-    DevBuf in_ptr_, in_src_, bu_act_, bu_obs_, bu_unnorm_, bu_mass_, bu_out_;   // batched belief update
+    DevBuf in_ptr_, in_src_, bu_act_, bu_obs_, bu_row_, bu_unnorm_, bu_mass_, bu_out_;   // batched belief update
     std::vector<int32_t> h_rs_;                                // host copy of rs [A][R][S_pad] for the lazy CSC build
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     const int32_t* res_action_ = nullptr;                  // results in caller order
@@ -242,7 +245,7 @@ class EngineT : public EngineBase {
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
-                         &bu_unnorm_, &bu_mass_, &bu_out_,
+                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
@@ -517,7 +520,7 @@ class EngineT : public EngineBase {
         // results go to rows in caller order: kernel row i writes out row perm[i] via a row-pointer trick is not
         // needed -- compute in engine order into stage, then gather back
         HIPCHK(launch_belief_update<T>(bel_.as<T>(), S_pad_, (int)B_, view(), in_ptr_.as<int32_t>(), in_src_.as<int32_t>(),
-                                       bu_act_.as<int32_t>(), bu_obs_.as<int32_t>(), bu_unnorm_.as<double>(),
+                                       bu_act_.as<int32_t>(), bu_obs_.as<int32_t>(), nullptr, bu_unnorm_.as<double>(),
                                        bu_mass_.as<double>(), bu_out_.as<T>(), S_, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
         if (!sorted_) {
@@ -530,6 +533,73 @@ class EngineT : public EngineBase {
         }
         return PBVI_OK;
     }
+
+    // Simulator step on the resident block (src/pomdp.py:3305-3311 update, :3326-3329 done-filter): every belief is
+    // updated with its own (a, o); rows with keep[b] == 0 are dropped and the survivors become the resident block,
+    // in the caller's order.  The beliefs never leave the device.
+    int beliefs_advance(const int32_t* act, const int32_t* obs, const uint8_t* keep, int64_t* out_B) override {
+        if (B_ <= 0) FAIL(PBVI_EINVAL, "beliefs_advance: no belief block resident");
+        if (!act || !obs) FAIL(PBVI_EINVAL, "beliefs_advance: NULL argument");
+        if ((int64_t)S_ * R_ > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "beliefs_advance: S*R exceeds int32");
+        for (int64_t b = 0; b < B_; ++b)
+            if (act[b] < 0 || act[b] >= A_ || obs[b] < 0 || obs[b] >= O_) FAIL(PBVI_EINVAL, "beliefs_advance: action / observation out of range");
+        HIPCHK(hipSetDevice(device_));
+        int rc = build_inverse_lists();
+        if (rc) return rc;
+        std::vector<int32_t> dst((size_t)B_);           // caller row -> surviving row
+        int64_t nb = 0;
+        for (int64_t c = 0; c < B_; ++c) dst[(size_t)c] = (!keep || keep[c]) ? (int32_t)nb++ : -1;
+        if (out_B) *out_B = nb;
+        if (nb == 0) {                                   // every simulation finished
+            B_ = 0;
+            B_pad_ = 0;
+            sorted_ = false;
+            have_result_ = false;
+            return PBVI_OK;
+        }
+        if ((rc = bu_act_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = bu_obs_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = bu_row_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = bu_unnorm_.ensure((size_t)B_ * S_ * sizeof(double), &bytes_))) return rc;
+        if ((rc = bu_mass_.ensure((size_t)B_ * sizeof(double), &bytes_))) return rc;
+        if ((rc = stage_.ensure((size_t)nb * S_pad_ * sizeof(T), &bytes_))) return rc;
+        std::vector<int32_t> ha((size_t)B_), ho((size_t)B_), hr((size_t)B_);
+        for (int64_t i = 0; i < B_; ++i) {               // engine row i holds the caller's row c
+            const int64_t c = sorted_ ? h_perm_[(size_t)i] : i;
+            ha[(size_t)i] = act[c];
+            ho[(size_t)i] = obs[c];
+            hr[(size_t)i] = dst[(size_t)c];
+        }
+        HIPCHK(hipMemcpyAsync(bu_act_.p, ha.data(), (size_t)B_ * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemcpyAsync(bu_obs_.p, ho.data(), (size_t)B_ * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemcpyAsync(bu_row_.p, hr.data(), (size_t)B_ * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemsetAsync(bu_mass_.p, 0, (size_t)B_ * sizeof(double), stream_));
+        HIPCHK(hipMemsetAsync(stage_.p, 0, (size_t)nb * S_pad_ * sizeof(T), stream_));   // pad columns stay zero
+        HIPCHK(launch_belief_update<T>(bel_.as<T>(), S_pad_, (int)B_, view(), in_ptr_.as<int32_t>(), in_src_.as<int32_t>(),
+                                       bu_act_.as<int32_t>(), bu_obs_.as<int32_t>(), bu_row_.as<int32_t>(),
+                                       bu_unnorm_.as<double>(), bu_mass_.as<double>(), stage_.as<T>(), S_pad_, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));           // ha/ho/hr are pageable host vectors
+        return beliefs_finish(nb);
+    }
+
+    // resident belief block back to the host (or a device buffer), caller order: [B][S] T
+    int beliefs_fetch(void* out) override {
+        if (B_ <= 0) FAIL(PBVI_EINVAL, "beliefs_fetch: no belief block resident");
+        if (!out) FAIL(PBVI_EINVAL, "beliefs_fetch: NULL argument");
+        HIPCHK(hipSetDevice(device_));
+        if (!sorted_) {
+            HIPCHK(hipMemcpy2DAsync(out, (size_t)S_ * sizeof(T), bel_.p, (size_t)S_pad_ * sizeof(T), (size_t)S_ * sizeof(T),
+                                    (size_t)B_, hipMemcpyDefault, stream_));
+        } else {
+            for (int64_t i = 0; i < B_; ++i)
+                HIPCHK(hipMemcpyAsync((char*)out + (size_t)h_perm_[(size_t)i] * S_ * sizeof(T),
+                                      bel_.as<T>() + (size_t)i * S_pad_, (size_t)S_ * sizeof(T), hipMemcpyDefault, stream_));
+        }
+        HIPCHK(hipStreamSynchronize(stream_));
+        return PBVI_OK;
+    }
+
+    int64_t beliefs_count() const override { return B_; }
 
     // ---- device row stores ------------------------------------------------ //
     int64_t store_append(int which, const void* rows, int64_t n) override {
@@ -1178,6 +1248,19 @@ int pbvi_belief_store_reset(pbvi_engine_t* e) {
     NEED(e);
     return e->impl->store_reset(1);
 }
+int pbvi_beliefs_advance(pbvi_engine_t* e, const int32_t* actions, const int32_t* observations, const uint8_t* keep,
+                         int64_t* out_B) {
+    NEED(e);
+    return e->impl->beliefs_advance(actions, observations, keep, out_B);
+}
+
+int pbvi_beliefs_fetch(pbvi_engine_t* e, void* out_beliefs) {
+    NEED(e);
+    return e->impl->beliefs_fetch(out_beliefs);
+}
+
+int64_t pbvi_beliefs_count(const pbvi_engine_t* e) { return (e && e->impl) ? e->impl->beliefs_count() : -1; }
+
 int pbvi_belief_update(pbvi_engine_t* e, const int32_t* actions, const int32_t* observations, void* out_beliefs) {
     NEED(e);
     return e->impl->belief_update(actions, observations, out_beliefs);

@@ -27,7 +27,7 @@ EXPORTS = [
     'pbvi_set_tie_window', 'pbvi_device_bytes',
     'pbvi_alpha_store_append', 'pbvi_alpha_select', 'pbvi_alpha_store_reset',
     'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset', 'pbvi_debug_poison',
-    'pbvi_belief_update',
+    'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
 ]
 
 
@@ -92,6 +92,9 @@ def load_library(path: str = LIB_PATH):
         'pbvi_belief_store_reset': (C.c_int, [vp]),
         'pbvi_debug_poison': (C.c_int, [C.c_int]),
         'pbvi_belief_update': (C.c_int, [vp, i32p, i32p, vp]),
+        'pbvi_beliefs_advance': (C.c_int, [vp, i32p, i32p, u8p, C.POINTER(C.c_int64)]),
+        'pbvi_beliefs_fetch': (C.c_int, [vp, vp]),
+        'pbvi_beliefs_count': (C.c_int64, [vp]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -382,6 +385,31 @@ class Engine:
         out = np.empty((self.B, self.S), dtype=self.np_dtype)
         _check(self._lib.pbvi_belief_update(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)),
                                             o.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(out)))
+        return out
+
+    def advance_beliefs(self, actions, observations, keep=None) -> int:
+        """Simulator step on the resident block (``src/pomdp.py:3305-3329``): Bayes-update every belief with its
+        ``(action, observation)`` and keep only the rows with ``keep[b]`` true, in order.  Returns the new B."""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        o = np.ascontiguousarray(observations, dtype=np.int32)
+        if a.shape != (self.B,) or o.shape != (self.B,):
+            raise ValueError('actions / observations must be [B]')
+        kp = None
+        if keep is not None:
+            k = np.ascontiguousarray(keep, dtype=np.uint8)
+            if k.shape != (self.B,):
+                raise ValueError('keep must be [B]')
+            kp = k.ctypes.data_as(C.POINTER(C.c_uint8))
+        nb = C.c_int64(0)
+        _check(self._lib.pbvi_beliefs_advance(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              o.ctypes.data_as(C.POINTER(C.c_int32)), kp, C.byref(nb)))
+        self.B = int(nb.value)
+        return self.B
+
+    def fetch_beliefs(self) -> np.ndarray:
+        """The resident belief block, ``[B,S]`` in caller order."""
+        out = np.empty((self.B, self.S), dtype=self.np_dtype)
+        _check(self._lib.pbvi_beliefs_fetch(self._h, _ptr(out)))
         return out
 
     def set_tie_window(self, rel: float) -> None:

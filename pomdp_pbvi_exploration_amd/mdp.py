@@ -3,8 +3,10 @@
 Only what the PBVI backup path and its callers need is here: ``log``, the MDP
 ``Model`` (reachable-state tables), ``AlphaVector`` / ``ValueFunction`` (the
 backup's output contract: byte-exact dedup, new-then-old union, level-2
-domination prune) and ``VI_Solver`` (seeds FSVI/HSVI).  Plotting, simulation and
-file persistence of the reference are out of scope.
+domination prune), ``VI_Solver`` (seeds FSVI/HSVI) and the simulation containers
+(``RewardSet``, ``SimulationHistory``, ``Simulation``, ``Agent``) that policy
+evaluation builds on.  Plotting, videos and file
+persistence of the reference are out of scope.
 
 Device residency replaces the reference's CuPy twins (``src/mdp.py:533-590``,
 ``:782-831``): ``Model.gpu_model`` returns a twin bound to a HIP engine handle
@@ -14,8 +16,9 @@ raises -- there is no silent CPU fallback.
 """
 from __future__ import annotations
 
+import random
 from datetime import datetime
-from typing import Union
+from typing import Tuple, Union
 
 import numpy as np
 
@@ -193,6 +196,17 @@ class Model:
         if self.reachable_state_count == 1:
             return int(self.reachable_states[s, a, 0])
         return int(np.random.choice(a=self.reachable_states[s, a], size=1, p=self.reachable_probabilities[s, a])[0])
+
+    def reward(self, s: int, a: int, s_p: int):
+        """Reward of landing in ``s_p`` after ``a`` in ``s``; a Bernoulli draw when rewards are
+        probabilities (``src/mdp.py:441-465``)."""
+        if self.immediate_reward_table is not None:
+            r = float(self.immediate_reward_table[s, a, s_p])
+        else:
+            r = float(self.immediate_reward_function(s, a, s_p))
+        if self.rewards_are_probabilistic:
+            return 1 if random.random() < r else 0
+        return r
 
     # -- residency ------------------------------------------------------- #
     def to_gpu(self, dtype: str = 'f64', device: int = 0) -> 'Model':
@@ -404,3 +418,130 @@ class VI_Solver(Solver):
             if change < limit:
                 break
         return V, hist
+
+
+# --------------------------------------------------------------------------- #
+# Simulation containers (policy evaluation)
+# --------------------------------------------------------------------------- #
+class RewardSet(list):
+    """List of step rewards (``src/mdp.py:1528-1566``; the plotting helpers are out of scope)."""
+
+    def __init__(self, items: list = []):
+        super().__init__()
+        self.extend(items)
+
+    def get_total_discounted_reward(self, gamma: float) -> float:
+        """``sum_t gamma^t r_t`` (``src/mdp.py:1546-1566``)."""
+        return float(np.dot(np.array(self, dtype=float), gamma ** np.arange(len(self))))
+
+
+class SimulationHistory:
+    """States, actions and rewards of one simulated episode (``src/mdp.py:1689-1756``)."""
+
+    def __init__(self, model: Model, start_state: int):
+        self.model = model.cpu_model
+        self.states = [start_state]
+        self.actions = []
+        self.rewards = RewardSet()
+
+    @property
+    def grid_point_sequence(self) -> list:
+        grid = self.model.state_grid
+        return [[int(i[0]) for i in np.where(grid == s)] for s in self.states]
+
+    def add(self, action: int, reward, next_state: int) -> None:
+        self.actions.append(action)
+        self.rewards.append(reward)
+        self.states.append(next_state)
+
+    def __len__(self) -> int:
+        return len(self.states)
+
+
+class Simulation:
+    """One agent walking the model (``src/mdp.py:1888-1977``): hidden state, done flag."""
+
+    def __init__(self, model: Model) -> None:
+        self.model = model
+        self.agent_state = -1
+        self.is_done = True
+        self.initialize_simulation()
+
+    def initialize_simulation(self, start_state: Union[int, None] = None) -> int:
+        if start_state is None:
+            self.agent_state = int(np.random.choice(a=self.model.states, size=1, p=self.model.start_probabilities)[0])
+        else:
+            self.agent_state = start_state
+        self.is_done = False
+        return self.agent_state
+
+    def _mark_done(self, s_p: int, a: int) -> None:
+        if s_p in self.model.end_states or a in self.model.end_actions:
+            self.is_done = True
+
+    def run_action(self, a: int) -> Tuple[Union[int, float], int]:
+        assert not self.is_done, "Action run when simulation is done."
+        s = self.agent_state
+        s_p = self.model.transition(s, a)
+        r = self.model.reward(s, a, s_p)
+        self.agent_state = s_p
+        self._mark_done(s_p, a)
+        return r, s_p
+
+
+class Agent:
+    """Greedy agent on a solved MDP (``src/mdp.py:1980-2200``)."""
+
+    def __init__(self, model: Model, value_function: Union[ValueFunction, None] = None) -> None:
+        self.model = model
+        self.value_function = value_function
+
+    def train(self, solver: Union[Solver, None] = None) -> SolverHistory:
+        solver = VI_Solver() if solver is None else solver
+        self.value_function, hist = solver.solve(self.model)
+        return hist
+
+    def get_best_action(self, state: int) -> int:
+        assert self.value_function is not None, "No value function, training probably has to be run..."
+        best = int(np.argmax(self.value_function.alpha_vector_array[:, state]))
+        return int(self.value_function.actions[best])
+
+    def simulate(self, simulator: Union[Simulation, None] = None, max_steps: int = 1000,
+                 start_state: Union[int, None] = None, print_progress: bool = True,
+                 print_stats: bool = True) -> SimulationHistory:
+        simulator = Simulation(self.model) if simulator is None else simulator
+        s = simulator.initialize_simulation(start_state=start_state)
+        history = SimulationHistory(self.model, s)
+        t0 = datetime.now()
+        for _ in range(max_steps):
+            a = self.get_best_action(s)
+            r, s = simulator.run_action(a)
+            history.add(action=a, next_state=s, reward=r)
+            if simulator.is_done:
+                break
+        if print_stats:
+            print('Simulation done:')
+            print(f'\t- Runtime (s): {(datetime.now() - t0).total_seconds()}')
+            print(f'\t- Steps: {len(history.states)}')
+            print(f'\t- Total rewards: {sum(history.rewards)}')
+            print(f'\t- End state: {self.model.state_labels[history.states[-1]]}')
+        return history
+
+    def run_n_simulations(self, simulator: Union[Simulation, None] = None, n: int = 1000, max_steps: int = 1000,
+                          start_state: int = -1, reward_discount: float = 0.99, print_progress: bool = True,
+                          print_stats: bool = True):
+        simulator = Simulation(self.model) if simulator is None else simulator
+        t0 = datetime.now()
+        totals, histories, discounted = RewardSet(), [], []
+        for _ in range(n):
+            h = self.simulate(simulator, max_steps, start_state, False, False)
+            histories.append(h)
+            totals.append(sum(h.rewards))
+            discounted.append(h.rewards.get_total_discounted_reward(reward_discount))
+        if print_stats:
+            print(f'All {n} simulations done:')
+            print(f'\t- Average runtime (s): {(datetime.now() - t0).total_seconds() / n}')
+            print(f'\t- Average step count: {sum(len(h) for h in histories) / n}')
+            print(f'\t- Average total rewards: {sum(totals) / n}')
+            print(f'\t- Average discounted rewards (ADR): {sum(discounted) / n}')
+        return totals, histories

@@ -23,6 +23,9 @@ import numpy as np
 from .mdp import AlphaVector, ValueFunction, VI_Solver, log, _log, set_quiet   # noqa: F401
 from .mdp import Model as MDP_Model
 from .mdp import Solver as MDP_Solver
+from .mdp import RewardSet                                   # noqa: F401
+from .mdp import SimulationHistory as MDP_SimulationHistory
+from .mdp import Simulation as MDP_Simulation
 
 gpu_support = True
 
@@ -82,6 +85,16 @@ class Model(MDP_Model):
 
     def _end_reward_function(self, s, a, sn, o):
         return (np.isin(sn, self.end_states) | np.isin(a, self.end_actions)).astype(int)
+
+    def reward(self, s: int, a: int, s_p: int, o: int):
+        """Reward of ``(s, a, s_p, o)``; a Bernoulli draw when rewards are probabilities (``src/pomdp.py:259-285``)."""
+        if self.immediate_reward_table is not None:
+            r = float(self.immediate_reward_table[s, a, s_p, o])
+        else:
+            r = float(self.immediate_reward_function(s, a, s_p, o))
+        if self.rewards_are_probabilistic:
+            return 1 if random.random() < r else 0
+        return r
 
     def observe(self, s_p: int, a: int) -> int:
         return int(np.random.choice(a=self.observations, size=1, p=self.observation_table[s_p, a])[0])
@@ -599,6 +612,311 @@ class HSVI_Solver(PBVI_Solver):
 
     def __init__(self, gamma: float = 0.99, eps: float = 0.001, mdp_policy=None):
         super().__init__(gamma, eps, 'hsvi', mdp_policy=mdp_policy)
+
+
+# --------------------------------------------------------------------------- #
+# Policy evaluation: simulators and the agent
+# --------------------------------------------------------------------------- #
+class SimulationHistory(MDP_SimulationHistory):
+    """Episode record with observations and beliefs (``src/pomdp.py:2581-2662``).  The belief sequence is rebuilt
+    on demand from the (action, observation) pairs when it was not recorded step by step."""
+
+    def __init__(self, model: Model, start_state: int, start_belief: Belief):
+        super().__init__(model, start_state)
+        self._beliefs = [start_belief]
+        self.observations = []
+
+    @property
+    def beliefs(self) -> list:
+        if len(self._beliefs) < len(self):
+            b = self._beliefs[0]
+            self._beliefs = [b]
+            for a, o in zip(self.actions, self.observations):
+                b = b.update(int(a), int(o))
+                self._beliefs.append(b)
+        return self._beliefs
+
+    def add(self, action: int, reward, next_state: int, next_belief: Belief, observation: int) -> None:
+        super().add(action, reward, next_state)
+        self._beliefs.append(next_belief)
+        self.observations.append(observation)
+
+
+class Simulation(MDP_Simulation):
+    """One hidden-state walk with observations (``src/pomdp.py:2756-2815``)."""
+
+    def __init__(self, model: Model) -> None:
+        super().__init__(model)
+        self.model = model
+
+    def run_action(self, a: int) -> Tuple[Union[int, float], int]:
+        assert not self.is_done, "Action run when simulation is done."
+        s = self.agent_state
+        s_p = self.model.transition(s, a)
+        o = self.model.observe(s_p, a)
+        r = self.model.reward(s, a, s_p, o)
+        self.agent_state = s_p
+        self._mark_done(s_p, a)
+        return r, o
+
+
+class SimulationSet:
+    """n hidden-state walks advanced together (``src/pomdp.py:2818-2945``).  The random draws are NumPy's global
+    stream in the reference's call order (start states: one ``choice``; per step: one ``choice`` per
+    simulation when R > 1, then one ``random(n)``), so a seeded run reproduces the reference's trajectories.
+
+    ``reference_indexing``: for R > 1 the reference picks the successor with ``potentials[chosen][:, 0, 0]``
+    (``:2928``), i.e. row ``chosen[i]`` column 0 rather than row ``i`` column ``chosen[i]``.  The default keeps
+    that behaviour for parity; set it to False to sample ``rs[s_i, a_i, chosen_i]``.
+    """
+
+    reference_indexing = True
+
+    def __init__(self, model: Model):
+        self.model = model
+        self.n = -1
+        self.agent_states = [-1]
+        self.simulations = []
+        self.is_done = [True]
+
+    def initialize_simulations(self, n: int = 1, start_state: Union[list, int, None] = None) -> np.ndarray:
+        if isinstance(start_state, int):
+            states = (np.ones(n) * start_state).astype(int)
+        elif isinstance(start_state, list):
+            rep = np.repeat(np.array(start_state), int(np.ceil(n / len(start_state))))
+            states = np.resize(rep, n)
+        else:
+            states = np.random.choice(self.model.states, size=n, p=self.model.start_probabilities).astype(int)
+        self.n = n
+        self.agent_states = states
+        self.simulations = np.arange(n)
+        self.is_done = np.zeros(n, dtype=bool)
+        return self.agent_states
+
+    def _step_rewards(self, s, a, s_p, o) -> np.ndarray:
+        m = self.model
+        if m.immediate_reward_table is not None:
+            return np.asarray(m.immediate_reward_table[s, a, s_p, o])
+        fn = m.immediate_reward_function
+        if getattr(fn, '__func__', None) is Model._end_reward_function:      # element-wise by construction
+            return np.asarray(fn(s, a, s_p, o))
+        return np.array([fn(int(w), int(x), int(y), int(z)) for w, x, y, z in zip(s, a, s_p, o)])
+
+    def run_actions(self, actions: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        m = self.model
+        actions = np.asarray(actions)
+        potentials = m.reachable_states[self.agent_states, actions]                 # [n, R]
+        if m.reachable_state_count == 1:
+            next_states = potentials[:, 0]
+        else:
+            probs = m.reachable_probabilities[self.agent_states, actions]            # [n, R]
+            chosen = np.apply_along_axis(lambda x: np.random.choice(len(x), size=1, p=x), axis=1, arr=probs)
+            if self.reference_indexing:
+                next_states = potentials[chosen][:, 0, 0]
+            else:
+                next_states = potentials[np.arange(self.n), chosen[:, 0]]
+        obs_p = m.observation_table[next_states, actions]                            # [n, O]
+        observations = np.sum(np.random.random(self.n)[:, None] > np.cumsum(obs_p[:, :-1], axis=1), axis=1)
+        step_rewards = self._step_rewards(self.agent_states, actions, next_states, observations)
+        rewards = np.where(~self.is_done, step_rewards, 0)
+        self.is_done |= np.isin(next_states, np.array(m.end_states))
+        self.agent_states = next_states
+        return rewards, observations
+
+
+class _HostBeliefBlock:
+    """Belief block of the parallel simulator held in NumPy (reference CPU statements, ``:3029``, ``:3306-3311``)."""
+
+    def __init__(self, model: Model, value_function: ValueFunction, beliefs: np.ndarray):
+        self.m, self.alpha, self.b = model, value_function.alpha_vector_array, beliefs
+
+    def best_vectors(self) -> np.ndarray:
+        return np.argmax(np.matmul(self.b, self.alpha.T), axis=1)
+
+    def advance(self, actions: np.ndarray, observations: np.ndarray, keep: np.ndarray) -> None:
+        m, n = self.m, self.b.shape[0]
+        S = m.state_count
+        w = m.reachable_transitional_observation_table[:, actions, observations, :] * self.b.T[:, :, None]   # [S,n,R]
+        tgt = m.reachable_states[:, actions, :]                                                             # [S,n,R]
+        flat = (n, S * m.reachable_state_count)
+        idx = tgt.swapaxes(0, 1).reshape(flat) + (np.arange(n)[:, None] * S)
+        nb = np.bincount(idx.ravel(), weights=w.swapaxes(0, 1).reshape(flat).ravel(), minlength=n * S).reshape((-1, S))
+        nb /= np.sum(nb, axis=1)[:, None]
+        self.b = nb[keep]
+
+
+class _DeviceBeliefBlock:
+    """Belief block resident in the HIP engine: ``pbvi_value_max`` + ``pbvi_beliefs_advance``."""
+
+    def __init__(self, model: Model, value_function: ValueFunction, beliefs: np.ndarray):
+        self.eng = model.engine
+        self.eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values)
+        self.eng.set_beliefs(beliefs)
+
+    def best_vectors(self) -> np.ndarray:
+        return self.eng.max_value_resident()[1]
+
+    def advance(self, actions: np.ndarray, observations: np.ndarray, keep: np.ndarray) -> None:
+        self.eng.advance_beliefs(actions, observations, keep)
+
+
+class Agent:
+    """Greedy agent over a value function (``src/pomdp.py:2948-3380``): best action for a belief, single
+    simulations, and n simulations advanced together with the belief block on the host or in the HIP engine."""
+
+    def __init__(self, model: Model, value_function: Union[ValueFunction, None] = None) -> None:
+        self.model = model
+        self.value_function = value_function
+
+    def train(self, solver: PBVI_Solver, expansions: int, horizon: int) -> SolverHistory:
+        self.value_function, hist = solver.solve(self.model, expansions, horizon)
+        return hist
+
+    def get_best_action(self, belief):
+        """``actions[argmax_v b.alpha_v]`` for one ``Belief`` (returns int) or a ``[n,S]`` array (``:3005-3034``)."""
+        vf = self.value_function
+        assert vf is not None, "No value function, training probably has to be run..."
+        single = isinstance(belief, Belief)
+        arr = belief.values[None, :] if single else belief
+        if vf.is_on_gpu:
+            eng = vf.model.engine
+            eng.sync_rows('alpha', vf.alpha_vector_list, lambda v: v.values)
+            eng.set_beliefs(arr)
+            best = eng.max_value_resident()[1]
+        else:
+            best = np.argmax(np.matmul(arr, vf.alpha_vector_array.T), axis=1)
+        acts = vf.actions[best]
+        return int(acts[0]) if single else acts
+
+    def simulate(self, simulator: Union[Simulation, None] = None, max_steps: int = 1000,
+                 start_state: Union[int, None] = None, initial_belief: Union[Belief, None] = None,
+                 print_progress: bool = True, print_stats: bool = True) -> SimulationHistory:
+        assert self.value_function is not None, "No value function, training probably has to be run..."
+        self.model = self.model.gpu_model if self.value_function.is_on_gpu else self.model.cpu_model
+        simulator = Simulation(self.model) if simulator is None else simulator
+        s = simulator.initialize_simulation(start_state=start_state)
+        belief = Belief(self.model) if initial_belief is None else initial_belief
+        history = SimulationHistory(self.model, start_state=s, start_belief=belief)
+        t0 = datetime.now()
+        for _ in range(max_steps):
+            a = self.get_best_action(belief)
+            r, o = simulator.run_action(a)
+            belief = belief.update(a, o)
+            history.add(action=a, next_state=simulator.agent_state, next_belief=belief, reward=r, observation=o)
+            if simulator.is_done:
+                break
+        if print_stats:
+            print('Simulation done:')
+            print(f'\t- Runtime (s): {(datetime.now() - t0).total_seconds()}')
+            print(f'\t- Steps: {len(history.states)}')
+            print(f'\t- Total rewards: {sum(history.rewards)}')
+            print(f'\t- End state: {self.model.state_labels[history.states[-1]]}')
+        return history
+
+    def run_n_simulations(self, simulator: Union[Simulation, None] = None, n: int = 1000, max_steps: int = 1000,
+                          start_states: Union[list, int, None] = None, initial_beliefs=None,
+                          reward_discount: float = 0.99, print_progress: bool = True, print_stats: bool = True):
+        simulator = Simulation(self.model) if simulator is None else simulator
+        assert (not isinstance(start_states, list)) or (len(start_states) == n), 'The size of the list of start states has to match n'
+        assert (not isinstance(initial_beliefs, list)) or (len(initial_beliefs) == n), 'The size of the list of initial beliefs has to match n'
+        t0 = datetime.now()
+        histories, totals, discounted, done = [], RewardSet(), [], 0
+        for i in range(n):
+            h = self.simulate(simulator=simulator, max_steps=max_steps,
+                              start_state=(start_states[i] if isinstance(start_states, list) else start_states),
+                              initial_belief=(initial_beliefs[i] if isinstance(initial_beliefs, list) else initial_beliefs),
+                              print_progress=False, print_stats=False)
+            done += int(simulator.is_done)
+            histories.append(h)
+            totals.append(np.sum(h.rewards))
+            discounted.append(h.rewards.get_total_discounted_reward(reward_discount))
+        if print_stats:
+            print(f'All {n} simulations done:')
+            print(f'\t- Average runtime (s): {(datetime.now() - t0).total_seconds() / n}')
+            print(f'\t- Simulations reached goal: {done}/{n} ({n - done} failures)')
+            print(f'\t- Average step count: {sum(len(h) for h in histories) / n}')
+            print(f'\t- Average total rewards: {sum(totals) / n}')
+            print(f'\t- Average discounted rewards (ADR): {sum(discounted) / n}')
+        return totals, histories
+
+    def run_n_simulations_parallel(self, n: int = 1000, simulator_set: Union[SimulationSet, None] = None,
+                                   max_steps: int = 1000, start_states: Union[list, int, None] = None,
+                                   initial_beliefs=None, reward_discount: float = 0.99,
+                                   print_progress: bool = True, print_stats: bool = True):
+        """n simulations advanced in lock-step (``src/pomdp.py:3203-3380``).  Per step: best α per belief
+        (GEMM + first-max), host simulator draw, Bayes update of every belief, done-filter.  With the value
+        function on the GPU the belief block lives in the HIP engine for the whole run; only the ``[n]`` index,
+        action and observation vectors cross the boundary each step."""
+        vf = self.value_function
+        assert vf is not None, "No value function, training probably has to be run..."
+        on_gpu = vf.is_on_gpu
+        model = self.model.gpu_model if on_gpu else self.model.cpu_model
+        assert (not isinstance(start_states, list)) or (len(start_states) == n), 'The size of the list of start states has to match n'
+        assert (not isinstance(initial_beliefs, list)) or (len(initial_beliefs) == n), 'The size of the list of initial beliefs has to match n'
+
+        if initial_beliefs is None:
+            b0 = np.repeat(Belief(model).values[None, :], n, axis=0)
+        elif isinstance(initial_beliefs, Belief):
+            b0 = np.repeat(initial_beliefs.values[None, :], n, axis=0)
+        else:
+            b0 = np.array([b.values for b in initial_beliefs])
+
+        simulator_set = SimulationSet(model) if simulator_set is None else simulator_set
+        start_state_array = simulator_set.initialize_simulations(n, start_states)
+        block = (_DeviceBeliefBlock if on_gpu else _HostBeliefBlock)(model, vf, b0)
+
+        done_at_step = np.full(n, -1, dtype=int)
+        alive = np.arange(n)
+        discount = reward_discount
+        rewards_history = np.zeros((max_steps, n))
+        discounted_history = np.zeros((max_steps, n))
+        states_history = np.empty((max_steps + 1, n))
+        states_history[0] = start_state_array
+        actions_history = np.empty((max_steps, n))
+        observations_history = np.empty((max_steps, n))
+
+        t0 = datetime.now()
+        for i in range(max_steps):
+            best_actions = vf.actions[block.best_vectors()]
+            rewards, observations = simulator_set.run_actions(best_actions)
+            finished = simulator_set.is_done
+            block.advance(best_actions, observations, ~finished)
+
+            rewards_history[i, alive] = rewards
+            discounted_history[i, alive] = rewards * discount
+            states_history[i + 1, alive] = simulator_set.agent_states
+            actions_history[i, alive] = best_actions
+            observations_history[i, alive] = observations
+            done_at_step[alive[finished]] = i
+
+            alive = alive[~finished]
+            simulator_set.n = len(alive)
+            simulator_set.agent_states = simulator_set.agent_states[~finished]
+            simulator_set.simulations = simulator_set.simulations[~finished]
+            simulator_set.is_done = finished[~finished]
+            discount *= reward_discount
+            if len(alive) == 0:
+                break
+
+        histories, steps_sum = [], 0
+        b_start = Belief(model)
+        for i, s0 in enumerate(start_state_array):
+            h = SimulationHistory(self.model, int(s0), b_start)
+            last = int(done_at_step[i]) if done_at_step[i] >= 0 else max_steps
+            steps_sum += last
+            h.states = states_history[:last + 1, i].tolist()
+            h.actions = actions_history[:last, i].tolist()
+            h.observations = observations_history[:last, i].tolist()
+            h.rewards = rewards_history[:last, i].tolist()
+            histories.append(h)
+        n_done = int(np.sum(done_at_step >= 0))
+        if print_stats:
+            print(f'All {n} simulations done in {(datetime.now() - t0).total_seconds():.3f}s:')
+            print(f'\t- Simulations reached goal: {n_done}/{n} ({n - n_done} failures)')
+            print(f'\t- Average step count: {steps_sum / n}')
+            print(f'\t- Average total rewards: {np.sum(rewards_history) / n}')
+            print(f'\t- Average discounted rewards (ADR): {np.sum(discounted_history) / n}')
+        return RewardSet(np.sum(rewards_history, axis=0).tolist()), histories
 
 
 # --------------------------------------------------------------------------- #

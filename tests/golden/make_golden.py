@@ -277,7 +277,68 @@ def gen_full():
         print(f'  stored; keep={int(keep.sum())}/{B}', flush=True)
 
 
+# --------------------------------------------------------------------------- #
+def _pack_histories(hists):
+    """Ragged per-simulation sequences -> flat arrays + lengths."""
+    return dict(n_steps=np.array([len(h.actions) for h in hists], dtype=np.int32),
+                states=np.concatenate([np.asarray(h.states, dtype=np.int32) for h in hists]),
+                actions=np.concatenate([np.asarray(h.actions, dtype=np.int8) for h in hists]),
+                observations=np.concatenate([np.asarray(h.observations, dtype=np.int8) for h in hists]),
+                rewards=np.concatenate([np.asarray(h.rewards, dtype=np.float64) for h in hists]))
+
+
+def gen_sim():
+    """Policy evaluation: the reference's Agent.run_n_simulations_parallel / simulate, seeded, on the
+    synthetic olfactory models at S=600 with a value function the reference's FSVI solver produced, and single
+    simulations on tiger.  Stored: the value function, the seeds and every trajectory."""
+    import random as pyrandom
+    for R in (1, 5):
+        m = synth.olfactory_model(H=15, W=40, R=R, f32=False)      # f64 tables: np.random.choice needs exact row sums
+        model = ref_model_from_synth(m)
+        np.random.seed(0)
+        pyrandom.seed(0)
+        solver = ref.FSVI_Solver(gamma=m.gamma, eps=1e-6)
+        vf, _ = quiet(solver.solve, model, expansions=12, max_belief_growth=20, print_progress=False)
+        alpha = np.array(vf.alpha_vector_array)
+        acts = np.asarray(vf.actions, dtype=np.int64)
+        agent = ref.Agent(model, vf)
+        out = {}
+        # R > 1: the reference indexes the sampled successor as potentials[chosen][:, 0, 0] (src/pomdp.py:2928), which
+        # raises IndexError once fewer than R simulations are alive; short horizons keep its run inside what it can do.
+        for tag, n, steps, seed in ((('par', 96, 80, 123), ('par2', 300, 40, 7)) if R == 1 else
+                                    (('par', 96, 12, 123), ('par2', 300, 8, 7))):
+            np.random.seed(seed)
+            pyrandom.seed(seed)
+            totals, hists = quiet(agent.run_n_simulations_parallel, n=n, max_steps=steps, print_progress=False, print_stats=False)
+            for k, v in _pack_histories(hists).items():
+                out[f'{tag}_{k}'] = v
+            out[f'{tag}_totals'] = np.asarray(totals, dtype=np.float64)
+            out[f'{tag}_cfg'] = np.array([n, steps, seed])
+            print(f'sim R={R} {tag}: n={n} reached={int(sum(t > 0 for t in totals))} mean steps={np.mean(out[tag + "_n_steps"]):.1f}')
+        np.random.seed(11)
+        pyrandom.seed(11)
+        _, hists = quiet(agent.run_n_simulations, n=6, max_steps=60, print_progress=False, print_stats=False)
+        for k, v in _pack_histories(hists).items():
+            out[f'seq_{k}'] = v
+        out['seq_cfg'] = np.array([6, 60, 11])
+        np.savez_compressed(os.path.join(HERE, f'olfactory_sim_R{R}.npz'), H=m.H, W=m.W, R=R, gamma=m.gamma,
+                            alpha=alpha, alpha_actions=acts.astype(np.int8), **out)
+        print(f'sim R={R}: |V|={len(acts)}')
+
+    model, solver = quiet(ref.load_POMDP_file, os.path.join(EXAMPLES, 'tiger.95.POMDP'))
+    model.end_actions = [1, 2]
+    vf, _ = quiet(solver.solve, model, expansions=8, update_passes=8, print_progress=False)
+    agent = ref.Agent(model, vf)
+    np.random.seed(5)
+    pyrandom.seed(5)
+    _, hists = quiet(agent.run_n_simulations, n=40, max_steps=30, print_progress=False, print_stats=False)
+    np.savez_compressed(os.path.join(HERE, 'tiger_sim.npz'), alpha=np.array(vf.alpha_vector_array),
+                        alpha_actions=np.asarray(vf.actions, dtype=np.int8), cfg=np.array([40, 30, 5]),
+                        **_pack_histories(hists))
+    print(f'tiger sim: mean steps {np.mean([len(h.actions) for h in hists]):.2f}')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['small', 'kat', 'c2']
     for w in which:
-        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full}[w]()
+        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim}[w]()

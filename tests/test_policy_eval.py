@@ -1,0 +1,229 @@
+"""Policy evaluation: Agent / Simulation / SimulationSet against trajectories the
+reference produced (tests/golden/make_golden.py sim; seeds stored in the fixtures).
+
+CPU tests run the host mirror (the reference's NumPy statements); GPU tests run the same calls with the value
+function on the GPU, where the belief block lives in the HIP engine (pbvi_value_max + pbvi_beliefs_advance).
+Trajectories are integer sequences: the bar is exact equality.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from pomdp_pbvi_exploration_amd import synth
+from pomdp_pbvi_exploration_amd.pomdp import (Agent, Belief, Model, Simulation, SimulationSet, ValueFunction,
+                                              load_POMDP_file)
+from pomdp_pbvi_exploration_amd.mdp import RewardSet
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load_npz(name):
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def mirror_model(m: synth.SynthModel) -> Model:
+    """Host-mirror Model over the synthetic tables, built the way make_golden.ref_model_from_synth builds the
+    reference's."""
+    model = Model(states=m.S, actions=m.A, observations=m.O, reachable_states=m.reachable_states,
+                  observation_table=m.observation_table, end_states=[m.goal], start_probabilities=list(m.start_belief))
+    if m.R == 1:
+        assert np.array_equal(model.reachable_transitional_observation_table, m.rto)
+    else:
+        model.reachable_probabilities = m.reachable_probabilities
+        model.reachable_transitional_observation_table = m.rto
+        model.expected_rewards_table = m.expected_rewards
+    return model
+
+
+def unpack(z, tag):
+    """Flat fixture arrays -> per-simulation lists."""
+    n_steps = z[f'{tag}_n_steps'] if tag else z['n_steps']
+    key = (lambda k: f'{tag}_{k}') if tag else (lambda k: k)
+    out, so, ao = [], 0, 0
+    for n in n_steps:
+        n = int(n)
+        out.append(dict(states=z[key('states')][so:so + n + 1], actions=z[key('actions')][ao:ao + n],
+                        observations=z[key('observations')][ao:ao + n], rewards=z[key('rewards')][ao:ao + n]))
+        so += n + 1
+        ao += n
+    return out
+
+
+def assert_histories(hists, want):
+    assert len(hists) == len(want)
+    for i, (h, w) in enumerate(zip(hists, want)):
+        assert np.array_equal(np.asarray(h.states, dtype=np.int64), w['states']), f'states of simulation {i}'
+        assert np.array_equal(np.asarray(h.actions, dtype=np.int64), w['actions']), f'actions of simulation {i}'
+        assert np.array_equal(np.asarray(h.observations, dtype=np.int64), w['observations']), f'observations of simulation {i}'
+        assert np.array_equal(np.asarray(h.rewards, dtype=np.float64), w['rewards']), f'rewards of simulation {i}'
+
+
+def olfactory_agent(R: int, on_gpu: bool = False, dtype: str = 'f64'):
+    z = load_npz(f'olfactory_sim_R{R}.npz')
+    m = synth.olfactory_model(H=int(z['H']), W=int(z['W']), R=R, f32=False)
+    model = mirror_model(m)
+    vf = ValueFunction(model, z['alpha'], z['alpha_actions'].astype(int))
+    if on_gpu:
+        model = model.to_gpu(dtype)
+        vf = vf.to_gpu()
+    return z, model, Agent(model, vf)
+
+
+def run_parallel(agent, z, tag):
+    n, steps, seed = (int(x) for x in z[f'{tag}_cfg'])
+    np.random.seed(seed)
+    random.seed(seed)
+    totals, hists = agent.run_n_simulations_parallel(n=n, max_steps=steps, print_progress=False, print_stats=False)
+    return totals, hists
+
+
+# --------------------------------------------------------------------------- #
+# host (CPU) mirror
+# --------------------------------------------------------------------------- #
+def test_reward_set_discounting():
+    rs = RewardSet([1.0, 0.0, 2.0])
+    assert rs.get_total_discounted_reward(0.5) == 1.0 + 2.0 * 0.25
+    assert RewardSet().get_total_discounted_reward(0.9) == 0.0
+
+
+@pytest.mark.parametrize('R', [1, 5])
+@pytest.mark.parametrize('tag', ['par', 'par2'])
+def test_parallel_simulations_match_reference_host(R, tag):
+    z, _, agent = olfactory_agent(R)
+    totals, hists = run_parallel(agent, z, tag)
+    assert_histories(hists, unpack(z, tag))
+    assert isinstance(totals, RewardSet)
+    np.testing.assert_array_equal(np.asarray(totals), z[f'{tag}_totals'])
+
+
+@pytest.mark.parametrize('R', [1, 5])
+def test_sequential_simulations_match_reference_host(R):
+    z, _, agent = olfactory_agent(R)
+    n, steps, seed = (int(x) for x in z['seq_cfg'])
+    np.random.seed(seed)
+    random.seed(seed)
+    totals, hists = agent.run_n_simulations(n=n, max_steps=steps, print_progress=False, print_stats=False)
+    assert_histories(hists, unpack(z, 'seq'))
+    # the belief sequence is rebuilt from (a, o) pairs and stays a distribution
+    b = hists[0].beliefs
+    assert len(b) == len(hists[0].states)
+    assert abs(float(np.sum(b[-1].values)) - 1.0) < 1e-9
+
+
+def test_tiger_simulations_match_reference_host():
+    z = load_npz('tiger_sim.npz')
+    model, _ = load_POMDP_file(os.path.join(GOLDEN, 'models', 'tiger.95.POMDP'))
+    model.end_actions = [1, 2]
+    agent = Agent(model, ValueFunction(model, z['alpha'], z['alpha_actions'].astype(int)))
+    n, steps, seed = (int(x) for x in z['cfg'])
+    np.random.seed(seed)
+    random.seed(seed)
+    _, hists = agent.run_n_simulations(n=n, max_steps=steps, print_progress=False, print_stats=False)
+    assert_histories(hists, unpack(z, ''))
+
+
+def test_simulation_set_start_states_and_done_filter():
+    _, model, agent = olfactory_agent(1)
+    sims = SimulationSet(model)
+    assert np.array_equal(sims.initialize_simulations(5, 7), np.full(5, 7))
+    assert np.array_equal(sims.initialize_simulations(5, [1, 2]), np.array([1, 1, 1, 2, 2]))
+    # starting next to the goal with the move that enters it ends the run in one step with reward 1
+    goal = model.end_states[0]
+    src = int(np.flatnonzero(model.reachable_states[:, 1, 0] == goal)[0])
+    sims.initialize_simulations(3, src)
+    r, o = sims.run_actions(np.array([1, 1, 1]))
+    assert np.array_equal(r, [1, 1, 1]) and sims.is_done.all() and np.array_equal(o, [2, 2, 2])
+    # list lengths are checked like the reference does
+    with pytest.raises(AssertionError):
+        agent.run_n_simulations_parallel(n=3, start_states=[1, 2], print_progress=False, print_stats=False)
+
+
+def test_reference_indexing_switch_changes_only_stochastic_models():
+    """R > 1: the reference's successor indexing (src/pomdp.py:2928) is kept by default; the corrected form picks
+    rs[s_i, a_i, chosen_i]."""
+    _, model, _ = olfactory_agent(5)
+    sims = SimulationSet(model)
+    sims.reference_indexing = False
+    np.random.seed(3)
+    s0 = sims.initialize_simulations(64).copy()
+    acts = np.zeros(64, dtype=int)
+    sims.run_actions(acts)
+    ok = [sims.agent_states[i] in model.reachable_states[s0[i], 0] for i in range(64)]
+    assert all(ok)
+
+
+def test_single_simulation_records_beliefs():
+    _, model, agent = olfactory_agent(1)
+    np.random.seed(2)
+    h = agent.simulate(Simulation(model), max_steps=15, print_progress=False, print_stats=False)
+    assert len(h.beliefs) == len(h.states) == len(h.actions) + 1
+    b = Belief(model)
+    for a, o in zip(h.actions, h.observations):
+        b = b.update(a, o)
+    assert np.array_equal(b.values, h.beliefs[-1].values)
+
+
+# --------------------------------------------------------------------------- #
+# HIP engine
+# --------------------------------------------------------------------------- #
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+@pytest.mark.parametrize('R,tag', [(1, 'par'), (1, 'par2'), (5, 'par'), (5, 'par2')])
+def test_parallel_simulations_match_reference_gpu(R, tag, dtype):
+    """Belief block resident in the engine for the whole run; trajectories equal the reference's."""
+    z, _, agent = olfactory_agent(R, on_gpu=True, dtype=dtype)
+    totals, hists = run_parallel(agent, z, tag)
+    assert_histories(hists, unpack(z, tag))
+    np.testing.assert_array_equal(np.asarray(totals), z[f'{tag}_totals'])
+
+
+@pytest.mark.gpu
+def test_single_simulations_gpu():
+    z, _, agent = olfactory_agent(1, on_gpu=True)
+    n, steps, seed = (int(x) for x in z['seq_cfg'])
+    np.random.seed(seed)
+    random.seed(seed)
+    _, hists = agent.run_n_simulations(n=n, max_steps=steps, print_progress=False, print_stats=False)
+    assert_histories(hists, unpack(z, 'seq'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,B', [('f64', 40), ('f32', 40), ('f32', 700)])
+def test_beliefs_advance_matches_host_update(dtype, B):
+    """pbvi_beliefs_advance: in-place Bayes step + done-filter equals Belief.update row by row (B=700 exercises the
+    sorted belief block of the f32 engine)."""
+    from pomdp_pbvi_exploration_amd.engine import Engine
+    m = synth.olfactory_model(H=15, W=40, R=5)
+    model = mirror_model(m)
+    rng = np.random.default_rng(4)
+    b = synth.belief_points(m, B, max_depth=12)
+    acts = rng.integers(0, m.A, size=B)
+    obs = np.zeros(B, dtype=int)
+    want = []
+    for i in range(B):                      # pick an observation with non-zero likelihood
+        for o in rng.permutation(m.O):
+            nb = Belief(model, b[i]).update(int(acts[i]), int(o)).values
+            if np.isfinite(nb).all():
+                obs[i] = o
+                want.append(nb)
+                break
+    want = np.array(want)
+    keep = rng.random(B) < 0.7
+    eng = Engine.for_model(model, dtype=dtype)
+    eng.set_beliefs(b)
+    assert eng.advance_beliefs(acts, obs, keep) == int(keep.sum())
+    got = eng.fetch_beliefs()
+    tol = 1e-12 if dtype == 'f64' else 2e-6
+    np.testing.assert_allclose(got, want[keep], rtol=tol, atol=tol * 1e-2)
+    # a second step without a filter keeps every row
+    a2 = rng.integers(0, m.A, size=eng.B)
+    o2 = np.zeros(eng.B, dtype=int)
+    assert eng.advance_beliefs(a2, o2) == int(keep.sum())
+    # dropping everything leaves no resident block
+    assert eng.advance_beliefs(a2, o2, np.zeros(eng.B, dtype=bool)) == 0
+    with pytest.raises(ValueError):
+        eng.max_value_resident()
+    eng.close()
