@@ -214,6 +214,20 @@ int pbvi_beliefs_advance(pbvi_engine_t* e, const int32_t* actions, const int32_t
 int pbvi_beliefs_fetch(pbvi_engine_t* e, void* out_beliefs);
 int64_t pbvi_beliefs_count(const pbvi_engine_t* e);
 
+/*
+ * MDP value iteration on the device (VI_Solver.solve, src/mdp.py:1442-1525; seeds FSVI / HSVI):
+ *   rows[a][s] = ER[s,a] + gamma * sum_r P[s,a,r] * v[rs[s,a,r]];   v'[s] = max_a rows[a][s]
+ * repeated from v0 until max_s |v' - v| < max_change_limit (the reference's eps * gamma / (1 - gamma)) or
+ * `horizon` sweeps.  Always fp64.  Not tied to an engine handle (the MDP tables are not the POMDP's).
+ *   reach_states [S][A][R] int32, reach_prob [S][A][R], exp_reward [S][A], v0 [S]   (NumPy C-order)
+ *   out_rows [A][S]: rows of the last sweep (the solution's alpha-vectors, before the container's dedup)
+ *   out_changes [horizon] (may be NULL): max change of each sweep that ran;  out_iterations (may be NULL).
+ */
+int pbvi_mdp_value_iteration(int device, int32_t S, int32_t A, int32_t R, const int32_t* reach_states,
+                             const double* reach_prob, const double* exp_reward, const double* v0, double gamma,
+                             double max_change_limit, int32_t horizon, double* out_rows, double* out_changes,
+                             int32_t* out_iterations);
+
 /* Tuning knob for f32 engines: relative half-width of the near-tie window that sends an
  * argmax to fp64 refinement (<= 0 restores the default derived from |S|). */
 int pbvi_set_tie_window(pbvi_engine_t* e, double rel);

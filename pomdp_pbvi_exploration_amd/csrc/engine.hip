@@ -1095,6 +1095,126 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     return PBVI_OK;
 }
 
+// --------------------------------------------------------------------------- //
+// MDP value iteration (VI_Solver.solve, src/mdp.py:1485-1510).  One thread per state, tables re-tiled [A][R][S] so
+// every load is coalesced; HBM/latency-bound (A*R gathers per state per sweep).  Products and sums are kept
+// un-fused (fp contract off) so R = 1 reproduces NumPy's  ER + gamma * (P * v)  bit for bit.
+// Sweep `it` leaves at once when sweep it-1 already met the change limit, so the host can enqueue sweeps in
+// batches without syncing; the rows / values of the converged sweep stay in place.
+// --------------------------------------------------------------------------- //
+__global__ void k_vi_sweep(int S, int A, int R, const int32_t* __restrict__ rs, const double* __restrict__ prob,
+                           const double* __restrict__ er, double gamma, double limit, int it,
+                           const double* __restrict__ v_in, double* __restrict__ v_out, double* __restrict__ rows,
+                           double* __restrict__ changes) {
+#pragma clang fp contract(off)   // no FMA fusion: every product and sum rounds like NumPy's separate ufuncs
+    if (it > 0 && changes[it - 1] < limit) return;
+    __shared__ double red[4];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    double diff = 0.0;
+    if (s < S) {
+        double best = 0.0;
+        for (int a = 0; a < A; ++a) {
+            double acc = 0.0;
+            for (int r = 0; r < R; ++r) {
+                const int64_t k = ((int64_t)a * R + r) * S + s;
+                const double t = prob[k] * v_in[rs[k]];
+                acc = r == 0 ? t : acc + t;
+            }
+            const double scaled = gamma * acc;
+            const double row = er[(int64_t)a * S + s] + scaled;
+            rows[(int64_t)a * S + s] = row;
+            best = (a == 0 || row > best) ? row : best;
+        }
+        v_out[s] = best;
+        diff = fabs(best - v_in[s]);
+    }
+    // block max, then one atomic per block (non-negative doubles order like their bit patterns)
+    for (int off = 32; off > 0; off >>= 1) diff = fmax(diff, __shfl_xor(diff, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = diff;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        atomicMax(reinterpret_cast<unsigned long long*>(&changes[it]), (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+static int mdp_value_iteration(int device, int S, int A, int R, const int32_t* rs, const double* prob, const double* er,
+                               const double* v0, double gamma, double limit, int horizon, double* out_rows,
+                               double* out_changes, int32_t* out_iterations) {
+    if (S <= 0 || A <= 0 || R <= 0 || horizon < 0 || !rs || !prob || !er || !v0 || !out_rows)
+        FAIL(PBVI_EINVAL, "mdp_value_iteration: bad arguments");
+    if ((int64_t)S * A * R > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "mdp_value_iteration: S*A*R exceeds int32");
+    const size_t n = (size_t)S * A * R;
+    std::vector<int32_t> h_rs(n);
+    std::vector<double> h_p(n), h_er((size_t)S * A);
+    for (int s = 0; s < S; ++s)
+        for (int a = 0; a < A; ++a) {
+            h_er[(size_t)a * S + s] = er[(size_t)s * A + a];
+            for (int r = 0; r < R; ++r) {
+                const size_t src = ((size_t)s * A + a) * R + r, dst = ((size_t)a * R + r) * S + s;
+                if (rs[src] < 0 || rs[src] >= S) FAIL(PBVI_EINVAL, "mdp_value_iteration: reachable state out of range");
+                h_rs[dst] = rs[src];
+                h_p[dst] = prob[src];
+            }
+        }
+    HIPCHK(hipSetDevice(device));
+    int64_t bytes = 0;
+    DevBuf d_rs, d_p, d_er, d_v[2], d_rows, d_ch;
+    struct Guard {
+        DevBuf* b[7];
+        hipStream_t st = nullptr;
+        ~Guard() {
+            for (DevBuf* x : b) x->release();
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } guard{{&d_rs, &d_p, &d_er, &d_v[0], &d_v[1], &d_rows, &d_ch}};
+    int rc;
+    if ((rc = d_rs.ensure(n * sizeof(int32_t), &bytes))) return rc;
+    if ((rc = d_p.ensure(n * sizeof(double), &bytes))) return rc;
+    if ((rc = d_er.ensure((size_t)S * A * sizeof(double), &bytes))) return rc;
+    if ((rc = d_v[0].ensure((size_t)S * sizeof(double), &bytes))) return rc;
+    if ((rc = d_v[1].ensure((size_t)S * sizeof(double), &bytes))) return rc;
+    if ((rc = d_rows.ensure((size_t)S * A * sizeof(double), &bytes))) return rc;
+    if ((rc = d_ch.ensure((size_t)std::max(horizon, 1) * sizeof(double), &bytes))) return rc;
+    HIPCHK(hipStreamCreateWithFlags(&guard.st, hipStreamNonBlocking));
+    hipStream_t st = guard.st;
+    HIPCHK(hipMemcpyAsync(d_rs.p, h_rs.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_p.p, h_p.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_er.p, h_er.data(), (size_t)S * A * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_v[0].p, v0, (size_t)S * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_ch.p, 0, (size_t)std::max(horizon, 1) * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(d_rows.p, 0, (size_t)S * A * sizeof(double), st));
+    std::vector<double> ch((size_t)std::max(horizon, 1), 0.0);
+    int done = 0;              // sweeps that ran
+    bool converged = false;
+    const int batch = 64;
+    for (int it0 = 0; it0 < horizon && !converged; it0 += batch) {
+        const int it1 = std::min(horizon, it0 + batch);
+        for (int it = it0; it < it1; ++it) {
+            hipLaunchKernelGGL(k_vi_sweep, dim3((S + 255) / 256), dim3(256), 0, st, S, A, R, d_rs.as<int32_t>(),
+                               d_p.as<double>(), d_er.as<double>(), gamma, limit, it, d_v[it & 1].as<double>(),
+                               d_v[(it + 1) & 1].as<double>(), d_rows.as<double>(), d_ch.as<double>());
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(ch.data() + it0, d_ch.as<double>() + it0, (size_t)(it1 - it0) * sizeof(double),
+                              hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int it = it0; it < it1; ++it) {
+            done = it + 1;
+            if (ch[(size_t)it] < limit) {
+                converged = true;
+                break;
+            }
+        }
+    }
+    HIPCHK(hipMemcpyAsync(out_rows, d_rows.p, (size_t)S * A * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (out_changes)
+        for (int it = 0; it < done; ++it) out_changes[it] = ch[(size_t)it];
+    if (out_iterations) *out_iterations = done;
+    return PBVI_OK;
+}
+
 }  // namespace pbvi
 
 // --------------------------------------------------------------------------- //
@@ -1260,6 +1380,14 @@ int pbvi_beliefs_fetch(pbvi_engine_t* e, void* out_beliefs) {
 }
 
 int64_t pbvi_beliefs_count(const pbvi_engine_t* e) { return (e && e->impl) ? e->impl->beliefs_count() : -1; }
+
+int pbvi_mdp_value_iteration(int device, int32_t S, int32_t A, int32_t R, const int32_t* reach_states,
+                             const double* reach_prob, const double* exp_reward, const double* v0, double gamma,
+                             double max_change_limit, int32_t horizon, double* out_rows, double* out_changes,
+                             int32_t* out_iterations) {
+    return pbvi::mdp_value_iteration(device, S, A, R, reach_states, reach_prob, exp_reward, v0, gamma, max_change_limit,
+                                     horizon, out_rows, out_changes, out_iterations);
+}
 
 int pbvi_belief_update(pbvi_engine_t* e, const int32_t* actions, const int32_t* observations, void* out_beliefs) {
     NEED(e);

@@ -28,6 +28,7 @@ EXPORTS = [
     'pbvi_alpha_store_append', 'pbvi_alpha_select', 'pbvi_alpha_store_reset',
     'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset', 'pbvi_debug_poison',
     'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
+    'pbvi_mdp_value_iteration',
 ]
 
 
@@ -95,6 +96,8 @@ def load_library(path: str = LIB_PATH):
         'pbvi_beliefs_advance': (C.c_int, [vp, i32p, i32p, u8p, C.POINTER(C.c_int64)]),
         'pbvi_beliefs_fetch': (C.c_int, [vp, vp]),
         'pbvi_beliefs_count': (C.c_int64, [vp]),
+        'pbvi_mdp_value_iteration': (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int32, i32p, f64p, f64p, f64p,
+                                               C.c_double, C.c_double, C.c_int32, f64p, f64p, i32p]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -113,6 +116,31 @@ def debug_poison(enable: bool) -> bool:
 
 def device_count() -> int:
     return int(load_library().pbvi_device_count())
+
+
+def mdp_value_iteration(reach_states: np.ndarray, reach_prob: np.ndarray, exp_reward: np.ndarray, v0: np.ndarray,
+                        gamma: float, max_change_limit: float, horizon: int, device: int = 0):
+    """MDP value-iteration sweeps on the device (``VI_Solver.solve``, ``src/mdp.py:1485-1510``).
+    Returns ``(rows [A,S] f64, changes [iterations] f64)``."""
+    lib = load_library()
+    S, A, R = reach_states.shape
+    if int(reach_states.min()) < 0 or int(reach_states.max()) >= S:
+        raise ValueError('reachable state out of range')
+    rs = np.ascontiguousarray(reach_states, dtype=np.int32)
+    p = np.ascontiguousarray(reach_prob, dtype=np.float64)
+    er = np.ascontiguousarray(exp_reward, dtype=np.float64)
+    v = np.ascontiguousarray(v0, dtype=np.float64)
+    if p.shape != (S, A, R) or er.shape != (S, A) or v.shape != (S,):
+        raise ValueError('mdp_value_iteration: table shapes do not agree')
+    rows = np.empty((A, S), dtype=np.float64)
+    changes = np.zeros(max(int(horizon), 1), dtype=np.float64)
+    its = C.c_int32(0)
+    f64p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    _check(lib.pbvi_mdp_value_iteration(int(device), S, A, R, rs.ctypes.data_as(i32p), p.ctypes.data_as(f64p),
+                                        er.ctypes.data_as(f64p), v.ctypes.data_as(f64p), float(gamma),
+                                        float(max_change_limit), int(horizon), rows.ctypes.data_as(f64p),
+                                        changes.ctypes.data_as(f64p), C.byref(its)))
+    return rows, changes[:its.value]
 
 
 def _check(rc: int) -> None:

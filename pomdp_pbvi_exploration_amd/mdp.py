@@ -16,6 +16,7 @@ raises -- there is no silent CPU fallback.
 """
 from __future__ import annotations
 
+import os
 import random
 from datetime import datetime
 from typing import Tuple, Union
@@ -335,6 +336,48 @@ class ValueFunction:
         cm = self.model.cpu_model
         return ValueFunction(cm, [AlphaVector(np.asarray(v.values, dtype=np.float64), v.action) for v in self.alpha_vector_list])
 
+    # -- on-disk formats (src/mdp.py:909-1036): one row per alpha-vector, columns ``action, <state labels>`` -- #
+    def _frame(self, path: str):
+        import pandas as pd
+        if not os.path.exists(path):
+            print('Folder does not exist yet, creating it...')
+            os.makedirs(path)
+        data = np.concatenate((np.asarray(self.actions)[:, None], self.alpha_vector_array), axis=1)
+        return pd.DataFrame(data, columns=['action', *self.model.state_labels])
+
+    @staticmethod
+    def _file_name(file_name: Union[str, None], ext: str) -> str:
+        if file_name is None:
+            file_name = datetime.now().strftime('%Y%m%d_%H%M%S') + '_value_function' + ext
+        return file_name if ext in file_name else file_name + ext
+
+    def save(self, path: str = './ValueFunctions', file_name: Union[str, None] = None, compress: bool = False) -> None:
+        """CSV (optionally gzip, suffix ``.gzip``) in the reference's layout (``src/mdp.py:930-964``)."""
+        df = self._frame(path)
+        name = self._file_name(file_name, '.csv')
+        if compress:
+            name += '.gzip'
+        df.to_csv(path + '/' + name, index=False, compression='gzip' if compress else None)
+
+    def save_parquet(self, path: str = './ValueFunctions', file_name: Union[str, None] = None) -> None:
+        """Parquet in the reference's layout (``src/mdp.py:967-990``)."""
+        self._frame(path).to_parquet(path + '/' + self._file_name(file_name, '.parquet'), index=False)
+
+    @classmethod
+    def load_from_file(cls, file: str, model: Model) -> 'ValueFunction':
+        """Read a CSV (gzip when the name contains ``.gzip``) written by ``save`` or by the reference
+        (``src/mdp.py:993-1013``)."""
+        import pandas as pd
+        rows = pd.read_csv(file, header=0, index_col=False, compression='gzip' if '.gzip' in file else None).to_numpy()
+        return cls(model, alpha_vectors=rows[:, 1:], action_list=rows[:, 0].astype(int))
+
+    @classmethod
+    def load_from_parquet(cls, file: str, model: Model) -> 'ValueFunction':
+        """Read a parquet file written by ``save_parquet`` or by the reference (``src/mdp.py:1016-1036``)."""
+        import pandas as pd
+        rows = pd.read_parquet(file).to_numpy()
+        return cls(model, alpha_vectors=rows[:, 1:], action_list=rows[:, 0].astype(int))
+
     def prune(self, level: int = 1) -> None:
         if level < self._pruning_level or level > 3:
             log("Attempting to prune a value function to a level already reached. Returning 'self'")
@@ -389,7 +432,9 @@ class Solver:
 
 
 class VI_Solver(Solver):
-    """MDP value iteration (``src/mdp.py:1414-1525``); host-side, seeds FSVI/HSVI."""
+    """MDP value iteration (``src/mdp.py:1414-1525``); seeds FSVI/HSVI.  ``use_gpu=True`` runs the sweeps on the
+    device (``pbvi_mdp_value_iteration``): the whole loop is enqueued in batches and only the per-sweep change
+    values come back until convergence."""
 
     def __init__(self, horizon: int = 10000, gamma: float = 0.99, eps: float = 0.001):
         self.horizon = horizon
@@ -402,10 +447,28 @@ class VI_Solver(Solver):
         if initial_value_function is None:
             V = ValueFunction(host, host.expected_rewards_table.T, host.actions)
         else:
-            V = initial_value_function
+            V = initial_value_function.to_cpu() if initial_value_function.is_on_gpu else initial_value_function
         v_opt = np.max(V.alpha_vector_array, axis=0)
         hist = SolverHistory(history_tracking_level, host, self.gamma, self.eps, V)
         limit = self.eps * (self.gamma / (1 - self.gamma))
+        if use_gpu:
+            from .engine import mdp_value_iteration          # raises if the HIP library is missing
+            # per-sweep value functions (tracking level 2+) need every sweep's rows: one sweep per call then
+            step = 1 if history_tracking_level >= 2 else self.horizon
+            left = self.horizon
+            while left > 0:
+                t0 = datetime.now()
+                rows, changes = mdp_value_iteration(host.reachable_states, host.reachable_probabilities,
+                                                    host.expected_rewards_table, v_opt, self.gamma, limit, min(step, left))
+                V = ValueFunction(host, rows, host.actions)
+                v_opt = np.max(V.alpha_vector_array, axis=0)
+                dt = (datetime.now() - t0).total_seconds() / max(len(changes), 1)
+                for c in changes:
+                    hist.add(dt, float(c), V)
+                left -= len(changes)
+                if len(changes) == 0 or changes[-1] < limit:
+                    break
+            return V, hist
         er_t = host.expected_rewards_table.T
         for _ in range(self.horizon):
             t0 = datetime.now()

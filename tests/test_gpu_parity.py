@@ -495,3 +495,47 @@ def test_adversarial_near_ties(S, B):
     assert_alpha_close(res.alpha, new, F32_RTOL)
     assert res.stats['n_refined'] > 0.5 * res.stats['n_pairs']      # refinement did the deciding
     eng.close()
+
+
+# --------------------------------------------------------------------------- #
+# MDP value iteration on the device
+# --------------------------------------------------------------------------- #
+def test_device_value_iteration_reproduces_reference_csv():
+    """The reference's stored VI solution (see tests/test_host_api.py) from the device sweeps: R = 1, so every
+    operation matches NumPy's and the rows are bit-identical to the host solver's."""
+    from pomdp_pbvi_exploration_amd.mdp import VI_Solver
+    from test_host_api import clipped_olfactory_mdp
+    model = clipped_olfactory_mdp()
+    ref = ValueFunction.load_from_file(os.path.join(GOLDEN, 'ref_value_function_61x361.csv.gzip'), model)
+    host_vf, host_hist = VI_Solver(gamma=0.99, eps=1e-4).solve(model, print_progress=False)
+    dev_vf, dev_hist = VI_Solver(gamma=0.99, eps=1e-4).solve(model, use_gpu=True, print_progress=False)
+    assert len(dev_hist.iteration_times) == len(host_hist.iteration_times) == 460
+    assert dev_hist.value_function_changes == host_hist.value_function_changes
+    assert np.array_equal(dev_vf.alpha_vector_array, host_vf.alpha_vector_array)
+    assert np.array_equal(dev_vf.actions, host_vf.actions)
+    np.testing.assert_allclose(dev_vf.alpha_vector_array, ref.alpha_vector_array, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('seed', range(3))
+def test_device_value_iteration_random_mdp(seed):
+    """Stochastic MDPs (R > 1: the sum over r may associate differently from einsum's): 1e-13 relative; horizon
+    cut-offs and per-sweep tracking follow the host solver."""
+    from pomdp_pbvi_exploration_amd.mdp import Model as MDPModel, VI_Solver
+    rng = np.random.default_rng(50 + seed)
+    S, A, R = int(rng.integers(5, 3000)), int(rng.integers(1, 6)), int(rng.integers(2, 6))
+    rs = np.stack([np.stack([rng.choice(S, size=R, replace=False) for _ in range(A)]) for _ in range(S)])
+    model = MDPModel(states=S, actions=A, reachable_states=rs, rewards=lambda s, a, sn: ((s * 7 + a * 3 + sn) % 11) / 10.0)
+    p = rng.random((S, A, R))
+    model.reachable_probabilities = p / p.sum(axis=2, keepdims=True)
+    for horizon, level in ((10000, 1), (7, 1), (5, 2)):
+        solver = VI_Solver(horizon=horizon, gamma=0.9, eps=1e-3)
+        host_vf, host_hist = solver.solve(model, history_tracking_level=level, print_progress=False)
+        dev_vf, dev_hist = solver.solve(model, use_gpu=True, history_tracking_level=level, print_progress=False)
+        assert len(dev_hist.iteration_times) == len(host_hist.iteration_times)
+        np.testing.assert_allclose(dev_hist.value_function_changes, host_hist.value_function_changes, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(dev_vf.alpha_vector_array, host_vf.alpha_vector_array, rtol=1e-13, atol=0)
+        assert np.array_equal(dev_vf.actions, host_vf.actions)
+        if level >= 2:
+            assert len(dev_hist.value_functions) == len(host_hist.value_functions)
+            np.testing.assert_allclose(dev_hist.value_functions[2].alpha_vector_array,
+                                       host_hist.value_functions[2].alpha_vector_array, rtol=1e-13, atol=0)

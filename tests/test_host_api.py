@@ -190,3 +190,52 @@ def test_backup_result_rows_for_value_function():
     res.keep[:] = False
     rows, acts = res.value_function_rows(use_keep=True)
     assert rows.shape == (0, 2) and acts.shape == (0,)
+
+
+# --------------------------------------------------------------------------- #
+# On-disk formats + MDP value iteration
+# --------------------------------------------------------------------------- #
+def clipped_olfactory_mdp(H=61, W=361):
+    """The 61x361 grid of the reference's stored value function: N/E/S/W/stay/stay moves, rows wrap, columns clip,
+    reward 1 on landing in the goal (30, 60)."""
+    from pomdp_pbvi_exploration_amd.mdp import Model as MDPModel
+    S = H * W
+    y, x = np.divmod(np.arange(S), W)
+
+    def nb(dy, dx):
+        return ((y + dy) % H) * W + np.clip(x + dx, 0, W - 1)
+
+    rs = np.stack([nb(-1, 0), nb(0, 1), nb(1, 0), nb(0, -1), np.arange(S), np.arange(S)], axis=1)[:, :, None]
+    return MDPModel(states=S, actions=6, reachable_states=rs, end_states=[(H // 2) * W + 60])
+
+
+def test_value_iteration_reproduces_reference_csv():
+    """KAT: the value function the reference stored (Experiments/Olfactory Navigation/ValueFunctions/
+    20231113_182429_value_function.csv, kept gzip-compressed under tests/golden) is the VI solution of the
+    clipped 61x361 grid at gamma=0.99, eps=1e-4: 460 sweeps from V0 = ER, max 99.0276 = 100(1 - 0.99^461)."""
+    from pomdp_pbvi_exploration_amd.mdp import VI_Solver
+    model = clipped_olfactory_mdp()
+    ref = ValueFunction.load_from_file(os.path.join(GOLDEN, 'ref_value_function_61x361.csv.gzip'), model)
+    assert list(ref.actions) == [0, 1, 2, 3, 5] and ref.alpha_vector_array.shape == (5, 22021)
+    vf, hist = VI_Solver(gamma=0.99, eps=1e-4).solve(model, print_progress=False)
+    assert len(hist.iteration_times) == 460                      # V0 = ER is the first term of the series
+    assert list(vf.actions) == [0, 1, 2, 3, 5]
+    np.testing.assert_allclose(vf.alpha_vector_array, ref.alpha_vector_array, rtol=0, atol=1e-12)
+    assert abs(float(vf.alpha_vector_array.max()) - 100 * (1 - 0.99 ** 461)) < 1e-10
+
+
+def test_value_function_file_round_trips(tmp_path):
+    model = _two_state(0.7)
+    vf = ValueFunction(model, np.array([[0.1, 1 / 3], [2.5, -7.25], [1e-17, 3.0]]), [1, 0, 1])
+    d = str(tmp_path / 'vfs')
+    vf.save(d, 'a')                                   # '.csv' is appended
+    vf.save(d, 'b.csv', compress=True)                # -> b.csv.gzip
+    vf.save_parquet(d, 'c')
+    assert sorted(os.listdir(d)) == ['a.csv', 'b.csv.gzip', 'c.parquet']
+    with open(os.path.join(d, 'a.csv')) as f:
+        assert f.readline().strip() == 'action,s0,s1'  # the reference's header: action, then state labels
+    for back in (ValueFunction.load_from_file(os.path.join(d, 'a.csv'), model),
+                 ValueFunction.load_from_file(os.path.join(d, 'b.csv.gzip'), model),
+                 ValueFunction.load_from_parquet(os.path.join(d, 'c.parquet'), model)):
+        assert np.array_equal(back.alpha_vector_array, vf.alpha_vector_array)
+        assert np.array_equal(back.actions, vf.actions)
