@@ -60,6 +60,8 @@ def main():
     ap.add_argument('--reach', type=int, default=1, choices=[1, 5], help='reachable states per (s,a)')
     ap.add_argument('--cpu-sample', type=int, default=1024, help='beliefs in the CPU baseline sample (0 = skip)')
     ap.add_argument('--grid', type=str, default='75x400')
+    ap.add_argument('--formulation', type=str, default='auto', choices=['auto', 'alpha', 'belief'],
+                    help='operand projected through the model (pbvi_set_formulation)')
     ap.add_argument('--mode', type=str, default='sparse', choices=['sparse', 'dense'],
                     help="projection: reachable-sparse ELL SpMM (BASELINE config 3, the reference's path) or dense "
                          "|A||O| MFMA GEMMs over densified T.O (config 2; 65 GB of matrices at S=30000)")
@@ -91,6 +93,7 @@ def main():
 
     eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32', device=local_rank,
                  mode=args.mode)
+    eng.set_formulation(args.formulation)
     eng.set_alpha(alpha)
     eng.set_beliefs(beliefs)
     shard = EngineShard(eng, m.gamma)

@@ -76,7 +76,7 @@ typedef struct pbvi_stats {
     int64_t project_flops;          /* dense mode: algorithmic 2*A*O*V*S*S of the projection GEMMs, else 0 */
     int64_t project_flops_executed; /* dense mode: MFMA flops issued by the projection GEMMs */
     int32_t split_k;        /* max K-chunks (partial slabs) per tile pair */
-    int32_t reserved;
+    int32_t formulation;    /* which operand was projected: 1 = alpha-vectors (Gamma), 2 = beliefs (pbvi_set_formulation) */
 } pbvi_stats_t;
 
 /* Library / device queries. */
@@ -227,6 +227,15 @@ int pbvi_mdp_value_iteration(int device, int32_t S, int32_t A, int32_t R, const 
                              const double* reach_prob, const double* exp_reward, const double* v0, double gamma,
                              double max_change_limit, int32_t horizon, double* out_rows, double* out_changes,
                              int32_t* out_iterations);
+
+/*
+ * Which operand of the score GEMM is projected through the model (f32 sparse engines; same scores, re-associated):
+ *   1 = alpha-vectors, the reference's order (Gamma[a,o,v,:], src/pomdp.py:1489-1491; GEMM [B] x [A*O*V]);
+ *   2 = beliefs (bp[a,o,b,:] = gamma * sum b[s] RTO[s,a,o,r] scattered to rs[s,a,r]; GEMM [B*A*O] x [V]);
+ *   0 = automatic (default): the cheaper of the two by projected rows and 256-row tile count -- the belief side
+ *       when B << V, e.g. the solve loop's ~100 new beliefs against thousands of alpha-vectors.
+ */
+int pbvi_set_formulation(pbvi_engine_t* e, int formulation);
 
 /* Tuning knob for f32 engines: relative half-width of the near-tie window that sends an
  * argmax to fp64 refinement (<= 0 restores the default derived from |S|). */

@@ -31,12 +31,30 @@ struct SlabView {
     const int* nchunks;   // [tiles_n][tiles_m] or nullptr
     int tiles_m;
     int fixed;
-    __device__ __forceinline__ T at(int row, int64_t col) const {
-        const T* p = slabs + (int64_t)row * ldc + col;
+    // Belief-side formulation (beliefs projected, not alpha-vectors): rows are (observation, action, belief) =
+    // ((o * A + a) * push_B + b) -- observation-major, so the rows of a rarely-seen observation (near-empty after
+    // the RTO product) share 256-row tiles and those tiles are skipped -- columns are the alpha index; the
+    // magnitude scores and reward dots come from side arrays.
+    int push = 0;
+    int push_B = 0, push_A = 1, push_O = 1;
+    const double* aux_mag = nullptr;   // [B][G]  sum_s' |bp[g,b,s']| * max_v|alpha[v,s']|
+    const double* aux_rd = nullptr;    // [B][A]  b . ER[:,a], accumulated in f64
+    __device__ __forceinline__ T at(int64_t row, int64_t col) const {
+        const T* p = slabs + row * ldc + col;
         const int n = nchunks ? nchunks[(col >> 8) * tiles_m + (row >> 8)] : fixed;
         T s = T(0);
         for (int z = 0; z < n; ++z) s += p[(int64_t)z * slab_stride];
         return s;
+    }
+    __device__ __forceinline__ int64_t push_row(int b, int g) const {      // g = a * O + o
+        return ((int64_t)(g % push_O) * push_A + g / push_O) * push_B + b;
+    }
+    // score of (belief b, group g, alpha v); V = columns per group in the alpha-side layout
+    __device__ __forceinline__ T score(int b, int g, int V, int v) const {
+        return push ? at(push_row(b, g), v) : at(b, (int64_t)g * V + v);
+    }
+    __device__ __forceinline__ double magnitude(int b, int g, int G, int V) const {
+        return push ? aux_mag[(int64_t)b * G + g] : (double)at(b, (int64_t)G * V + g);
     }
 };
 
@@ -57,6 +75,18 @@ template <typename T>
 hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const uint8_t* nzB /* [A*O][k_tiles] */,
                        int k_tiles, uint8_t* dead, int32_t* btl /* out: [B][k_tiles] non-zero tile lists */,
                        int32_t* btc /* out: [B] list lengths */, hipStream_t st);
+
+// Belief-side projection: bp[((o*A + a)*B + b)][s'] = gamma * sum_{(s,r): rs[s,a,r] = s'} b[b][s] * RTO[s,a,o,r]  (g = a*O+o), so
+// that bp[g,b,:] . alpha[v,:] == b . Gamma[a,o,v,:] re-associated; accumulated in f64, rounded once to T.
+// mag [B][G] (zeroed by the caller) receives sum_s' |bp| * amax[s'].  in_ptr / in_src: inverse transition lists.
+template <typename T>
+hipError_t launch_push_project(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* in_ptr,
+                               const int32_t* in_src, double gamma, const T* amax, T* bp, int ldp, double* mag,
+                               hipStream_t st);
+// rd[b][a] = b . ER[:,a] in f64 over the belief's non-zero tiles
+template <typename T>
+hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* btl, const int32_t* btc, double* rd,
+                       hipStream_t st);
 
 // first-max argmax over the V columns [g*V, (g+1)*V) of each (row b, group g) of the score matrix;
 // column G*V + g holds the magnitude score (b . Gamma of the max|alpha| row) that scales the tie

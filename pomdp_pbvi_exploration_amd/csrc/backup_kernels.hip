@@ -319,12 +319,11 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
         }
         return;
     }
-    const int64_t col0 = (int64_t)g * V;
     // one pass: running maximum (first index) and runner-up value per lane, merged across the wave
     T m = -std::numeric_limits<T>::infinity(), m2 = -std::numeric_limits<T>::infinity();
     int idx = 0x7fffffff;
     for (int v = lane; v < V; v += 64) {
-        const T sc = sv.at(b, col0 + v);
+        const T sc = sv.score(b, g, V, v);
         if (sc > m || idx == 0x7fffffff) {
             m2 = (idx == 0x7fffffff) ? m2 : m;
             m = sc;
@@ -349,12 +348,13 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
     double E = 0.0;
     int push = 0;
     if (queue != nullptr) {
-        const double mag = fmax(fabs((double)m), fabs((double)sv.at(b, (int64_t)G * V + g)));
+        const double mag = fmax(fabs((double)m), fabs(sv.magnitude(b, g, G, V)));
         // f32 error model: 8 * 2^-24 * sqrt(longest fma chain) (+ slab sums); the chain length is the
         // stream-K share size, known only on the device
         double tr = tol_rel;
         if (chain_steps != nullptr && tol_rel < 0.0)
             tr = 8.0 * 5.9604644775390625e-08 * (sqrt((double)chain_steps[0] * 32.0) + 1.0);
+        if (sv.push) tr += 2.0 * 5.9604644775390625e-08;    // bp is rounded once to f32 after its f64 accumulation
         E = tr * mag + tol_abs;
         push = (flag_all || (double)m2 >= (double)m - 2.0 * E) ? 1 : 0;
     }
@@ -402,7 +402,6 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
     const int a = PROJ ? g / mv.O : 0, o = PROJ ? g % mv.O : 0;
     const double m = best_score[e], E = err[e];
     const double thr = m - 2.0 * E;
-    const int64_t col0 = (int64_t)g * V;
     const T* brow = bel + (int64_t)b * ldb;
     const int k_tiles = mv.S_pad >> 5;
     const TileList tl{btl ? btl + (int64_t)b * k_tiles : nullptr, btl ? btc[b] : k_tiles};
@@ -411,7 +410,7 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
     for (int v0 = 0; v0 < V; v0 += 256) {
         const int v = v0 + tid;
         int flag = 0;
-        if (v < V) flag = ((double)sv.at(b, col0 + v) >= thr) ? 1 : 0;
+        if (v < V) flag = ((double)sv.score(b, g, V, v) >= thr) ? 1 : 0;
         const unsigned long long mask = __ballot(flag);
         __syncthreads();
         if (lane == 0) wcount[wid] = __popcll(mask);
@@ -492,8 +491,13 @@ __global__ void k_action_select(int B, ModelView<T> mv, SlabView<T> sv, int64_t 
     int best = 0;
     double bv = -std::numeric_limits<double>::infinity(), lo = bv;
     for (int a = 0; a < mv.A; ++a) {
-        const double rd = (double)sv.at(b, rd_col0 + a);
-        double E = (aqueue != nullptr) ? tr * fmax(fabs(rd), fabs((double)sv.at(b, rd_col0 + mv.A + a))) : 0.0;
+        double rd, E = 0.0;
+        if (sv.push) {
+            rd = sv.aux_rd[(int64_t)b * mv.A + a];          // f64 dot: exact to 1e-16, no window needed
+        } else {
+            rd = (double)sv.at(b, rd_col0 + a);
+            if (aqueue != nullptr) E = tr * fmax(fabs(rd), fabs((double)sv.at(b, rd_col0 + mv.A + a)));
+        }
         rdot[(int64_t)b * mv.A + a] = rd;
         rdot_err[(int64_t)b * mv.A + a] = E;
         double v = rd;
@@ -862,6 +866,84 @@ hipError_t launch_belief_update(const T* bel, int ldb, int B, ModelView<T> mv, c
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------- //
+// Belief-side formulation of the score GEMM's operands (used when B * A * O rows are cheaper than A * O * V):
+// project every belief through every (a, o) instead of every alpha-vector.
+//   bp[((o*A + a)*B + b)][s'] = gamma * sum_{(s,r): rs[s,a,r] = s'} b[b][s] * RTO[s,a,o,r]
+//   score[b,a,o,v] = bp[g,b,:] . alpha[v,:]   ( = b . Gamma[a,o,v,:] of src/pomdp.py:1489-1495, re-associated)
+// Pull form over the inverse transition lists (no atomics on bp), f64 accumulation, one rounding to T.
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void k_push_project(const T* __restrict__ bel, int ldb, int B, ModelView<T> mv,
+                               const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src, double gamma,
+                               const T* __restrict__ amax, T* __restrict__ bp, int ldp, double* __restrict__ mag) {
+    __shared__ double red[4];
+    const int sp = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, a = blockIdx.z;
+    const int G = mv.A * mv.O;
+    const T* brow = bel + (int64_t)b * ldb;
+    const int32_t* ptr = in_ptr + (int64_t)a * (mv.S + 1);
+    const int32_t* src = in_src + (int64_t)a * mv.S * mv.R;
+    const int j0 = sp < mv.S ? ptr[sp] : 0, j1 = sp < mv.S ? ptr[sp + 1] : 0;
+    const double am = sp < mv.S ? fabs((double)amax[sp]) : 0.0;
+    for (int o0 = 0; o0 < mv.O; o0 += 4) {
+        const int no = mv.O - o0 < 4 ? mv.O - o0 : 4;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = j0; j < j1; ++j) {
+            const int e = src[j];                           // e = s * R + r
+            const int s = e / mv.R, r = e - s * mv.R;
+            const double bs = (double)brow[s];
+            if (bs != 0.0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < no) acc[q] += bs * (double)mv.rto[((int64_t)(a * mv.O + o0 + q) * mv.R + r) * mv.S_pad + s];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= no) break;                             // uniform across the block
+            const int g = a * mv.O + o0 + q;
+            const T val = (T)(gamma * acc[q]);
+            const int64_t row = ((int64_t)(o0 + q) * mv.A + a) * B + b;     // observation-major (see SlabView)
+            if (sp < ldp) bp[row * ldp + sp] = val;                         // pad columns get exact zeros
+            const double part = block_sum(fabs((double)val) * am, red);
+            if (threadIdx.x == 0 && part != 0.0) atomicAdd(&mag[(int64_t)b * G + g], part);
+        }
+    }
+}
+
+template <typename T>
+hipError_t launch_push_project(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* in_ptr,
+                               const int32_t* in_src, double gamma, const T* amax, T* bp, int ldp, double* mag,
+                               hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    if (B > 65535 || mv.A > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_push_project<T>, dim3((ldp + 255) / 256, B, mv.A), dim3(256), 0, st, bel, ldb, B, mv, in_ptr,
+                       in_src, gamma, amax, bp, ldp, mag);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void k_rdot(const T* __restrict__ bel, int ldb, ModelView<T> mv, const int32_t* __restrict__ btl,
+                       const int32_t* __restrict__ btc, double* __restrict__ rd) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    const int k_tiles = mv.S_pad >> 5;
+    const TileList tl{btl ? btl + (int64_t)b * k_tiles : nullptr, btl ? btc[b] : k_tiles};
+    const T* brow = bel + (int64_t)b * ldb;
+    for (int a = 0; a < mv.A; ++a) {
+        const double v = block_sum(plain_dot_partial(brow, mv.er + (int64_t)a * mv.S_pad, mv.S, tl), red);
+        if (threadIdx.x == 0) rd[(int64_t)b * mv.A + a] = v;
+    }
+}
+
+template <typename T>
+hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* btl, const int32_t* btc, double* rd,
+                       hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rdot<T>, dim3(B), dim3(256), 0, st, bel, ldb, mv, btl, btc, rd);
+    return hipGetLastError();
+}
+
 // explicit instantiations
 #define PBVI_INST(T)                                                                                                   \
     template hipError_t launch_support<T>(ModelView<T>, uint8_t*, hipStream_t);                                        \
@@ -889,6 +971,10 @@ hipError_t launch_belief_update(const T* bel, int ldb, int B, ModelView<T> mv, c
     template hipError_t launch_belief_update<T>(const T*, int, int, ModelView<T>, const int32_t*, const int32_t*,      \
                                                 const int32_t*, const int32_t*, const int32_t*, double*, double*, T*,  \
                                                 int, hipStream_t);                                                     \
+    template hipError_t launch_push_project<T>(const T*, int, int, ModelView<T>, const int32_t*, const int32_t*,       \
+                                               double, const T*, T*, int, double*, hipStream_t);                      \
+    template hipError_t launch_rdot<T>(const T*, int, int, ModelView<T>, const int32_t*, const int32_t*, double*,      \
+                                       hipStream_t);                                                                   \
     template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
 PBVI_INST(float)
 PBVI_INST(double)

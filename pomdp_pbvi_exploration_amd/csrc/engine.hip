@@ -187,6 +187,7 @@ class EngineBase {
     virtual int prune_dominated(uint8_t* keep) = 0;
     virtual int value_max(double* out_value, int32_t* out_index) = 0;
     virtual int set_tie_window(double rel) = 0;
+    virtual int set_formulation(int f) = 0;
     virtual int64_t device_bytes() const = 0;
     virtual int64_t store_append(int which, const void* rows, int64_t n) = 0;
     virtual int store_select(int which, const int32_t* ids, int64_t n) = 0;
@@ -222,6 +223,9 @@ class EngineT : public EngineBase {
     DevBuf in_ptr_, in_src_, bu_act_, bu_obs_, bu_row_, bu_unnorm_, bu_mass_, bu_out_;   // batched belief update
     std::vector<int32_t> h_rs_;                                // host copy of rs [A][R][S_pad] for the lazy CSC build
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
+    DevBuf bp_, nzP_, pmag_, prd_;                          // belief-side formulation: projected beliefs, tile map, magnitudes, b.ER
+    int formulation_ = 0;                                   // 0 auto, 1 project alpha-vectors, 2 project beliefs
+    int last_formulation_ = 1;
     const int32_t* res_action_ = nullptr;                  // results in caller order
     const int32_t* res_best_ = nullptr;
     int64_t res_unique_ = 0;
@@ -245,7 +249,7 @@ class EngineT : public EngineBase {
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
-                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_,
+                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &bp_, &nzP_, &pmag_, &prd_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
@@ -278,6 +282,10 @@ class EngineT : public EngineBase {
         R_ = R;
         mode_ = mode;
         S_pad_ = (int)round_up(S, GEMM_BK);
+        if (const char* f = getenv("PBVI_FORMULATION")) {     // initial setting (tests run the whole suite both ways)
+            const std::string v(f);
+            formulation_ = (v == "alpha" || v == "1") ? 1 : (v == "belief" || v == "2") ? 2 : 0;
+        }
         HIPCHK(hipSetDevice(device_));
         HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
@@ -685,7 +693,9 @@ class EngineT : public EngineBase {
 
     // score GEMM: C = beliefs[B_pad][S_pad] . Y[rows_y][S_pad]^T -> slabs_.  Y's zero structure:
     // G row groups of v_group rows with support nzB (nullptr = dense Y).
-    int score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv);
+    // scores of X rows (default: the resident belief block) against the rows of Y
+    int score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv,
+                   const T* X = nullptr, int64_t x_rows = 0, const uint8_t* nzX = nullptr);
 
     int project_dense(double gamma);   // K1-dense: Gamma = gamma * alpha . D_ao^T as A*O (batched) GEMMs
     int backup_run(double gamma, int flags, pbvi_stats_t* st) override;
@@ -786,6 +796,11 @@ class EngineT : public EngineBase {
         return PBVI_OK;
     }
 
+    int set_formulation(int f) override {
+        if (f < 0 || f > 2) FAIL(PBVI_EINVAL, "set_formulation: 0 = auto, 1 = project alpha-vectors, 2 = project beliefs");
+        formulation_ = f;
+        return PBVI_OK;
+    }
     int set_tie_window(double rel) override {
         tie_rel_user_ = rel;
         return PBVI_OK;
@@ -794,19 +809,27 @@ class EngineT : public EngineBase {
 };
 
 template <typename T>
-int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv) {
+int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv,
+                           const T* X, int64_t x_rows, const uint8_t* nzX) {
     int rc;
+    const int64_t m_rows = X ? x_rows : B_;
+    const int64_t m_pad = X ? round_up(x_rows, GEMM_BM) : B_pad_;
+    if (!X) {
+        X = bel_.as<T>();
+        nzX = nzA_.as<uint8_t>();
+    }
     if constexpr (kF32) {
         const int64_t n_pad = round_up(rows_y, GEMM_BN);
-        plan_ = make_gemm_plan((int)B_pad_, (int)n_pad, S_pad_);
+        if (m_pad > 0x7fffffff || n_pad > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "score_gemm: operand rows exceed int32");
+        plan_ = make_gemm_plan((int)m_pad, (int)n_pad, S_pad_);
         const size_t pairs = (size_t)plan_.tiles_m * plan_.tiles_n;
         if ((rc = slabs_.ensure((size_t)plan_.max_chunks * plan_.slab_stride * sizeof(float), &bytes_))) return rc;
         if ((rc = klist_.ensure(pairs * plan_.k_tiles * sizeof(int), &bytes_))) return rc;
         if ((rc = kcount_.ensure(pairs * sizeof(int), &bytes_))) return rc;
         if ((rc = nchunks_.ensure(pairs * sizeof(int), &bytes_))) return rc;
         if ((rc = skws_.ensure(streamk_workspace_ints(plan_) * sizeof(int), &bytes_))) return rc;
-        HIPCHK(launch_gemm_nt_f32((const float*)bel_.p, S_pad_, (const float*)Y, S_pad_, slabs_.as<float>(), plan_,
-                                  nzA_.as<uint8_t>(), nzB, G, v_group, (int)rows_y, klist_.as<int>(), kcount_.as<int>(),
+        HIPCHK(launch_gemm_nt_f32((const float*)X, S_pad_, (const float*)Y, S_pad_, slabs_.as<float>(), plan_,
+                                  nzX, nzB, G, v_group, (int)rows_y, klist_.as<int>(), kcount_.as<int>(),
                                   nchunks_.as<int>(), stream_, 1, 0, 0, skws_.as<int>()));
         sv->slabs = slabs_.as<T>();
         sv->slab_stride = plan_.slab_stride;
@@ -815,8 +838,8 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
         sv->tiles_m = plan_.tiles_m;
         sv->fixed = 0;
     } else {
-        if ((rc = slabs_.ensure((size_t)B_ * rows_y * sizeof(T), &bytes_))) return rc;
-        HIPCHK(launch_gemm_nt_simple<T>(bel_.as<T>(), S_pad_, Y, S_pad_, slabs_.as<T>(), (int)rows_y, (int)B_, (int)rows_y,
+        if ((rc = slabs_.ensure((size_t)m_rows * rows_y * sizeof(T), &bytes_))) return rc;
+        HIPCHK(launch_gemm_nt_simple<T>(X, S_pad_, Y, S_pad_, slabs_.as<T>(), (int)rows_y, (int)m_rows, (int)rows_y,
                                         S_, stream_));
         sv->slabs = slabs_.as<T>();
         sv->slab_stride = 0;
@@ -907,8 +930,24 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     if (N > 0x7fffffff || pairs > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "backup_run: A*O*(V+1) or B*A*O exceeds int32");
     const ModelView<T> mv = view();
 
+    // Which operand is projected through the model (same scores, re-associated):
+    //   alpha-side (the reference's order): Gamma = A*O*(V+1)+2A rows, GEMM  [B] x [Gamma rows]
+    //   belief-side: bp = B*A*O rows,                                  GEMM  [B*A*O] x [V]
+    // The belief side wins when B << V (the solve loop: ~100 new beliefs against thousands of alpha-vectors):
+    // fewer rows to project and far less 256-row tile padding.  f32 sparse engines only.
+    bool use_push = false;
+    if (kF32 && mode_ != PBVI_DENSE && (int64_t)B_ * AO <= 0x7fffffff) {
+        auto cost = [&](int64_t m_rows, int64_t n_rows, int64_t proj_rows) {
+            const double tiles = (double)((m_rows + GEMM_BM - 1) / GEMM_BM) * (double)((n_rows + GEMM_BN - 1) / GEMM_BN);
+            return tiles * S_pad_ * (2.0 * GEMM_BM * GEMM_BN / 130e12) + (double)proj_rows * S_pad_ * sizeof(T) / 3e12;
+        };
+        const double c_pull = cost(B_, N, N), c_push = cost(B_ * AO, V_, B_ * AO);
+        use_push = formulation_ == 2 || (formulation_ == 0 && c_push < 0.8 * c_pull);
+    }
+    last_formulation_ = use_push ? 2 : 1;
     const int64_t n_rows_alloc = kF32 ? round_up(N, GEMM_BN) : N;
-    if ((rc = gam_.ensure((size_t)n_rows_alloc * S_pad_ * sizeof(T), &bytes_))) return rc;
+    if (!use_push)
+        if ((rc = gam_.ensure((size_t)n_rows_alloc * S_pad_ * sizeof(T), &bytes_))) return rc;
     if ((rc = best_v_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc;
     if ((rc = best_score_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
     if ((rc = err_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
@@ -922,7 +961,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     int* qcount = counters_.as<int>();
     int* aqcount = counters_.as<int>() + 1;
     HIPCHK(hipMemsetAsync(counters_.p, 0, 4 * sizeof(int), stream_));
-    if (n_rows_alloc > N)   // zero the Gamma pad rows the GEMM tiles read
+    if (!use_push && n_rows_alloc > N)   // zero the Gamma pad rows the GEMM tiles read
         HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)N * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
 
     HIPCHK(hipEventRecord(ev_[0], stream_));
@@ -940,7 +979,35 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(),
                               btl_.as<int32_t>(), btc_.as<int32_t>(), side));
     }
+    if (use_push) {   // b . ER[:,a] in f64 (the alpha-side gets it from Gamma's reward rows)
+        if ((rc = prd_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
+        HIPCHK(launch_rdot<T>(bel_.as<T>(), S_pad_, (int)B_, mv, btl_.as<int32_t>(), btc_.as<int32_t>(), prd_.as<double>(), side));
+    }
     HIPCHK(hipEventRecord(ev_join_, side));
+    SlabView<T> sv;
+    if (use_push) {
+        // K1 (belief side): every belief through every (a, o); K2: [B*A*O] x [V]
+        if ((rc = build_inverse_lists())) return rc;
+        const int64_t M = (int64_t)AO * B_, M_pad = round_up(M, GEMM_BM);
+        if ((rc = bp_.ensure((size_t)M_pad * S_pad_ * sizeof(T), &bytes_))) return rc;
+        if ((rc = pmag_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
+        if ((rc = nzP_.ensure((size_t)(M_pad / GEMM_BM) * k_tiles, &bytes_))) return rc;
+        HIPCHK(hipMemsetAsync(pmag_.p, 0, (size_t)pairs * sizeof(double), stream_));
+        if (M_pad > M)
+            HIPCHK(hipMemsetAsync(bp_.as<T>() + (size_t)M * S_pad_, 0, (size_t)(M_pad - M) * S_pad_ * sizeof(T), stream_));
+        HIPCHK(launch_push_project<T>(bel_.as<T>(), S_pad_, (int)B_, mv, in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), gamma,
+                                      alpha_.as<T>() + (size_t)V_ * S_pad_, bp_.as<T>(), S_pad_, pmag_.as<double>(), stream_));
+        if constexpr (kF32)
+            HIPCHK(launch_tile_nonzero_f32((const float*)bp_.p, S_pad_, (int)M_pad, k_tiles, nzP_.as<uint8_t>(), stream_));
+        HIPCHK(hipEventRecord(ev_[1], stream_));
+        if ((rc = score_gemm(alpha_.as<T>(), V_, nullptr, 1, (int)V_, &sv, bp_.as<T>(), M, nzP_.as<uint8_t>()))) return rc;
+        sv.push = 1;
+        sv.push_B = (int)B_;
+        sv.push_A = A_;
+        sv.push_O = O_;
+        sv.aux_mag = pmag_.as<double>();
+        sv.aux_rd = prd_.as<double>();
+    } else {
     // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
     const uint8_t* need = nullptr;
     if (kF32) {
@@ -964,8 +1031,8 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     HIPCHK(launch_tail_rows<T>(mv, gam_.as<T>() + (size_t)(AO * Vt) * S_pad_, S_pad_, stream_));
     HIPCHK(hipEventRecord(ev_[1], stream_));
     // K2: scores
-    SlabView<T> sv;
     if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv))) return rc;
+    }
     HIPCHK(hipEventRecord(ev_[2], stream_));
     HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));       // dead flags + rdot ready
     const GemmPlan plan = plan_;    // value_max_device (K5) re-plans; keep this GEMM's for the stats
@@ -1063,6 +1130,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         st->n_refined = h[0];
         st->n_refined_actions = h[1];
         st->n_unique = h_ucount;
+        st->formulation = last_formulation_;
         if (kF32) {
             std::vector<uint8_t> hd((size_t)pairs);
             HIPCHK(hipMemcpy(hd.data(), dead_.p, (size_t)pairs, hipMemcpyDeviceToHost));
@@ -1392,6 +1460,10 @@ int pbvi_mdp_value_iteration(int device, int32_t S, int32_t A, int32_t R, const 
 int pbvi_belief_update(pbvi_engine_t* e, const int32_t* actions, const int32_t* observations, void* out_beliefs) {
     NEED(e);
     return e->impl->belief_update(actions, observations, out_beliefs);
+}
+int pbvi_set_formulation(pbvi_engine_t* e, int formulation) {
+    NEED(e);
+    return e->impl->set_formulation(formulation);
 }
 int pbvi_set_tie_window(pbvi_engine_t* e, double rel) {
     NEED(e);

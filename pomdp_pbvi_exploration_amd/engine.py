@@ -28,7 +28,7 @@ EXPORTS = [
     'pbvi_alpha_store_append', 'pbvi_alpha_select', 'pbvi_alpha_store_reset',
     'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset', 'pbvi_debug_poison',
     'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
-    'pbvi_mdp_value_iteration',
+    'pbvi_mdp_value_iteration', 'pbvi_set_formulation',
 ]
 
 
@@ -44,10 +44,10 @@ class PbviStats(C.Structure):
                 ('n_unique', C.c_int64),
                 ('score_flops', C.c_int64), ('score_flops_executed', C.c_int64), ('score_tiles_dense', C.c_int64),
                 ('score_tiles_run', C.c_int64), ('project_flops', C.c_int64), ('project_flops_executed', C.c_int64),
-                ('split_k', C.c_int32), ('reserved', C.c_int32)]
+                ('split_k', C.c_int32), ('formulation', C.c_int32)]
 
     def as_dict(self) -> dict:
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != 'reserved'}
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 _lib = None
@@ -98,6 +98,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_beliefs_count': (C.c_int64, [vp]),
         'pbvi_mdp_value_iteration': (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int32, i32p, f64p, f64p, f64p,
                                                C.c_double, C.c_double, C.c_int32, f64p, f64p, i32p]),
+        'pbvi_set_formulation': (C.c_int, [vp, C.c_int]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -439,6 +440,11 @@ class Engine:
         out = np.empty((self.B, self.S), dtype=self.np_dtype)
         _check(self._lib.pbvi_beliefs_fetch(self._h, _ptr(out)))
         return out
+
+    def set_formulation(self, which: str = 'auto') -> None:
+        """Operand projected through the model: ``'auto'``, ``'alpha'`` (Gamma, the reference's order) or
+        ``'belief'`` (beliefs pushed through every (a, o); cheaper when B << V)."""
+        _check(self._lib.pbvi_set_formulation(self._h, {'auto': 0, 'alpha': 1, 'belief': 2}[which]))
 
     def set_tie_window(self, rel: float) -> None:
         _check(self._lib.pbvi_set_tie_window(self._h, float(rel)))

@@ -539,3 +539,44 @@ def test_device_value_iteration_random_mdp(seed):
             assert len(dev_hist.value_functions) == len(host_hist.value_functions)
             np.testing.assert_allclose(dev_hist.value_functions[2].alpha_vector_array,
                                        host_hist.value_functions[2].alpha_vector_array, rtol=1e-13, atol=0)
+
+
+# --------------------------------------------------------------------------- #
+# Belief-side formulation (pbvi_set_formulation): same results as the alpha-side order
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize('R', [1, 5])
+def test_formulations_agree_and_auto_picks_by_shape(R):
+    """Projecting the beliefs instead of the alpha-vectors re-associates the same sums: indices identical, values
+    within 1e-6 of the oracle, on both; the automatic choice takes the belief side only when B << V."""
+    z = load_npz(f'olfactory_small_R{R}.npz')
+    rs, rto, er = z['reachable_states'], z['rto'].astype(np.float64), z['expected_rewards'].astype(np.float64)
+    S, A, O, Rr = rto.shape[0], rto.shape[1], rto.shape[2], rto.shape[3]
+    alpha, b = z['alpha'].astype(np.float64), z['beliefs'].astype(np.float64)
+    gamma = float(z['gamma'])
+    want_rows, want_a, want_v = orc.backup_core(alpha, b, rs, rto, er, gamma)
+    eng = Engine(S, A, O, Rr, rs, rto, er, dtype='f32')
+    for which, expect in (('alpha', 1), ('belief', 2)):
+        eng.set_formulation(which)
+        eng.set_alpha(alpha)
+        eng.set_beliefs(b)
+        st = eng.run(gamma)
+        assert st['formulation'] == expect
+        res = eng.fetch()
+        assert np.array_equal(res.actions, want_a)
+        assert np.array_equal(res.best_alpha_ind, want_v)
+        np.testing.assert_allclose(res.alpha, want_rows, rtol=1e-6, atol=1e-7)
+    # auto: 64 beliefs x 48 alpha-vectors -> alpha side; 4 beliefs x 2000 alpha-vectors -> belief side
+    eng.set_formulation('auto')
+    assert eng.run(gamma)['formulation'] == 1
+    rng = np.random.default_rng(0)
+    big = np.concatenate([alpha] + [alpha[rng.integers(0, len(alpha), 488)] * rng.uniform(0.5, 1.0, (488, 1)) for _ in range(4)])
+    big = big.astype(np.float32).astype(np.float64)
+    eng.set_alpha(big)
+    eng.set_beliefs(b[:4])
+    st = eng.run(gamma)
+    assert st['formulation'] == 2
+    res = eng.fetch()
+    w_rows, w_a, w_v = orc.backup_core(big, b[:4], rs, rto, er, gamma)
+    assert np.array_equal(res.actions, w_a) and np.array_equal(res.best_alpha_ind, w_v)
+    np.testing.assert_allclose(res.alpha, w_rows, rtol=1e-6, atol=1e-7)
+    eng.close()
