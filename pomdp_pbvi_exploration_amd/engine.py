@@ -217,6 +217,7 @@ class Engine:
         self._alpha_token = None
         self._store_epoch = {'alpha': 0, 'belief': 0}
         self.B = 0
+        self._vmax_cache, self._vmax_epochs = [], None
 
     @classmethod
     def for_model(cls, model, dtype: str = 'f64', device: int = 0, mode: str = 'sparse') -> 'Engine':
@@ -285,10 +286,10 @@ class Engine:
         _check((self._lib.pbvi_alpha_store_reset if which == 'alpha' else self._lib.pbvi_belief_store_reset)(self._h))
         self._store_epoch[which] += 1
 
-    def sync_rows(self, which: str, objects, values_of) -> None:
-        """Make ``objects`` (AlphaVector / Belief instances, in list order) the working set: rows not yet in
-        this engine's store are uploaded in one batch, then the set is selected by id.  The id lives on the
-        object (``_dev``), tagged with this engine and the store epoch."""
+    def row_ids(self, which: str, objects, values_of) -> np.ndarray:
+        """Store ids of ``objects`` (AlphaVector / Belief instances, list order); rows not yet in this engine's
+        store are uploaded in one batch.  The id lives on the object (``_dev``), tagged with this engine and the
+        store epoch."""
         tag = (id(self), which, self._store_epoch[which])
         missing = [o for o in objects if getattr(o, '_dev', (None, -1))[0] != tag]
         if missing:
@@ -301,11 +302,70 @@ class Engine:
             first = self.store_rows(which, np.stack([np.asarray(values_of(o)) for o in todo]))
             for k, o in enumerate(todo):
                 o._dev = (tag, first + k)
-        ids = np.fromiter((o._dev[1] for o in objects), dtype=np.int32, count=len(objects))
+        return np.fromiter((o._dev[1] for o in objects), dtype=np.int32, count=len(objects))
+
+    def sync_rows(self, which: str, objects, values_of) -> None:
+        """Make ``objects`` the working set: upload what is missing (``row_ids``), then select by id."""
+        ids = self.row_ids(which, objects, values_of)
         if which == 'alpha':
             self.select_alpha(ids)
         else:
             self.select_beliefs(ids)
+
+    # -- max_v b.alpha_v with memory (compute_change on a growing belief set / alpha set) -------------- #
+    _VMAX_ENTRIES = 3
+    _BLOCK = 32768          # beliefs per resident block (the engine takes at most 65535)
+
+    def _vmax_block(self, a_ids: np.ndarray, b_ids: np.ndarray) -> np.ndarray:
+        out = np.empty(len(b_ids), dtype=np.float64)
+        self.select_alpha(a_ids)
+        for i0 in range(0, len(b_ids), self._BLOCK):
+            self.select_beliefs(b_ids[i0:i0 + self._BLOCK])
+            out[i0:i0 + self._BLOCK] = self.max_value_resident()[0]
+        return out
+
+    def max_value_objects(self, alpha_objects, belief_objects, alpha_values, belief_values) -> np.ndarray:
+        """``max_v b.alpha_v`` for every belief object against the set of alpha objects, reusing earlier results.
+
+        ``compute_change`` (``src/pomdp.py:2141-2169``) asks for this twice per backup on the whole accumulated
+        belief set.  The maximum over a set that grew is the maximum of the old value and the maximum over the new
+        rows, and a belief scored before keeps its value, so only (known beliefs x new alpha rows) and
+        (new beliefs x all alpha rows) go through the GEMM.  Values are the engine's exact re-scored ones, so the
+        result equals the from-scratch one.  Entries are keyed by the set of alpha store ids."""
+        a_ids = self.row_ids('alpha', alpha_objects, alpha_values)
+        b_ids = self.row_ids('belief', belief_objects, belief_values)
+        epochs = (self._store_epoch['alpha'], self._store_epoch['belief'])
+        if self._vmax_epochs != epochs:
+            self._vmax_cache, self._vmax_epochs = [], epochs
+        aset = frozenset(a_ids.tolist())
+        hit = next((e for e in self._vmax_cache if e['aset'] == aset), None)
+        base = hit
+        if base is None:     # largest cached subset of this alpha set
+            subs = [e for e in self._vmax_cache if e['aset'] <= aset]
+            base = max(subs, key=lambda e: len(e['aset'])) if subs else None
+        n_ids = int(b_ids.max()) + 1 if len(b_ids) else 0
+        vals = np.full(len(b_ids), np.nan)
+        if base is not None:
+            have = base['vals']
+            inside = b_ids < len(have)
+            vals[inside] = have[b_ids[inside]]
+        known = ~np.isnan(vals)
+        if base is not None and base is not hit and known.any():
+            fresh = np.array([i for i in a_ids.tolist() if i not in base['aset']], dtype=np.int32)
+            if len(fresh):
+                vals[known] = np.maximum(vals[known], self._vmax_block(fresh, b_ids[known]))
+        if (~known).any():
+            vals[~known] = self._vmax_block(a_ids, b_ids[~known])
+        if hit is None:
+            hit = {'aset': aset, 'vals': np.full(n_ids, np.nan)}
+            self._vmax_cache.append(hit)
+        elif len(hit['vals']) < n_ids:
+            hit['vals'] = np.concatenate([hit['vals'], np.full(n_ids - len(hit['vals']), np.nan)])
+        hit['vals'][b_ids] = vals
+        self._vmax_cache.remove(hit)
+        self._vmax_cache.append(hit)                 # most recent last
+        del self._vmax_cache[:-self._VMAX_ENTRIES]
+        return vals
 
     def _ensure_alpha(self, alpha: np.ndarray) -> None:
         """Make ``alpha`` the resident set.  Always uploads: array identity is not a safe

@@ -479,15 +479,15 @@ class PBVI_Solver(Solver):
 
     def compute_change(self, value_function: ValueFunction, new_value_function: ValueFunction, belief_set: BeliefSet) -> float:
         """Largest change of ``max_v b.alpha_v`` over the belief set (``src/pomdp.py:2141-2169``)."""
-        b = belief_set.belief_array
         if value_function.is_on_gpu:
+            # the belief set and the alpha set only grow between calls: the engine wrapper scores just the new
+            # (belief, alpha) pairs and keeps the rest (Engine.max_value_objects)
             eng = value_function.model.engine
-            eng.sync_rows('belief', belief_set.belief_list, lambda x: x.values)
-            eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values)
-            old = eng.max_value_resident()[0]
-            eng.sync_rows('alpha', new_value_function.alpha_vector_list, lambda v: v.values)
-            new = eng.max_value_resident()[0]
+            beliefs = belief_set.belief_list
+            old = eng.max_value_objects(value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda x: x.values)
+            new = eng.max_value_objects(new_value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda x: x.values)
         else:
+            b = belief_set.belief_array
             old = np.max(np.matmul(b, value_function.alpha_vector_array.T), axis=1)
             new = np.max(np.matmul(b, new_value_function.alpha_vector_array.T), axis=1)
         return float(np.max(np.abs(new - old)))
