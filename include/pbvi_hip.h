@@ -77,6 +77,7 @@ typedef struct pbvi_stats {
     int64_t project_flops_executed; /* dense mode: MFMA flops issued by the projection GEMMs */
     int32_t split_k;        /* max K-chunks (partial slabs) per tile pair */
     int32_t formulation;    /* which operand was projected: 1 = alpha-vectors (Gamma), 2 = beliefs (pbvi_set_formulation) */
+    int64_t n_refine_candidates; /* f32 engines: alpha-vectors re-scored in fp64 over all refined triples */
 } pbvi_stats_t;
 
 /* Library / device queries. */

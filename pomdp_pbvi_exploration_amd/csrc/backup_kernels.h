@@ -97,12 +97,36 @@ hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dea
                          int flag_all, int32_t* best_v, double* best_score, double* err, int32_t* queue, int* qcount,
                          hipStream_t st);
 
+// Work list of the refinement: entries with many near-tied candidates hand their (entry, candidate) pairs to a
+// grid-wide pass instead of scoring them one block per entry (device memory; items_v == nullptr: all in-block).
+struct RefineWork {
+    int32_t* items_v = nullptr;          // [item_cap] candidate alpha index
+    int32_t* items_slot = nullptr;       // [item_cap] slot of the entry (-1 = void item)
+    double* scores = nullptr;            // [item_cap] exact score
+    int32_t* slot_entry = nullptr;       // [slot_cap] queue entry (b * G + g) of the slot
+    int32_t* slot_n = nullptr;           // [slot_cap] tiles in the slot's list
+    int32_t* tiles = nullptr;            // [slot_cap][k_tiles] filtered tile list of the entry
+    unsigned long long* emax = nullptr;  // [slot_cap] max exact score, order-preserving bit pattern (0 = none)
+    int32_t* eidx = nullptr;             // [slot_cap] smallest candidate index attaining emax
+    double* ib_val = nullptr;            // [slot_cap] best of the candidates the entry's own block scored
+    int32_t* ib_idx = nullptr;           // [slot_cap] (0x7fffffff = none)
+    int* cnt = nullptr;                  // [2] items reserved, slots reserved
+    int item_cap = 0, slot_cap = 0;
+};
+
 // fp64 re-decision of queued near-ties.  PROJ: scores are b . Gamma[a,o,v,:]; else b . alpha[v,:]
 template <typename T>
 hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entries, const int32_t* queue,
                          const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
                          double gamma, const int32_t* btl, const int32_t* btc /* belief tile lists or nullptr */,
-                         int32_t* best_v, double* best_score, double* err, hipStream_t st);
+                         const uint8_t* nzG /* PROJ: [G][k_tiles] support tiles of RTO per group, or nullptr */,
+                         int32_t* best_v, double* best_score, double* err, int* cand_total /* += candidates, or nullptr */,
+                         RefineWork work, hipStream_t st);
+
+// btl [B][k_tiles] / btc [B]: compact lists of each belief's non-zero 32-state tiles
+template <typename T>
+hipError_t launch_belief_tiles(const T* bel, int ldb, int B, int S, int k_tiles, int32_t* btl, int32_t* btc,
+                               hipStream_t st);
 
 // K4: val[b][a] = b.ER[:,a] + sum_o best_score[b][a][o]; action = first max; near-ties queued
 // Gamma tail rows [A*O*V + A*O, +2A): ER[:,a] and |ER[:,a]|, so the score GEMM also yields b.ER[:,a]

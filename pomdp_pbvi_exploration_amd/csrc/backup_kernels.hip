@@ -291,6 +291,49 @@ __global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, cons
     }
 }
 
+// Non-zero tile lists of the resident beliefs alone (value-max path, where k_dead does not run).
+template <typename T>
+__global__ void k_belief_tiles(const T* __restrict__ bel, int ldb, int S, int k_tiles, int32_t* __restrict__ btl,
+                               int32_t* __restrict__ btc) {
+    extern __shared__ uint8_t dsm[];
+    uint8_t* tz = dsm;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const T* brow = bel + (int64_t)b * ldb;
+    for (int kt0 = 0; kt0 < k_tiles; kt0 += 32) {
+        const int kt = kt0 + (tid >> 3);
+        int f = 0;
+        if (kt < k_tiles) {
+            const int s = kt * 32 + (tid & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f |= (s + j < S && brow[s + j] != T(0)) ? 1 : 0;
+        }
+        f |= __shfl_xor(f, 1, 64);
+        f |= __shfl_xor(f, 2, 64);
+        f |= __shfl_xor(f, 4, 64);
+        if (kt < k_tiles && (tid & 7) == 0) tz[kt] = (uint8_t)f;
+    }
+    __syncthreads();
+    if (wid == 0) {
+        int base = 0;
+        for (int kt0 = 0; kt0 < k_tiles; kt0 += 64) {
+            const int kt = kt0 + lane;
+            const int f = (kt < k_tiles) ? tz[kt] : 0;
+            const unsigned long long m = __ballot(f);
+            if (f) btl[(int64_t)b * k_tiles + base + __popcll(m & ((1ull << lane) - 1ull))] = kt;
+            base += __popcll(m);
+        }
+        if (lane == 0) btc[b] = base;
+    }
+}
+
+template <typename T>
+hipError_t launch_belief_tiles(const T* bel, int ldb, int B, int S, int k_tiles, int32_t* btl, int32_t* btc,
+                               hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_belief_tiles<T>, dim3(B), dim3(256), (size_t)k_tiles, st, bel, ldb, S, k_tiles, btl, btc);
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const uint8_t* nzB, int k_tiles, uint8_t* dead,
                        int32_t* btl, int32_t* btc, hipStream_t st) {
@@ -384,17 +427,76 @@ hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dea
 // fp64 re-decision of a queued (belief, group): every candidate whose f32 score is
 // within the error window of the f32 maximum is re-scored exactly (f32 x f32 products
 // are exact in f64) and the first maximum of the exact scores wins.
+//
+// Real value functions are full of near-ties (and exact ties: every alpha-vector has the same value at an
+// absorbing goal state, so for the "goal" observation ALL of them tie), so this kernel sees entries with
+// thousands of candidates.  Two things keep those cheap:
+//   * the dot runs only over tiles where the belief AND the (a,o) support of RTO are non-zero (list built once
+//     per entry in LDS) -- for a rarely-seen observation that is one or two tiles instead of the belief's
+//     hundreds;
+//   * candidates are scored one per wave, four at a time, with wave-level reductions only (no block barrier
+//     per candidate).
 // ------------------------------------------------------------------------- //
+constexpr int REFINE_LIST_CAP = 2048;   // tiles kept in LDS (65536 states of support); longer lists stay global
+constexpr int REFINE_DEFER_MIN = 8;     // more candidates than this in a 256-column chunk go to the grid-wide pass
+
+// exact score of one candidate over a tile list, computed by one wave (all lanes get the sum)
+template <typename T, bool PROJ>
+__device__ __forceinline__ double refine_wave_dot(const T* __restrict__ brow, const T* __restrict__ arow,
+                                                  const ModelView<T>& mv, int a, int o, double gamma,
+                                                  const int* L, int n_tiles, int lane) {
+    const int32_t* __restrict__ rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
+    const T* __restrict__ rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
+    const int n_el = n_tiles * 32;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = lane; i0 < n_el; i0 += 256) {
+        int s[4];
+        double w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + 64 * j;
+            const bool ok = i < n_el;
+            const int ii = ok ? i : i0;
+            const int t = L ? L[ii >> 5] : (ii >> 5);
+            s[j] = t * 32 + (ii & 31);                       // < S_pad; pads hold rs = 0, rto = 0, b = 0
+            w[j] = ok ? 1.0 : 0.0;
+        }
+        if constexpr (PROJ) {
+            double g[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int r = 0; r < mv.R; ++r) {
+                const int64_t ro = (int64_t)r * mv.S_pad;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] += (double)rto[ro + s[j]] * (double)arow[rs[ro + s[j]]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += w[j] * ((double)brow[s[j]] * (gamma * g[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = s[j] < mv.S;                 // alpha rows are valid for s < S only
+                acc[j] += (in ? w[j] : 0.0) * ((double)brow[s[j]] * (double)arow[in ? s[j] : 0]);
+            }
+        }
+    }
+    return wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+}
+
 template <typename T, bool PROJ>
 __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict__ queue,
                          const int* __restrict__ qcount,
                          const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
                          ModelView<T> mv, double gamma, const int32_t* __restrict__ btl, const int32_t* __restrict__ btc,
+                         const uint8_t* __restrict__ nzG /* [G][k_tiles] support tiles per group, or nullptr */,
                          int32_t* __restrict__ best_v,
-                         double* __restrict__ best_score, double* __restrict__ err) {
+                         double* __restrict__ best_score, double* __restrict__ err, int* __restrict__ cand_total,
+                         RefineWork work) {
     __shared__ int cand[256];
     __shared__ int wcount[4];
-    __shared__ double red[4];
+    __shared__ int ltile[REFINE_LIST_CAP];
+    __shared__ int lbase, loverflow;
+    __shared__ int sh_slot, sh_base;
+    __shared__ double wbest[4];
+    __shared__ int widx[4];
     if ((int)blockIdx.x >= *qcount) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int e = queue[blockIdx.x];
@@ -404,9 +506,46 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
     const double thr = m - 2.0 * E;
     const T* brow = bel + (int64_t)b * ldb;
     const int k_tiles = mv.S_pad >> 5;
-    const TileList tl{btl ? btl + (int64_t)b * k_tiles : nullptr, btl ? btc[b] : k_tiles};
+    // -- tile list of this entry: belief tiles, filtered by the group's support tiles
+    const int32_t* src = btl ? btl + (int64_t)b * k_tiles : nullptr;
+    const int n_src = btl ? btc[b] : k_tiles;
+    const uint8_t* zg = (PROJ && nzG) ? nzG + (int64_t)g * k_tiles : nullptr;
+    if (tid == 0) {
+        lbase = 0;
+        loverflow = 0;
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < n_src; i0 += 256) {
+        const int i = i0 + tid;
+        int t = 0, f = 0;
+        if (i < n_src) {
+            t = src ? src[i] : i;
+            f = zg ? (zg[t] != 0) : 1;
+        }
+        const unsigned long long mask = __ballot(f);
+        if (lane == 0) wcount[wid] = __popcll(mask);
+        __syncthreads();
+        int off = lbase;
+        for (int w = 0; w < wid; ++w) off += wcount[w];
+        const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        const bool fits = lbase + tot <= REFINE_LIST_CAP;
+        if (f && fits) ltile[off + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+        __syncthreads();
+        if (tid == 0) {
+            if (fits) lbase += tot;
+            else loverflow = 1;
+        }
+        __syncthreads();
+        if (loverflow) break;
+    }
+    // overflow: fall back to the belief's own (unfiltered) list in global memory -- zero tiles add exact zeros
+    const int* L = loverflow ? src : ltile;
+    const int n_tiles = loverflow ? n_src : lbase;
+
     double bestval = -std::numeric_limits<double>::infinity();
-    int bestidx = -1;
+    int bestidx = 0x7fffffff;
+    int slot = -1;                                           // >= 0 once this entry hands candidates to the work list
+    if (tid == 0) sh_slot = -1;
     for (int v0 = 0; v0 < V; v0 += 256) {
         const int v = v0 + tid;
         int flag = 0;
@@ -419,39 +558,179 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
         for (int w = 0; w < wid; ++w) base += wcount[w];
         const int ncand = wcount[0] + wcount[1] + wcount[2] + wcount[3];
         if (flag) cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = v;
+        if (tid == 0 && cand_total != nullptr && ncand > 0) atomicAdd(cand_total, ncand);
+        // Many candidates: one block scoring them four at a time is a long latency chain (tens of microseconds per
+        // candidate on a wide belief); hand them to the grid-wide pass instead.
+        if (work.items_v != nullptr && !loverflow && (slot >= 0 || ncand > REFINE_DEFER_MIN)) {
+            if (tid == 0) {
+                int sl = slot;
+                if (sl < 0) {
+                    sl = atomicAdd(&work.cnt[1], 1);
+                    if (sl >= work.slot_cap) sl = -1;
+                }
+                int ib = -1;
+                if (sl >= 0) {
+                    ib = atomicAdd(&work.cnt[0], ncand);
+                    if (ib + ncand > work.item_cap) {        // no room: void whatever part of the range exists
+                        for (int c = ib; c < work.item_cap && c < ib + ncand; ++c) work.items_slot[c] = -1;
+                        ib = -1;
+                    }
+                }
+                sh_slot = sl;
+                sh_base = ib;
+            }
+            __syncthreads();
+            const int sl = sh_slot, ib = sh_base;
+            if (sl >= 0 && slot < 0) {                       // first use of the slot: publish the entry and its tile list
+                for (int i = tid; i < n_tiles; i += 256) work.tiles[(int64_t)sl * k_tiles + i] = L[i];
+                if (tid == 0) {
+                    work.slot_entry[sl] = e;
+                    work.slot_n[sl] = n_tiles;
+                }
+                slot = sl;
+            }
+            if (sl >= 0 && ib >= 0) {
+                for (int c = tid; c < ncand; c += 256) {
+                    work.items_v[ib + c] = cand[c];
+                    work.items_slot[ib + c] = sl;
+                }
+                continue;                                    // next chunk (the barrier at its top orders cand reuse)
+            }
+        }
         __syncthreads();
-        for (int c = 0; c < ncand; ++c) {
+        for (int c = wid; c < ncand; c += 4) {               // one candidate per wave, ascending v within a wave
             const int vv = cand[c];
-            const T* arow = alpha + (int64_t)vv * lda;
-            const double part = PROJ ? proj_dot_partial(brow, arow, mv, a, o, gamma, tl)
-                                     : plain_dot_partial(brow, arow, mv.S, tl);
-            const double tot = block_sum(part, red);
-            if (tot > bestval) {          // candidates ascend in v: first maximum wins
+            const double tot = refine_wave_dot<T, PROJ>(brow, alpha + (int64_t)vv * lda, mv, a, o, gamma, L, n_tiles, lane);
+            if (tot > bestval) {
                 bestval = tot;
                 bestidx = vv;
             }
         }
-        __syncthreads();
     }
-    if (tid == 0 && bestidx >= 0) {
-        best_v[e] = bestidx;
-        best_score[e] = bestval;
-        err[e] = 0.0;
+    // first maximum over the four waves: largest value, then smallest index
+    if (lane == 0) {
+        wbest[wid] = bestval;
+        widx[wid] = bestidx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = wbest[0];
+        int bi = widx[0];
+        for (int w = 1; w < 4; ++w)
+            if (wbest[w] > bv || (wbest[w] == bv && widx[w] < bi)) {
+                bv = wbest[w];
+                bi = widx[w];
+            }
+        if (slot >= 0) {                                     // merged with the work-list results in k_refine_merge
+            work.ib_val[slot] = bv;
+            work.ib_idx[slot] = bi;
+        } else if (bi != 0x7fffffff) {
+            best_v[e] = bi;
+            best_score[e] = bv;
+            err[e] = 0.0;
+        }
+    }
+}
+
+// order-preserving map of finite doubles to unsigned integers (0 is below every mapped value)
+__device__ __forceinline__ unsigned long long ordered_bits(double x) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double unordered_bits(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+// Grid-wide pass over the deferred (entry, candidate) items: one wave per item.
+template <typename T, bool PROJ>
+__global__ void k_refine_items(int G, const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
+                               ModelView<T> mv, double gamma, RefineWork work) {
+    const int lane = threadIdx.x & 63;
+    const int n_items = min(work.cnt[0], work.item_cap);
+    const int k_tiles = mv.S_pad >> 5;
+    const int waves = gridDim.x * 4;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n_items; i += waves) {
+        const int sl = work.items_slot[i];
+        if (sl < 0) continue;
+        const int e = work.slot_entry[sl];
+        const int b = e / G, g = e % G;
+        const int a = PROJ ? g / mv.O : 0, o = PROJ ? g % mv.O : 0;
+        const double tot = refine_wave_dot<T, PROJ>(bel + (int64_t)b * ldb, alpha + (int64_t)work.items_v[i] * lda, mv, a, o,
+                                                    gamma, work.tiles + (int64_t)sl * k_tiles, work.slot_n[sl], lane);
+        if (lane == 0) {
+            work.scores[i] = tot;
+            if (tot == tot) atomicMax(&work.emax[sl], ordered_bits(tot));
+        }
+    }
+}
+
+// first maximum: among the items that attain the entry's maximum, the smallest candidate index
+__global__ void k_refine_first(RefineWork work) {
+    const int n_items = min(work.cnt[0], work.item_cap);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
+        const int sl = work.items_slot[i];
+        if (sl < 0) continue;
+        const double sc = work.scores[i];
+        if (sc == sc && ordered_bits(sc) == work.emax[sl]) atomicMin(&work.eidx[sl], work.items_v[i]);
+    }
+}
+
+__global__ void k_refine_merge(RefineWork work, int32_t* __restrict__ best_v, double* __restrict__ best_score,
+                               double* __restrict__ err) {
+    const int n_slots = min(work.cnt[1], work.slot_cap);
+    for (int sl = blockIdx.x * blockDim.x + threadIdx.x; sl < n_slots; sl += gridDim.x * blockDim.x) {
+        double bv = work.ib_val[sl];
+        int bi = work.ib_idx[sl];
+        if (work.emax[sl] != 0ull) {
+            const double wv = unordered_bits(work.emax[sl]);
+            const int wi = work.eidx[sl];
+            if (bi == 0x7fffffff || wv > bv || (wv == bv && wi < bi)) {
+                bv = wv;
+                bi = wi;
+            }
+        }
+        if (bi != 0x7fffffff) {
+            const int e = work.slot_entry[sl];
+            best_v[e] = bi;
+            best_score[e] = bv;
+            err[e] = 0.0;
+        }
     }
 }
 
 template <typename T>
 hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entries, const int32_t* queue,
                          const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
-                         double gamma, const int32_t* btl, const int32_t* btc, int32_t* best_v, double* best_score,
-                         double* err, hipStream_t st) {
+                         double gamma, const int32_t* btl, const int32_t* btc, const uint8_t* nzG, int32_t* best_v,
+                         double* best_score, double* err, int* cand_total, RefineWork work, hipStream_t st) {
     if (max_entries <= 0) return hipSuccess;
+    hipError_t e;
+    if (work.items_v != nullptr) {
+        if ((e = hipMemsetAsync(work.cnt, 0, 2 * sizeof(int), st)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(work.emax, 0, (size_t)work.slot_cap * sizeof(unsigned long long), st)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(work.eidx, 0x7f, (size_t)work.slot_cap * sizeof(int32_t), st)) != hipSuccess) return e;
+    }
     if (proj)
         hipLaunchKernelGGL((k_refine<T, true>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,
-                           alpha, lda, mv, gamma, btl, btc, best_v, best_score, err);
+                           alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
     else
         hipLaunchKernelGGL((k_refine<T, false>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel,
-                           ldb, alpha, lda, mv, gamma, btl, btc, best_v, best_score, err);
+                           ldb, alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (work.items_v != nullptr) {
+        const int blocks = 2048;                           // 8192 waves: every SIMD of the chip has work in flight
+        if (proj)
+            hipLaunchKernelGGL((k_refine_items<T, true>), dim3(blocks), dim3(256), 0, st, G, bel, ldb, alpha, lda, mv, gamma,
+                               work);
+        else
+            hipLaunchKernelGGL((k_refine_items<T, false>), dim3(blocks), dim3(256), 0, st, G, bel, ldb, alpha, lda, mv,
+                               gamma, work);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_refine_first, dim3(1024), dim3(256), 0, st, work);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_refine_merge, dim3(64), dim3(256), 0, st, work, best_v, best_score, err);
+    }
     return hipGetLastError();
 }
 
@@ -952,11 +1231,12 @@ hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, const int3
     template hipError_t launch_tail_rows<T>(ModelView<T>, T*, int, hipStream_t);                                       \
     template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const uint8_t*, int, uint8_t*, int32_t*,      \
                                        int32_t*, hipStream_t);                                                         \
+    template hipError_t launch_belief_tiles<T>(const T*, int, int, int, int, int32_t*, int32_t*, hipStream_t);         \
     template hipError_t launch_argmax<T>(SlabView<T>, int, int, int, const uint8_t*, double, double, const int*, int,  \
                                          int32_t*, double*, double*, int32_t*, int*, hipStream_t);                     \
     template hipError_t launch_refine<T>(bool, SlabView<T>, int, int, int, const int32_t*, const int*, const T*, int,  \
                                          const T*, int, ModelView<T>, double, const int32_t*, const int32_t*,          \
-                                         int32_t*, double*, double*, hipStream_t);                                     \
+                                         const uint8_t*, int32_t*, double*, double*, int*, RefineWork, hipStream_t);   \
     template hipError_t launch_action<T>(int, ModelView<T>, SlabView<T>, int64_t, double, const int*, const double*,   \
                                          const double*, double*, double*, int32_t*, int32_t*, int*, hipStream_t);      \
     template hipError_t launch_refine_action<T>(const T*, int, int, const T*, int, ModelView<T>, double,               \

@@ -224,6 +224,8 @@ class EngineT : public EngineBase {
     std::vector<int32_t> h_rs_;                                // host copy of rs [A][R][S_pad] for the lazy CSC build
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     DevBuf bp_, nzP_, pmag_, prd_;                          // belief-side formulation: projected beliefs, tile map, magnitudes, b.ER
+    bool btl_valid_ = false;                                // btl_/btc_ describe the resident belief block
+    DevBuf rf_v_, rf_slot_, rf_sc_, rf_entry_, rf_n_, rf_tiles_, rf_emax_, rf_eidx_, rf_ibv_, rf_ibi_, rf_cnt_;   // refinement work list
     int formulation_ = 0;                                   // 0 auto, 1 project alpha-vectors, 2 project beliefs
     int last_formulation_ = 1;
     const int32_t* res_action_ = nullptr;                  // results in caller order
@@ -249,7 +251,8 @@ class EngineT : public EngineBase {
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
-                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &bp_, &nzP_, &pmag_, &prd_,
+                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &bp_, &nzP_, &pmag_, &prd_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
+                         &rf_emax_, &rf_eidx_, &rf_ibv_, &rf_ibi_, &rf_cnt_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
@@ -325,7 +328,7 @@ class EngineT : public EngineBase {
         HIPCHK(hipMemcpyAsync(rto_.p, h_rto.data(), n_rto * sizeof(T), hipMemcpyHostToDevice, stream_));
         HIPCHK(hipMemcpyAsync(er_.p, h_er.data(), n_er * sizeof(T), hipMemcpyHostToDevice, stream_));
         HIPCHK(launch_support<T>(view(), sup_.as<uint8_t>(), stream_));
-        if ((rc = counters_.ensure(4 * sizeof(int), &bytes_))) return rc;
+        if ((rc = counters_.ensure(8 * sizeof(int), &bytes_))) return rc;
         {   // nzB[(a,o)][kt] = 1 iff RTO[:,a,o,:] has support inside K tile kt (32 states)
             const int k_tiles = S_pad_ / GEMM_BK;
             // ... plus one extra row [A*O] for the support of ER (the reward rows in Gamma's tail tile)
@@ -461,6 +464,7 @@ class EngineT : public EngineBase {
         B_ = B;
         B_pad_ = Bp;
         have_result_ = false;
+        btl_valid_ = false;
         return PBVI_OK;
     }
 
@@ -796,6 +800,51 @@ class EngineT : public EngineBase {
         return PBVI_OK;
     }
 
+    // Work list of the f64 refinement (see RefineWork): room for every candidate of up to 16M (entry, alpha) pairs
+    // and the tile lists of up to 65536 entries; what does not fit is scored by the entry's own block.
+    int refine_work(int64_t max_entries, int64_t V, RefineWork* w) {
+        static const bool off = getenv("PBVI_REFINE_INBLOCK") != nullptr;     // debug / A-B only
+        *w = RefineWork{};
+        if (off) return PBVI_OK;
+        const int k_tiles = S_pad_ / GEMM_BK;
+        // capacities move in powers of two: the alpha set grows by a few rows per backup in a solve loop and a
+        // reallocation (hipFree + hipMalloc, both synchronising) per call would cost more than the refinement
+        auto pow2 = [](int64_t x, int64_t lo, int64_t hi) {
+            int64_t p = lo;
+            while (p < x && p < hi) p <<= 1;
+            return p;
+        };
+        const int64_t items = pow2(max_entries * V, (int64_t)1 << 16, (int64_t)1 << 24);
+        const int64_t slots = pow2(max_entries, 1024, 65536);
+        if (items <= 0 || slots <= 0) return PBVI_OK;
+        int rc;
+        if ((rc = rf_v_.ensure((size_t)items * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = rf_slot_.ensure((size_t)items * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = rf_sc_.ensure((size_t)items * sizeof(double), &bytes_))) return rc;
+        if ((rc = rf_entry_.ensure((size_t)slots * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = rf_n_.ensure((size_t)slots * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = rf_tiles_.ensure((size_t)slots * k_tiles * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = rf_emax_.ensure((size_t)slots * sizeof(unsigned long long), &bytes_))) return rc;
+        if ((rc = rf_eidx_.ensure((size_t)slots * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = rf_ibv_.ensure((size_t)slots * sizeof(double), &bytes_))) return rc;
+        if ((rc = rf_ibi_.ensure((size_t)slots * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = rf_cnt_.ensure(2 * sizeof(int), &bytes_))) return rc;
+        w->items_v = rf_v_.as<int32_t>();
+        w->items_slot = rf_slot_.as<int32_t>();
+        w->scores = rf_sc_.as<double>();
+        w->slot_entry = rf_entry_.as<int32_t>();
+        w->slot_n = rf_n_.as<int32_t>();
+        w->tiles = rf_tiles_.as<int32_t>();
+        w->emax = rf_emax_.as<unsigned long long>();
+        w->eidx = rf_eidx_.as<int32_t>();
+        w->ib_val = rf_ibv_.as<double>();
+        w->ib_idx = rf_ibi_.as<int32_t>();
+        w->cnt = rf_cnt_.as<int>();
+        w->item_cap = (int)items;
+        w->slot_cap = (int)slots;
+        return PBVI_OK;
+    }
+
     int set_formulation(int f) override {
         if (f < 0 || f > 2) FAIL(PBVI_EINVAL, "set_formulation: 0 = auto, 1 = project alpha-vectors, 2 = project beliefs");
         formulation_ = f;
@@ -910,10 +959,21 @@ int EngineT<T>::value_max_device() {
     // follows (new value > old best value) is strict and must not see GEMM rounding
     HIPCHK(launch_argmax<T>(sv, (int)V_, 1, (int)B_, nullptr, tie_window(k_chunk), 0.0, chain_steps(), 1, bv2_.as<int32_t>(),
                             bs2_.as<double>(), err2_.as<double>(), kF32 ? queue2_.as<int32_t>() : nullptr, qc, stream_));
-    if (kF32)
+    if (kF32) {
+        if (!btl_valid_) {   // tile lists of the resident block (the backup's k_dead builds them too)
+            const int k_tiles = S_pad_ / GEMM_BK;
+            if ((rc = btl_.ensure((size_t)B_ * k_tiles * sizeof(int32_t), &bytes_))) return rc;
+            if ((rc = btc_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+            HIPCHK(launch_belief_tiles<T>(bel_.as<T>(), S_pad_, (int)B_, S_, k_tiles, btl_.as<int32_t>(), btc_.as<int32_t>(),
+                                          stream_));
+            btl_valid_ = true;
+        }
+        RefineWork work;
+        if ((rc = refine_work(B_, V_, &work))) return rc;
         HIPCHK(launch_refine<T>(false, sv, (int)V_, 1, (int)B_, queue2_.as<int32_t>(), qc, bel_.as<T>(), S_pad_,
-                                alpha_.as<T>(), S_pad_, view(), 0.0, nullptr, nullptr, bv2_.as<int32_t>(),
-                                bs2_.as<double>(), err2_.as<double>(), stream_));
+                                alpha_.as<T>(), S_pad_, view(), 0.0, btl_.as<int32_t>(), btc_.as<int32_t>(), nullptr,
+                                bv2_.as<int32_t>(), bs2_.as<double>(), err2_.as<double>(), nullptr, work, stream_));
+    }
     return PBVI_OK;
 }
 
@@ -960,7 +1020,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     if ((rc = keep_.ensure((size_t)B_, &bytes_))) return rc;
     int* qcount = counters_.as<int>();
     int* aqcount = counters_.as<int>() + 1;
-    HIPCHK(hipMemsetAsync(counters_.p, 0, 4 * sizeof(int), stream_));
+    HIPCHK(hipMemsetAsync(counters_.p, 0, 8 * sizeof(int), stream_));
     if (!use_push && n_rows_alloc > N)   // zero the Gamma pad rows the GEMM tiles read
         HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)N * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
 
@@ -978,6 +1038,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         if ((rc = val_exact_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
         HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(),
                               btl_.as<int32_t>(), btc_.as<int32_t>(), side));
+        btl_valid_ = true;
     }
     if (use_push) {   // b . ER[:,a] in f64 (the alpha-side gets it from Gamma's reward rows)
         if ((rc = prd_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
@@ -1047,10 +1108,14 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         h_kcount.resize((size_t)plan.tiles_m * plan.tiles_n);
         HIPCHK(hipMemcpyAsync(h_kcount.data(), kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
     }
+    RefineWork work;
+    if (kF32)
+        if ((rc = refine_work(pairs, V_, &work))) return rc;
     if (kF32)
         HIPCHK(launch_refine<T>(true, sv, (int)V_, AO, (int)pairs, queue_.as<int32_t>(), qcount, bel_.as<T>(), S_pad_,
-                                alpha_.as<T>(), S_pad_, mv, gamma, btl_.as<int32_t>(), btc_.as<int32_t>(),
-                                best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), stream_));
+                                alpha_.as<T>(), S_pad_, mv, gamma, btl_.as<int32_t>(), btc_.as<int32_t>(), nzB_.as<uint8_t>(),
+                                best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), counters_.as<int>() + 4,
+                                work, stream_));
     HIPCHK(hipEventRecord(ev_[4], stream_));
     // K4: action
     double* rdot_err = rdot_.as<double>() + (size_t)B_ * A_;
@@ -1125,8 +1190,9 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         st->ms_dominance = el(6, 7);
         st->ms_total = el(0, 7);
         st->n_pairs = pairs;
-        int h[4] = {0, 0, 0, 0};
+        int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIPCHK(hipMemcpy(h, counters_.p, sizeof(h), hipMemcpyDeviceToHost));
+        st->n_refine_candidates = h[4];
         st->n_refined = h[0];
         st->n_refined_actions = h[1];
         st->n_unique = h_ucount;

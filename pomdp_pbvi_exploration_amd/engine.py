@@ -44,7 +44,7 @@ class PbviStats(C.Structure):
                 ('n_unique', C.c_int64),
                 ('score_flops', C.c_int64), ('score_flops_executed', C.c_int64), ('score_tiles_dense', C.c_int64),
                 ('score_tiles_run', C.c_int64), ('project_flops', C.c_int64), ('project_flops_executed', C.c_int64),
-                ('split_k', C.c_int32), ('formulation', C.c_int32)]
+                ('split_k', C.c_int32), ('formulation', C.c_int32), ('n_refine_candidates', C.c_int64)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}

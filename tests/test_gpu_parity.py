@@ -619,3 +619,40 @@ def test_max_value_objects_incremental_equals_from_scratch(dtype):
         v.__dict__.pop('_dev', None)
     check(a2, b1)                   # ids restart after the reset: the cache must not survive it
     eng.close()
+
+
+@pytest.mark.parametrize('formulation', ['alpha', 'belief'])
+def test_exact_ties_with_hundreds_of_candidates(formulation):
+    """Value functions are full of exact ties (every alpha-vector has the same value at an absorbing goal).  Here all
+    arithmetic is exact by construction (dyadic beliefs / RTO / gamma, small-integer alpha rows drawn from five
+    distinct rows), so every triple has ~140 exactly tied candidates: np.argmax takes the first, and so must the
+    engine -- through the grid-wide refinement pass that scores long candidate lists."""
+    rng = np.random.default_rng(77)
+    S, A, O, R, V, B = 300, 2, 2, 1, 700, 40
+    rs = rng.integers(0, S, size=(S, A, R))
+    pick = rng.random((S, A)) < 0.5
+    rto = np.empty((S, A, O, R))
+    rto[:, :, 0, 0] = np.where(pick, 0.25, 0.75)
+    rto[:, :, 1, 0] = 1.0 - rto[:, :, 0, 0]
+    er = rng.integers(-4, 5, size=(S, A)).astype(np.float64)
+    base = rng.integers(-8, 9, size=(5, S)).astype(np.float64)
+    alpha = base[rng.integers(0, 5, size=V)]
+    b = np.zeros((B, S))
+    for i in range(B):
+        np.add.at(b[i], rng.integers(0, S, size=64), 1.0 / 64.0)
+    want_rows, want_a, want_v = orc.backup_core(alpha, b, rs, rto, er, 0.5)
+    eng = Engine(S, A, O, R, rs, rto, er, dtype='f32')
+    eng.set_formulation(formulation)
+    eng.set_alpha(alpha)
+    eng.set_beliefs(b)
+    st = eng.run(0.5)
+    res = eng.fetch()
+    assert st['n_refine_candidates'] > 100 * st['n_refined'] > 0      # the long-list path really ran
+    assert np.array_equal(res.best_alpha_ind, want_v)
+    assert np.array_equal(res.actions, want_a)
+    np.testing.assert_array_equal(res.alpha, want_rows)
+    val, idx = eng.max_value_resident()                               # value-max path: same machinery, G = 1
+    sc = b @ alpha.T
+    assert np.array_equal(idx, np.argmax(sc, axis=1))
+    np.testing.assert_array_equal(val, sc.max(axis=1))
+    eng.close()
