@@ -107,11 +107,12 @@ struct RefineWork {
     int32_t* slot_n = nullptr;           // [slot_cap] tiles in the slot's list
     int32_t* tiles = nullptr;            // [slot_cap][k_tiles] filtered tile list of the entry
     unsigned long long* emax = nullptr;  // [slot_cap] max exact score, order-preserving bit pattern (0 = none)
-    int32_t* eidx = nullptr;             // [slot_cap] smallest candidate index attaining emax
+    int32_t* eidx = nullptr;             // [slot_cap] 0x7fffffff - (smallest candidate index attaining emax); 0 = none
     double* ib_val = nullptr;            // [slot_cap] best of the candidates the entry's own block scored
     int32_t* ib_idx = nullptr;           // [slot_cap] (0x7fffffff = none)
     int* cnt = nullptr;                  // [2] items reserved, slots reserved
     int item_cap = 0, slot_cap = 0;
+    size_t zero_bytes = 0;               // cnt, emax, eidx are one allocation starting at cnt: bytes to clear per launch
 };
 
 // fp64 re-decision of queued near-ties.  PROJ: scores are b . Gamma[a,o,v,:]; else b . alpha[v,:]

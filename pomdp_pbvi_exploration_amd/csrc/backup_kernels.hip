@@ -495,6 +495,7 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
     __shared__ int ltile[REFINE_LIST_CAP];
     __shared__ int lbase, loverflow;
     __shared__ int sh_slot, sh_base;
+    __shared__ double red[4];
     __shared__ double wbest[4];
     __shared__ int widx[4];
     if ((int)blockIdx.x >= *qcount) return;
@@ -598,12 +599,29 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
             }
         }
         __syncthreads();
-        for (int c = wid; c < ncand; c += 4) {               // one candidate per wave, ascending v within a wave
-            const int vv = cand[c];
-            const double tot = refine_wave_dot<T, PROJ>(brow, alpha + (int64_t)vv * lda, mv, a, o, gamma, L, n_tiles, lane);
-            if (tot > bestval) {
-                bestval = tot;
-                bestidx = vv;
+        if (ncand <= 2) {
+            // the common case (a runner-up inside the window): all 256 threads on one dot at a time -- a quarter of
+            // the latency of giving each candidate to a single wave
+            const TileList tl{L, n_tiles};
+            for (int c = 0; c < ncand; ++c) {
+                const int vv = cand[c];
+                const T* arow = alpha + (int64_t)vv * lda;
+                const double part = PROJ ? proj_dot_partial(brow, arow, mv, a, o, gamma, tl)
+                                         : plain_dot_partial(brow, arow, mv.S, tl);
+                const double tot = block_sum(part, red);
+                if (tot > bestval) {                         // every wave tracks the same (value, index)
+                    bestval = tot;
+                    bestidx = vv;
+                }
+            }
+        } else {
+            for (int c = wid; c < ncand; c += 4) {           // one candidate per wave, ascending v within a wave
+                const int vv = cand[c];
+                const double tot = refine_wave_dot<T, PROJ>(brow, alpha + (int64_t)vv * lda, mv, a, o, gamma, L, n_tiles, lane);
+                if (tot > bestval) {
+                    bestval = tot;
+                    bestidx = vv;
+                }
             }
         }
     }
@@ -672,7 +690,7 @@ __global__ void k_refine_first(RefineWork work) {
         const int sl = work.items_slot[i];
         if (sl < 0) continue;
         const double sc = work.scores[i];
-        if (sc == sc && ordered_bits(sc) == work.emax[sl]) atomicMin(&work.eidx[sl], work.items_v[i]);
+        if (sc == sc && ordered_bits(sc) == work.emax[sl]) atomicMax(&work.eidx[sl], 0x7fffffff - work.items_v[i]);
     }
 }
 
@@ -684,7 +702,7 @@ __global__ void k_refine_merge(RefineWork work, int32_t* __restrict__ best_v, do
         int bi = work.ib_idx[sl];
         if (work.emax[sl] != 0ull) {
             const double wv = unordered_bits(work.emax[sl]);
-            const int wi = work.eidx[sl];
+            const int wi = 0x7fffffff - work.eidx[sl];   // stored reversed so that zero-filled memory means "none"
             if (bi == 0x7fffffff || wv > bv || (wv == bv && wi < bi)) {
                 bv = wv;
                 bi = wi;
@@ -707,9 +725,8 @@ hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entrie
     if (max_entries <= 0) return hipSuccess;
     hipError_t e;
     if (work.items_v != nullptr) {
-        if ((e = hipMemsetAsync(work.cnt, 0, 2 * sizeof(int), st)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(work.emax, 0, (size_t)work.slot_cap * sizeof(unsigned long long), st)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(work.eidx, 0x7f, (size_t)work.slot_cap * sizeof(int32_t), st)) != hipSuccess) return e;
+        // cnt, emax and eidx live in one allocation (cnt first): one fill
+        if ((e = hipMemsetAsync(work.cnt, 0, work.zero_bytes, st)) != hipSuccess) return e;
     }
     if (proj)
         hipLaunchKernelGGL((k_refine<T, true>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,

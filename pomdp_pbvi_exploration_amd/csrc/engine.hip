@@ -824,19 +824,19 @@ class EngineT : public EngineBase {
         if ((rc = rf_entry_.ensure((size_t)slots * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = rf_n_.ensure((size_t)slots * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = rf_tiles_.ensure((size_t)slots * k_tiles * sizeof(int32_t), &bytes_))) return rc;
-        if ((rc = rf_emax_.ensure((size_t)slots * sizeof(unsigned long long), &bytes_))) return rc;
-        if ((rc = rf_eidx_.ensure((size_t)slots * sizeof(int32_t), &bytes_))) return rc;
+        const size_t zero_bytes = 16 + (size_t)slots * (sizeof(unsigned long long) + sizeof(int32_t));
+        if ((rc = rf_cnt_.ensure(zero_bytes, &bytes_))) return rc;      // [cnt: 16 B][emax][eidx]
         if ((rc = rf_ibv_.ensure((size_t)slots * sizeof(double), &bytes_))) return rc;
         if ((rc = rf_ibi_.ensure((size_t)slots * sizeof(int32_t), &bytes_))) return rc;
-        if ((rc = rf_cnt_.ensure(2 * sizeof(int), &bytes_))) return rc;
         w->items_v = rf_v_.as<int32_t>();
         w->items_slot = rf_slot_.as<int32_t>();
         w->scores = rf_sc_.as<double>();
         w->slot_entry = rf_entry_.as<int32_t>();
         w->slot_n = rf_n_.as<int32_t>();
         w->tiles = rf_tiles_.as<int32_t>();
-        w->emax = rf_emax_.as<unsigned long long>();
-        w->eidx = rf_eidx_.as<int32_t>();
+        w->emax = reinterpret_cast<unsigned long long*>(rf_cnt_.as<char>() + 16);
+        w->eidx = reinterpret_cast<int32_t*>(rf_cnt_.as<char>() + 16 + (size_t)slots * sizeof(unsigned long long));
+        w->zero_bytes = zero_bytes;
         w->ib_val = rf_ibv_.as<double>();
         w->ib_idx = rf_ibi_.as<int32_t>();
         w->cnt = rf_cnt_.as<int>();

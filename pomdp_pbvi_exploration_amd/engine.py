@@ -286,11 +286,17 @@ class Engine:
         _check((self._lib.pbvi_alpha_store_reset if which == 'alpha' else self._lib.pbvi_belief_store_reset)(self._h))
         self._store_epoch[which] += 1
 
-    def row_ids(self, which: str, objects, values_of) -> np.ndarray:
+    def row_ids(self, which: str, objects, values_of, owner=None) -> np.ndarray:
         """Store ids of ``objects`` (AlphaVector / Belief instances, list order); rows not yet in this engine's
         store are uploaded in one batch.  The id lives on the object (``_dev``), tagged with this engine and the
-        store epoch."""
+        store epoch.  ``owner`` (the ValueFunction / BeliefSet holding the list) caches the id array so the
+        per-object walk happens once per container, not once per call; containers drop ``_dev_ids`` when they
+        change."""
         tag = (id(self), which, self._store_epoch[which])
+        if owner is not None:
+            c = getattr(owner, '_dev_ids', None)
+            if c is not None and c[0] == tag and len(c[1]) == len(objects):
+                return c[1]
         missing = [o for o in objects if getattr(o, '_dev', (None, -1))[0] != tag]
         if missing:
             # the same object may appear twice in a list: upload it once
@@ -302,11 +308,14 @@ class Engine:
             first = self.store_rows(which, np.stack([np.asarray(values_of(o)) for o in todo]))
             for k, o in enumerate(todo):
                 o._dev = (tag, first + k)
-        return np.fromiter((o._dev[1] for o in objects), dtype=np.int32, count=len(objects))
+        ids = np.fromiter((o._dev[1] for o in objects), dtype=np.int32, count=len(objects))
+        if owner is not None:
+            owner._dev_ids = (tag, ids)
+        return ids
 
-    def sync_rows(self, which: str, objects, values_of) -> None:
+    def sync_rows(self, which: str, objects, values_of, owner=None) -> None:
         """Make ``objects`` the working set: upload what is missing (``row_ids``), then select by id."""
-        ids = self.row_ids(which, objects, values_of)
+        ids = self.row_ids(which, objects, values_of, owner)
         if which == 'alpha':
             self.select_alpha(ids)
         else:
@@ -324,7 +333,8 @@ class Engine:
             out[i0:i0 + self._BLOCK] = self.max_value_resident()[0]
         return out
 
-    def max_value_objects(self, alpha_objects, belief_objects, alpha_values, belief_values) -> np.ndarray:
+    def max_value_objects(self, alpha_objects, belief_objects, alpha_values, belief_values, alpha_owner=None,
+                          belief_owner=None) -> np.ndarray:
         """``max_v b.alpha_v`` for every belief object against the set of alpha objects, reusing earlier results.
 
         ``compute_change`` (``src/pomdp.py:2141-2169``) asks for this twice per backup on the whole accumulated
@@ -332,8 +342,8 @@ class Engine:
         rows, and a belief scored before keeps its value, so only (known beliefs x new alpha rows) and
         (new beliefs x all alpha rows) go through the GEMM.  Values are the engine's exact re-scored ones, so the
         result equals the from-scratch one.  Entries are keyed by the set of alpha store ids."""
-        a_ids = self.row_ids('alpha', alpha_objects, alpha_values)
-        b_ids = self.row_ids('belief', belief_objects, belief_values)
+        a_ids = self.row_ids('alpha', alpha_objects, alpha_values, alpha_owner)
+        b_ids = self.row_ids('belief', belief_objects, belief_values, belief_owner)
         epochs = (self._store_epoch['alpha'], self._store_epoch['belief'])
         if self._vmax_epochs != epochs:
             self._vmax_cache, self._vmax_epochs = [], epochs

@@ -318,12 +318,14 @@ class ValueFunction:
         assert alpha_vector.values.shape[0] == self.model.state_count, "Vector to add to value function doesn't have the right size"
         self._uniqueness_dict[alpha_vector.values.tobytes()] = alpha_vector
         self._vector_list = list(self._uniqueness_dict.values())
+        self._dev_ids = None
         self._vector_array = None
         self._actions = None
 
     def extend(self, other: 'ValueFunction') -> None:
         self._uniqueness_dict.update(other._uniqueness_dict)
         self._vector_list = list(self._uniqueness_dict.values())
+        self._dev_ids = None
         self._vector_array = None
         self._actions = None
         self._pruning_level = 1
@@ -395,8 +397,10 @@ class ValueFunction:
             self._vector_array = arr[keep]
             self._actions = self._actions[keep]
             self._vector_list = None
+            self._dev_ids = None
             self._uniqueness_dict = {r.tobytes(): AlphaVector(r, a) for r, a in zip(self._vector_array, self._actions)}
             self._vector_list = list(self._uniqueness_dict.values())
+            self._dev_ids = None
         self._pruning_level = level
 
 

@@ -313,8 +313,8 @@ class PBVI_Solver(Solver):
             # working sets are selected by id in list order (tie-breaks follow the host order), the device
             # runs the backup, and only the distinct new rows come back.
             eng = value_function.model.engine
-            eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values)
-            eng.sync_rows('belief', belief_set.belief_list, lambda b: b.values)
+            eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values, owner=value_function)
+            eng.sync_rows('belief', belief_set.belief_list, lambda b: b.values, owner=belief_set)
             eng.run(self.gamma, belief_dominance_prune)
             alpha_new, actions = eng.fetch().value_function_rows(use_keep=belief_dominance_prune)
             new_vf = ValueFunction(value_function.model, alpha_new, actions)
@@ -484,8 +484,10 @@ class PBVI_Solver(Solver):
             # (belief, alpha) pairs and keeps the rest (Engine.max_value_objects)
             eng = value_function.model.engine
             beliefs = belief_set.belief_list
-            old = eng.max_value_objects(value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda x: x.values)
-            new = eng.max_value_objects(new_value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda x: x.values)
+            old = eng.max_value_objects(value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda x: x.values,
+                                        alpha_owner=value_function, belief_owner=belief_set)
+            new = eng.max_value_objects(new_value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda x: x.values,
+                                        alpha_owner=new_value_function, belief_owner=belief_set)
         else:
             b = belief_set.belief_array
             old = np.max(np.matmul(b, value_function.alpha_vector_array.T), axis=1)
