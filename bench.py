@@ -26,6 +26,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F64_MFMA_TFLOPS = 78.6       # MI355X_MICROARCH.md: v_mfma_f64_16x16x4_f64, dense
 PEAK_HBM_GBS = 8000.0
 
 
@@ -60,6 +61,7 @@ def main():
     ap.add_argument('--reach', type=int, default=1, choices=[1, 5], help='reachable states per (s,a)')
     ap.add_argument('--cpu-sample', type=int, default=1024, help='beliefs in the CPU baseline sample (0 = skip)')
     ap.add_argument('--grid', type=str, default='75x400')
+    ap.add_argument('--dtype', type=str, default='f32', choices=['f32', 'f64'], help='engine arithmetic type')
     ap.add_argument('--formulation', type=str, default='auto', choices=['auto', 'alpha', 'belief'],
                     help='operand projected through the model (pbvi_set_formulation)')
     ap.add_argument('--mode', type=str, default='sparse', choices=['sparse', 'dense'],
@@ -91,7 +93,7 @@ def main():
     B = args.beliefs
     beliefs = synth.belief_points(m, B, start=rank * B)            # this rank's block of the global set
 
-    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32', device=local_rank,
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=args.dtype, device=local_rank,
                  mode=args.mode)
     eng.set_formulation(args.formulation)
     eng.set_alpha(alpha)
@@ -139,17 +141,19 @@ def main():
         flops_dense = stats[0]['score_flops']                   # 2*B*S*A*O*V
         flops = stats[0]['score_flops_executed']                # same, restricted to structurally non-zero tiles
         achieved = flops / (ms_score * 1e-3) / 1e12
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_F64_MFMA_TFLOPS
+        gemm_name = ('k_gemm_nt_f32_streamk' if args.dtype == 'f32' else 'k_gemm_nt_f64_mfma')
         out = {
             'metric': 'alpha-vector backups/sec', 'value': B * world * K / elapsed, 'unit': 'backups/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'olfactory-{m.S} {"reachable-sparse" if args.mode == "sparse" else "dense-projection"} R={m.R} backup (S={m.S}, A={m.A}, O={m.O}), '
                                    f'V={args.alphas} alpha-vectors, B={B} beliefs per GPU',
                        'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': args.alphas, 'B_per_gpu': B,
                        'parallelism': f'belief-sharded x{world}, 1 all-gather of alpha rows' if distributed else 'single GPU'},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_gemm_nt_f32_streamk (belief x Gamma score GEMM, non-zero tiles)',
-                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+            'roofline': {'bound': 'mfma', 'kernel': f'{gemm_name} (belief x Gamma score GEMM, non-zero tiles)',
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': None,
                          'flops_per_launch': flops, 'ms_per_launch': ms_score,
                          'dense_flops_per_launch': flops_dense,
                          'dense_equivalent_tflops': flops_dense / (ms_score * 1e-3) / 1e12,
@@ -165,7 +169,7 @@ def main():
         try:
             with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')) as fh:
                 pmc = json.load(fh)
-            if (args.mode == 'sparse' and m.S == 30000 and m.R == 1 and args.alphas == 1024 and B == 1024):
+            if (args.mode == 'sparse' and args.dtype == 'f32' and m.S == 30000 and m.R == 1 and args.alphas == 1024 and B == 1024):
                 out['roofline']['traffic'] = pmc['traffic_bytes']
                 out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes)'
         except (OSError, KeyError, ValueError):

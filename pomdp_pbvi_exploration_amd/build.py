@@ -13,7 +13,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libpbvi_hip.so')
-SOURCES = ['gemm.hip', 'backup_kernels.hip', 'engine.hip']
+SOURCES = ['gemm.hip', 'gemm_f64.hip', 'backup_kernels.hip', 'engine.hip']
 
 
 def _stale() -> bool:

@@ -47,14 +47,31 @@ void set_error(const std::string& msg) { g_err = msg; }
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    // grow-only; contents are NOT preserved on growth
+    // grow-only; contents are NOT preserved on growth.  A buffer that grows again gets 25 % headroom: in a solve
+    // loop the alpha set gains a few rows per backup, and re-allocating a multi-GB buffer (hipFree + hipMalloc,
+    // both synchronising, hundreds of ms at 20 GB) on every call would dwarf the backup itself.
     int ensure(size_t bytes, int64_t* total) {
         if (bytes <= cap) return PBVI_OK;
+        const bool regrow = p != nullptr;
         if (p) {
             (void)hipFree(p);
             *total -= (int64_t)cap;
             p = nullptr;
             cap = 0;
+        }
+        if (regrow) {
+            const size_t want = bytes + bytes / 4;
+            if (hipMalloc(&p, want) == hipSuccess) {
+                cap = want;
+                *total += (int64_t)want;
+                if (poison_enabled()) {
+                    if (hipMemset(p, 0xFF, want) != hipSuccess) (void)hipGetLastError();
+                    (void)hipDeviceSynchronize();
+                }
+                return PBVI_OK;
+            }
+            (void)hipGetLastError();                     // no room for the headroom: fall through to the exact size
+            p = nullptr;
         }
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
@@ -228,6 +245,7 @@ class EngineT : public EngineBase {
     DevBuf rf_v_, rf_slot_, rf_sc_, rf_entry_, rf_n_, rf_tiles_, rf_emax_, rf_eidx_, rf_ibv_, rf_ibi_, rf_cnt_;   // refinement work list
     int formulation_ = 0;                                   // 0 auto, 1 project alpha-vectors, 2 project beliefs
     int last_formulation_ = 1;
+    int64_t f64_pairs_ = 0;                                 // tile pairs of the last fp64 MFMA GEMM (0: plain kernel)
     const int32_t* res_action_ = nullptr;                  // results in caller order
     const int32_t* res_best_ = nullptr;
     int64_t res_unique_ = 0;
@@ -455,10 +473,13 @@ class EngineT : public EngineBase {
         } else {
             HIPCHK(hipMemcpyAsync(bel_.p, stage_.p, (size_t)B * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
         }
-        if (kF32) {   // which 256x32 belief tiles hold a non-zero (A-operand side of zero-tile skipping)
+        {   // which 256x32 belief tiles hold a non-zero (A-operand side of zero-tile skipping)
             const int k_tiles = S_pad_ / GEMM_BK;
             if ((rc = nzA_.ensure((size_t)(Bp / GEMM_BM) * k_tiles, &bytes_))) return rc;
-            HIPCHK(launch_tile_nonzero_f32((const float*)bel_.p, S_pad_, (int)Bp, k_tiles, nzA_.as<uint8_t>(), stream_));
+            if constexpr (kF32)
+                HIPCHK(launch_tile_nonzero_f32((const float*)bel_.p, S_pad_, (int)Bp, k_tiles, nzA_.as<uint8_t>(), stream_));
+            else
+                HIPCHK(launch_tile_nonzero_f64((const double*)bel_.p, S_pad_, (int)Bp, k_tiles, nzA_.as<uint8_t>(), stream_));
         }
         HIPCHK(hipStreamSynchronize(stream_));
         B_ = B;
@@ -845,6 +866,12 @@ class EngineT : public EngineBase {
         return PBVI_OK;
     }
 
+    // fp64 engines: MFMA GEMM unless the problem is a handful of tiles (the plain kernel is as good there)
+    static bool f64_uses_mfma(int64_t m_rows, int64_t n_rows) {
+        static const bool simple = getenv("PBVI_F64_SIMPLE") != nullptr;      // debug / A-B only
+        return !simple && m_rows * n_rows >= 64 * 64;
+    }
+
     int set_formulation(int f) override {
         if (f < 0 || f > 2) FAIL(PBVI_EINVAL, "set_formulation: 0 = auto, 1 = project alpha-vectors, 2 = project beliefs");
         formulation_ = f;
@@ -888,8 +915,19 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
         sv->fixed = 0;
     } else {
         if ((rc = slabs_.ensure((size_t)m_rows * rows_y * sizeof(T), &bytes_))) return rc;
-        HIPCHK(launch_gemm_nt_simple<T>(X, S_pad_, Y, S_pad_, slabs_.as<T>(), (int)rows_y, (int)m_rows, (int)rows_y,
-                                        S_, stream_));
+        f64_pairs_ = 0;
+        if (!f64_uses_mfma(m_rows, rows_y)) {
+            HIPCHK(launch_gemm_nt_simple<T>(X, S_pad_, Y, S_pad_, slabs_.as<T>(), (int)rows_y, (int)m_rows, (int)rows_y,
+                                            S_, stream_));
+        } else {
+            const int kt32 = S_pad_ / GEMM_BK;
+            if ((rc = klist_.ensure(gemm_f64_klist_ints((int)m_rows, (int)rows_y, kt32) * sizeof(int), &bytes_))) return rc;
+            if ((rc = kcount_.ensure(gemm_f64_pairs((int)m_rows, (int)rows_y) * sizeof(int), &bytes_))) return rc;
+            HIPCHK(launch_gemm_nt_f64((const double*)X, S_pad_, (int)m_rows, (const double*)Y, S_pad_, (int)rows_y,
+                                      slabs_.as<double>(), (int)rows_y, S_pad_, nzX, nzB, G, v_group, klist_.as<int>(),
+                                      kcount_.as<int>(), stream_));
+            f64_pairs_ = (int64_t)gemm_f64_pairs((int)m_rows, (int)rows_y);
+        }
         sv->slabs = slabs_.as<T>();
         sv->slab_stride = 0;
         sv->ldc = (int)rows_y;
@@ -1071,7 +1109,9 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     } else {
     // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
     const uint8_t* need = nullptr;
-    if (kF32) {
+    // f64 engines: the 128-row tiles of their MFMA GEMM nest inside these 256-row ones, so the set is a superset;
+    // the plain kernel (tiny problems) reads every Gamma element and needs them all written.
+    if (kF32 || f64_uses_mfma(B_, N)) {
         if ((rc = need_.ensure((size_t)AO * k_tiles, &bytes_))) return rc;
         HIPCHK(launch_need_tiles(nzA_.as<uint8_t>(), (int)(B_pad_ / GEMM_BM), nzB_.as<uint8_t>(), AO, (int)V_, k_tiles,
                                  need_.as<uint8_t>(), stream_));
@@ -1104,6 +1144,11 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
                             kF32 ? queue_.as<int32_t>() : nullptr, qcount, stream_));
     HIPCHK(hipEventRecord(ev_[3], stream_));
     std::vector<int> h_kcount;
+    const int64_t f64_pairs = f64_pairs_;
+    if (!kF32 && st && f64_pairs > 0) {
+        h_kcount.resize((size_t)f64_pairs);
+        HIPCHK(hipMemcpyAsync(h_kcount.data(), kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    }
     if (kF32 && st) {   // list lengths of this GEMM (K5 rebuilds the lists for its own GEMM later)
         h_kcount.resize((size_t)plan.tiles_m * plan.tiles_n);
         HIPCHK(hipMemcpyAsync(h_kcount.data(), kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -1221,6 +1266,13 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
             st->score_tiles_dense = (int64_t)plan.tiles_m * plan.tiles_n * plan.k_tiles;
             st->score_tiles_run = kt_sum;
             st->split_k = plan.max_chunks;
+        } else if (f64_pairs > 0) {   // fp64 MFMA path: 128 x 128 tiles, lists in 32-column steps
+            int64_t kt_sum = 0;
+            for (int c : h_kcount) kt_sum += c;
+            st->score_flops_executed = kt_sum * 2LL * 128 * 128 * 32;
+            st->score_tiles_dense = f64_pairs * (S_pad_ / GEMM_BK);
+            st->score_tiles_run = kt_sum;
+            st->split_k = 1;
         } else {
             st->score_flops_executed = st->score_flops;
             st->split_k = 1;

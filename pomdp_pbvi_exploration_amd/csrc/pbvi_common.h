@@ -42,7 +42,16 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
                               int* kcount, int* nchunks, hipStream_t stream, int batch = 1,
                               int64_t batch_stride_b = 0, int64_t batch_stride_c = 0, int* streamk_ws = nullptr);
 // streamk_ws layout: prefix[pairs+1], start_pair[nblocks], first_block[pairs], plan[2] = {steps per block, total steps}
-// Any-size reference GEMM (used for f64 engines): C[m][n], no padding requirements.
+// fp64 MFMA GEMM (gemm_f64.hip): C[M][N] = A[M][K_pad] * B[N][K_pad]^T, one dense result slab, zero-tile lists
+// built from 32-column maps: nzA [ceil(M/256)][K_pad/32] (or nullptr), nzB [G+1][K_pad/32] per row group (or nullptr).
+// klist: gemm_f64_klist_ints(M, N, K_pad/32) ints, kcount: gemm_f64_pairs(M, N) ints of device workspace.
+size_t gemm_f64_klist_ints(int M, int N, int kt32);
+size_t gemm_f64_pairs(int M, int N);
+hipError_t launch_tile_nonzero_f64(const double* X, int ld, int rows, int kt32, uint8_t* nz, hipStream_t stream);
+hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,
+                              int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
+                              int* kcount, hipStream_t stream);
+// Any-size reference GEMM (small f64 problems, A/B checks): C[m][n], no padding requirements.
 template <typename T>
 hipError_t launch_gemm_nt_simple(const T* A, int lda, const T* B, int ldb, T* C, int ldc,
                                  int M, int N, int K, hipStream_t stream);
