@@ -230,7 +230,7 @@ int pbvi_mdp_value_iteration(int device, int32_t S, int32_t A, int32_t R, const 
                              int32_t* out_iterations);
 
 /*
- * Which operand of the score GEMM is projected through the model (f32 sparse engines; same scores, re-associated):
+ * Which operand of the score GEMM is projected through the model (sparse mode; same scores, re-associated):
  *   1 = alpha-vectors, the reference's order (Gamma[a,o,v,:], src/pomdp.py:1489-1491; GEMM [B] x [A*O*V]);
  *   2 = beliefs (bp[a,o,b,:] = gamma * sum b[s] RTO[s,a,o,r] scattered to rs[s,a,r]; GEMM [B*A*O] x [V]);
  *   0 = automatic (default): the cheaper of the two by projected rows and 256-row tile count -- the belief side

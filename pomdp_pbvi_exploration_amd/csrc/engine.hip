@@ -1032,12 +1032,14 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     //   alpha-side (the reference's order): Gamma = A*O*(V+1)+2A rows, GEMM  [B] x [Gamma rows]
     //   belief-side: bp = B*A*O rows,                                  GEMM  [B*A*O] x [V]
     // The belief side wins when B << V (the solve loop: ~100 new beliefs against thousands of alpha-vectors):
-    // fewer rows to project and far less 256-row tile padding.  f32 sparse engines only.
+    // fewer rows to project and far less tile padding.  Sparse mode only.
     bool use_push = false;
-    if (kF32 && mode_ != PBVI_DENSE && (int64_t)B_ * AO <= 0x7fffffff) {
+    if (mode_ != PBVI_DENSE && (int64_t)B_ * AO <= 0x7fffffff && (kF32 || f64_uses_mfma(B_ * AO, V_))) {
+        const int64_t bm = kF32 ? GEMM_BM : 128;                       // GEMM tile edge and sustained rate per dtype
+        const double rate = kF32 ? 130e12 : 45e12;
         auto cost = [&](int64_t m_rows, int64_t n_rows, int64_t proj_rows) {
-            const double tiles = (double)((m_rows + GEMM_BM - 1) / GEMM_BM) * (double)((n_rows + GEMM_BN - 1) / GEMM_BN);
-            return tiles * S_pad_ * (2.0 * GEMM_BM * GEMM_BN / 130e12) + (double)proj_rows * S_pad_ * sizeof(T) / 3e12;
+            const double tiles = (double)((m_rows + bm - 1) / bm) * (double)((n_rows + bm - 1) / bm);
+            return tiles * S_pad_ * (2.0 * bm * bm / rate) + (double)proj_rows * S_pad_ * sizeof(T) / 3e12;
         };
         const double c_pull = cost(B_, N, N), c_push = cost(B_ * AO, V_, B_ * AO);
         use_push = formulation_ == 2 || (formulation_ == 0 && c_push < 0.8 * c_pull);
@@ -1098,6 +1100,8 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
                                       alpha_.as<T>() + (size_t)V_ * S_pad_, bp_.as<T>(), S_pad_, pmag_.as<double>(), stream_));
         if constexpr (kF32)
             HIPCHK(launch_tile_nonzero_f32((const float*)bp_.p, S_pad_, (int)M_pad, k_tiles, nzP_.as<uint8_t>(), stream_));
+        else
+            HIPCHK(launch_tile_nonzero_f64((const double*)bp_.p, S_pad_, (int)M_pad, k_tiles, nzP_.as<uint8_t>(), stream_));
         HIPCHK(hipEventRecord(ev_[1], stream_));
         if ((rc = score_gemm(alpha_.as<T>(), V_, nullptr, 1, (int)V_, &sv, bp_.as<T>(), M, nzP_.as<uint8_t>()))) return rc;
         sv.push = 1;
