@@ -230,6 +230,18 @@ int pbvi_mdp_value_iteration(int device, int32_t S, int32_t A, int32_t R, const 
                              int32_t* out_iterations);
 
 /*
+ * Belief walk of the FSVI-style expansions (PBVI_Solver.expand_fsvi / expand_fsvi_eg, src/pomdp.py:1895-1935; the
+ * trajectory of (action, observation) pairs is simulated by the caller in the underlying MDP and does not depend
+ * on the beliefs): n chained Bayes updates (Belief.update, :382-421) entirely on the device, in fp64,
+ *   b_{i+1} = update(restart[i] ? b0 : b_i, actions[i], observations[i]),        b_0 = b0
+ * Each b_{i+1} is appended to the belief row store (so the following backup selects it by id with no upload) and
+ * copied to out_beliefs [n][S] fp64 (host), which the caller's containers need for their byte-keyed dedup.
+ * restart may be NULL (never).  Returns the store id of b_1 (b_{i+1} has id + i), or a negative error code.
+ */
+int64_t pbvi_belief_walk(pbvi_engine_t* e, const double* b0, int64_t n, const int32_t* actions, const int32_t* observations,
+                         const uint8_t* restart, double* out_beliefs);
+
+/*
  * Which operand of the score GEMM is projected through the model (sparse mode; same scores, re-associated):
  *   1 = alpha-vectors, the reference's order (Gamma[a,o,v,:], src/pomdp.py:1489-1491; GEMM [B] x [A*O*V]);
  *   2 = beliefs (bp[a,o,b,:] = gamma * sum b[s] RTO[s,a,o,r] scattered to rs[s,a,r]; GEMM [B*A*O] x [V]);

@@ -1240,6 +1240,70 @@ hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, const int3
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------- //
+// Belief walk (FSVI-style expansion, src/pomdp.py:1895-1935): n sequential Bayes updates
+//   b_{i+1} = normalise( sum_{(s,r)->s'} base_i[s] * RTO[s, a_i, o_i, r] ),   base_i = restart[i] ? b0 : b_i
+// in fp64 whatever the engine's T (the host mirror keeps fp64 belief values).  One step = k_walk_push (pull over
+// the inverse lists in bincount's accumulation order, per-block partial masses) + k_walk_norm (every block sums
+// the partials in the same fixed order, so the normaliser is deterministic; writes the fp64 row and the T row of
+// the device store).  Products and sums are not fused so the un-normalised values equal NumPy's bincount.
+// ------------------------------------------------------------------------- //
+template <typename T>
+__global__ void k_walk_push(const double* __restrict__ base, ModelView<T> mv, const int32_t* __restrict__ in_ptr,
+                            const int32_t* __restrict__ in_src, int a, int o, double* __restrict__ unnorm,
+                            double* __restrict__ partial) {
+#pragma clang fp contract(off)
+    __shared__ double red[4];
+    const int sp = blockIdx.x * 256 + threadIdx.x;
+    double u = 0.0;
+    if (sp < mv.S) {
+        const int32_t* ptr = in_ptr + (int64_t)a * (mv.S + 1);
+        const int32_t* src = in_src + (int64_t)a * mv.S * mv.R;
+        const T* rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
+        for (int j = ptr[sp]; j < ptr[sp + 1]; ++j) {
+            const int e = src[j];
+            const int s = e / mv.R, r = e - s * mv.R;
+            const double w = (double)rto[(int64_t)r * mv.S_pad + s] * base[s];
+            u = u + w;
+        }
+        unnorm[sp] = u;
+    }
+    const double tot = block_sum(u, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+template <typename T>
+__global__ void k_walk_norm(const double* __restrict__ unnorm, const double* __restrict__ partial, int n_partial, int S,
+                            int S_pad, double* __restrict__ out64, T* __restrict__ out_store) {
+    __shared__ double mass_sh;
+    if (threadIdx.x == 0) {
+        double m = 0.0;
+        for (int i = 0; i < n_partial; ++i) m += partial[i];   // same order in every block
+        mass_sh = m;
+    }
+    __syncthreads();
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < S) {
+        const double v = unnorm[s] / mass_sh;
+        out64[s] = v;
+        out_store[s] = (T)v;
+    } else if (s < S_pad) {
+        out_store[s] = T(0);
+    }
+}
+
+template <typename T>
+hipError_t launch_walk_step(const double* base, ModelView<T> mv, const int32_t* in_ptr, const int32_t* in_src, int a, int o,
+                            double* unnorm, double* partial, double* out64, T* out_store, hipStream_t st) {
+    const int blocks = (mv.S_pad + 255) / 256;
+    hipLaunchKernelGGL(k_walk_push<T>, dim3(blocks), dim3(256), 0, st, base, mv, in_ptr, in_src, a, o, unnorm, partial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_walk_norm<T>, dim3(blocks), dim3(256), 0, st, unnorm, partial, blocks, mv.S, mv.S_pad, out64,
+                       out_store);
+    return hipGetLastError();
+}
+
 // explicit instantiations
 #define PBVI_INST(T)                                                                                                   \
     template hipError_t launch_support<T>(ModelView<T>, uint8_t*, hipStream_t);                                        \
@@ -1272,6 +1336,8 @@ hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, const int3
                                                double, const T*, T*, int, double*, hipStream_t);                      \
     template hipError_t launch_rdot<T>(const T*, int, int, ModelView<T>, const int32_t*, const int32_t*, double*,      \
                                        hipStream_t);                                                                   \
+    template hipError_t launch_walk_step<T>(const double*, ModelView<T>, const int32_t*, const int32_t*, int, int,     \
+                                            double*, double*, double*, T*, hipStream_t);                               \
     template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
 PBVI_INST(float)
 PBVI_INST(double)

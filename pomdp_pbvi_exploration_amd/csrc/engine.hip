@@ -212,6 +212,8 @@ class EngineBase {
     virtual int belief_update(const int32_t* act, const int32_t* obs, void* out) = 0;
     virtual int beliefs_advance(const int32_t* act, const int32_t* obs, const uint8_t* keep, int64_t* out_B) = 0;
     virtual int beliefs_fetch(void* out) = 0;
+    virtual int64_t belief_walk(const double* b0, int64_t n, const int32_t* act, const int32_t* obs, const uint8_t* restart,
+                                double* out) = 0;
     virtual int64_t beliefs_count() const = 0;
 };
 
@@ -237,7 +239,7 @@ class EngineT : public EngineBase {
     DevBuf rep_, uniq_, inv_, slot_, out_full_;            // K6 key dedup: out_ holds the unique rows
     DevBuf store_[2], ids_;                                // device row stores: [0] alpha-vectors, [1] beliefs
     int64_t store_rows_[2] = {0, 0};
-    DevBuf in_ptr_, in_src_, bu_act_, bu_obs_, bu_row_, bu_unnorm_, bu_mass_, bu_out_;   // batched belief update
+    DevBuf in_ptr_, in_src_, bu_act_, bu_obs_, bu_row_, bu_unnorm_, bu_mass_, bu_out_, walk64_;   // batched belief update
     std::vector<int32_t> h_rs_;                                // host copy of rs [A][R][S_pad] for the lazy CSC build
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     DevBuf bp_, nzP_, pmag_, prd_;                          // belief-side formulation: projected beliefs, tile map, magnitudes, b.ER
@@ -269,7 +271,7 @@ class EngineT : public EngineBase {
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
-                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &bp_, &nzP_, &pmag_, &prd_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
+                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &bp_, &nzP_, &pmag_, &prd_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &rf_emax_, &rf_eidx_, &rf_ibv_, &rf_ibi_, &rf_cnt_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
@@ -662,6 +664,58 @@ class EngineT : public EngineBase {
         }
         store_rows_[which] = have + n;
         return have;
+    }
+
+    // make room for n more rows in a store, keeping what is there; returns the destination of the new rows
+    int store_reserve(int which, int64_t n, T** dst) {
+        DevBuf& st = store_[which];
+        const int64_t have = store_rows_[which];
+        const size_t need = (size_t)(have + n) * S_pad_ * sizeof(T);
+        if (need > st.cap) {
+            DevBuf nb;
+            int rc = nb.ensure(std::max(need, st.cap * 2), &bytes_);
+            if (rc) return rc;
+            if (have > 0) HIPCHK(hipMemcpyAsync(nb.p, st.p, (size_t)have * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            bytes_ -= (int64_t)st.cap;
+            st.release();
+            st = nb;
+        }
+        *dst = st.as<T>() + (size_t)have * S_pad_;
+        return PBVI_OK;
+    }
+
+    // FSVI-style walk: n chained Bayes updates on the device (fp64), every new belief appended to the belief store
+    // and copied to `out` [n][S] fp64.  Returns the store id of the first new belief.
+    int64_t belief_walk(const double* b0, int64_t n, const int32_t* act, const int32_t* obs, const uint8_t* restart,
+                        double* out) override {
+        if (!b0 || n <= 0 || !act || !obs || !out) FAIL(PBVI_EINVAL, "belief_walk: bad arguments");
+        if ((int64_t)S_ * R_ > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "belief_walk: S*R exceeds int32");
+        for (int64_t i = 0; i < n; ++i)
+            if (act[i] < 0 || act[i] >= A_ || obs[i] < 0 || obs[i] >= O_) FAIL(PBVI_EINVAL, "belief_walk: action / observation out of range");
+        HIPCHK(hipSetDevice(device_));
+        int rc = build_inverse_lists();
+        if (rc) return rc;
+        const int blocks = (S_pad_ + 255) / 256;
+        if ((rc = walk64_.ensure((size_t)(n + 1) * S_ * sizeof(double), &bytes_))) return rc;      // row 0 = b0
+        if ((rc = bu_unnorm_.ensure((size_t)S_ * sizeof(double), &bytes_))) return rc;
+        if ((rc = bu_mass_.ensure((size_t)blocks * sizeof(double), &bytes_))) return rc;
+        T* dst = nullptr;
+        if ((rc = store_reserve(1, n, &dst))) return rc;
+        double* rows = walk64_.as<double>();
+        HIPCHK(hipMemcpyAsync(rows, b0, (size_t)S_ * sizeof(double), hipMemcpyHostToDevice, stream_));
+        const ModelView<T> mv = view();
+        for (int64_t i = 0; i < n; ++i) {
+            const double* base = (restart && restart[i]) ? rows : rows + (size_t)i * S_;       // row i = b_i (row 0 = b0)
+            HIPCHK(launch_walk_step<T>(base, mv, in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), act[i], obs[i],
+                                       bu_unnorm_.as<double>(), bu_mass_.as<double>(), rows + (size_t)(i + 1) * S_,
+                                       dst + (size_t)i * S_pad_, stream_));
+        }
+        HIPCHK(hipMemcpyAsync(out, rows + S_, (size_t)n * S_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        const int64_t first = store_rows_[1];
+        store_rows_[1] = first + n;
+        return first;
     }
 
     int store_reset(int which) override {
@@ -1562,6 +1616,12 @@ int pbvi_beliefs_advance(pbvi_engine_t* e, const int32_t* actions, const int32_t
                          int64_t* out_B) {
     NEED(e);
     return e->impl->beliefs_advance(actions, observations, keep, out_B);
+}
+
+int64_t pbvi_belief_walk(pbvi_engine_t* e, const double* b0, int64_t n, const int32_t* actions, const int32_t* observations,
+                         const uint8_t* restart, double* out_beliefs) {
+    NEED(e);
+    return e->impl->belief_walk(b0, n, actions, observations, restart, out_beliefs);
 }
 
 int pbvi_beliefs_fetch(pbvi_engine_t* e, void* out_beliefs) {

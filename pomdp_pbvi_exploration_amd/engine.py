@@ -28,7 +28,7 @@ EXPORTS = [
     'pbvi_alpha_store_append', 'pbvi_alpha_select', 'pbvi_alpha_store_reset',
     'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset', 'pbvi_debug_poison',
     'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
-    'pbvi_mdp_value_iteration', 'pbvi_set_formulation',
+    'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk',
 ]
 
 
@@ -99,6 +99,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_mdp_value_iteration': (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int32, i32p, f64p, f64p, f64p,
                                                C.c_double, C.c_double, C.c_int32, f64p, f64p, i32p]),
         'pbvi_set_formulation': (C.c_int, [vp, C.c_int]),
+        'pbvi_belief_walk': (C.c_int64, [vp, f64p, C.c_int64, i32p, i32p, u8p, f64p]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -485,6 +486,35 @@ class Engine:
         _check(self._lib.pbvi_belief_update(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)),
                                             o.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(out)))
         return out
+
+    def belief_walk(self, b0: np.ndarray, actions, observations, restart=None):
+        """Chained Bayes updates on the device (``pbvi_belief_walk``): returns ``(values [n,S] f64, first store id)``;
+        belief ``i`` of the walk is already in the belief store under id ``first + i``."""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        o = np.ascontiguousarray(observations, dtype=np.int32)
+        n = a.shape[0]
+        if o.shape != (n,) or n == 0:
+            raise ValueError('actions / observations must be equally long and non-empty')
+        start = np.ascontiguousarray(b0, dtype=np.float64)
+        if start.shape != (self.S,):
+            raise ValueError(f'b0 must be [{self.S}]')
+        rp = None
+        if restart is not None:
+            r = np.ascontiguousarray(restart, dtype=np.uint8)
+            if r.shape != (n,):
+                raise ValueError('restart must be [n]')
+            rp = r.ctypes.data_as(C.POINTER(C.c_uint8))
+        out = np.empty((n, self.S), dtype=np.float64)
+        f64p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        first = int(self._lib.pbvi_belief_walk(self._h, start.ctypes.data_as(f64p), n, a.ctypes.data_as(i32p),
+                                               o.ctypes.data_as(i32p), rp, out.ctypes.data_as(f64p)))
+        if first < 0:
+            _check(first)
+        return out, first
+
+    def belief_tag(self):
+        """Tag that marks an object as resident in this engine's belief store (see ``row_ids``)."""
+        return (id(self), 'belief', self._store_epoch['belief'])
 
     def advance_beliefs(self, actions, observations, keep=None) -> int:
         """Simulator step on the resident block (``src/pomdp.py:3305-3329``): Bayes-update every belief with its

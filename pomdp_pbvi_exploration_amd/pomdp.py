@@ -417,7 +417,43 @@ class PBVI_Solver(Solver):
                         * err[b_i[:, None], a_i[:, None], model.observations[None, :]], axis=1)
         return BeliefSet(model, succ[b_i[:, None], a_i[:, None], o_i[:, None], model.states[None, :]])
 
+    def _walk_device(self, model, b0: Belief, policy_action, max_generation: int) -> BeliefSet:
+        """``_walk`` with the beliefs on the device.  The (action, observation) trajectory is simulated in the underlying
+        MDP and does not depend on the beliefs, so it is drawn first (same random draws, same order), then the n
+        chained Bayes updates run in one C-ABI call (``pbvi_belief_walk``): the new beliefs land in the engine's
+        belief store -- the following backup selects them by id, nothing is uploaded -- and their fp64 values come
+        back once for the containers' byte-keyed dedup."""
+        acts, obs, restart = [], [], []
+        s = b0.random_state()
+        fresh = True                                   # the belief this step starts from is b0
+        for i in range(max_generation - 1):
+            a = int(policy_action(i, s))
+            s_p = model.transition(s, a)
+            acts.append(a)
+            obs.append(model.observe(s_p, a))
+            restart.append(fresh)
+            fresh = False
+            s = s_p
+            if s in model.end_states:
+                s = b0.random_state()
+                fresh = True
+        if not acts:
+            return BeliefSet(model, [b0])
+        eng = model.engine
+        values, first = eng.belief_walk(b0.values, acts, obs, restart)
+        tag = eng.belief_tag()
+        seq = [b0]
+        for i in range(len(acts)):
+            nb = Belief.__new__(Belief)
+            nb.model = b0.model
+            nb._values = values[i]
+            nb._dev = (tag, first + i)
+            seq.append(nb)
+        return BeliefSet(model, seq)
+
     def _walk(self, model, b0: Belief, policy_action, max_generation: int) -> BeliefSet:
+        if getattr(model, 'is_on_gpu', False):
+            return self._walk_device(model, b0, policy_action, max_generation)
         seq = [b0]
         s = b0.random_state()
         b = b0

@@ -659,3 +659,42 @@ def test_exact_ties_with_hundreds_of_candidates(formulation):
     assert np.array_equal(idx, np.argmax(sc, axis=1))
     np.testing.assert_array_equal(val, sc.max(axis=1))
     eng.close()
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_belief_walk_matches_host_updates(dtype):
+    """pbvi_belief_walk: chained Bayes updates with restarts equal Belief.update applied step by step (fp64 engines:
+    to rounding of the normaliser; f32 engines: to the f32 rounding of the model tables), and the rows it leaves in
+    the belief store are the ones a following selection reads."""
+    m = synth.olfactory_model(H=15, W=40, R=5, f32=(dtype == 'f32'))
+    from test_policy_eval import mirror_model
+    model = mirror_model(m)
+    rng = np.random.default_rng(9)
+    b0 = Belief(model)
+    n = 40
+    acts = rng.integers(0, m.A, size=n)
+    obs = np.zeros(n, dtype=int)
+    restart = rng.random(n) < 0.15
+    restart[0] = True
+    want, b = [], b0
+    for i in range(n):
+        if restart[i]:
+            b = b0
+        for o in rng.permutation(m.O):              # an observation that is possible from here
+            nb = b.update(int(acts[i]), int(o))
+            if np.isfinite(nb.values).all():
+                obs[i] = o
+                b = nb
+                break
+        want.append(b.values)
+    want = np.array(want)
+    eng = Engine.for_model(model, dtype=dtype)
+    got, first = eng.belief_walk(b0.values, acts, obs, restart)
+    tol = 1e-13 if dtype == 'f64' else 1e-6
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol * 1e-3)
+    assert np.allclose(got.sum(axis=1), 1.0, atol=1e-12)
+    got2, first2 = eng.belief_walk(b0.values, acts[:5], obs[:5], None)     # appended after the first walk's rows
+    assert first2 == first + n
+    eng.select_beliefs(np.arange(first, first + n))
+    np.testing.assert_allclose(eng.fetch_beliefs(), got.astype(eng.np_dtype), rtol=0, atol=0)
+    eng.close()
