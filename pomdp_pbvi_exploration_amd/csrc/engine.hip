@@ -889,8 +889,10 @@ class EngineT : public EngineBase {
             while (p < x && p < hi) p <<= 1;
             return p;
         };
-        const int64_t items = pow2(max_entries * V, (int64_t)1 << 16, (int64_t)1 << 24);
-        const int64_t slots = pow2(max_entries, 1024, 65536);
+        int64_t items = pow2(max_entries * V, (int64_t)1 << 16, (int64_t)1 << 24);
+        int64_t slots = pow2(max_entries, 1024, 65536);
+        if (const char* c = getenv("PBVI_REFINE_ITEM_CAP")) items = std::max<int64_t>(1, atoll(c));   // tests: force the
+        if (const char* c = getenv("PBVI_REFINE_SLOT_CAP")) slots = std::max<int64_t>(1, atoll(c));   // overflow paths
         if (items <= 0 || slots <= 0) return PBVI_OK;
         int rc;
         if ((rc = rf_v_.ensure((size_t)items * sizeof(int32_t), &bytes_))) return rc;

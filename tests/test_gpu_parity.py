@@ -698,3 +698,33 @@ def test_belief_walk_matches_host_updates(dtype):
     eng.select_beliefs(np.arange(first, first + n))
     np.testing.assert_allclose(eng.fetch_beliefs(), got.astype(eng.np_dtype), rtol=0, atol=0)
     eng.close()
+
+
+def test_exact_ties_on_a_support_wider_than_the_lds_tile_list():
+    """|S| = 131072 with dense dyadic beliefs: 4096 non-zero tiles per belief, twice what the refinement keeps in
+    LDS -- the kernel falls back to the belief's global tile list.  Exact arithmetic again, so np.argmax's first
+    index is the only right answer."""
+    rng = np.random.default_rng(5)
+    S, A, O, R, V, B = 131072, 1, 2, 1, 30, 3
+    rs = rng.integers(0, S, size=(S, A, R))
+    rto = np.empty((S, A, O, R))
+    rto[:, :, 0, 0] = np.where(rng.random((S, A)) < 0.5, 0.25, 0.75)
+    rto[:, :, 1, 0] = 1.0 - rto[:, :, 0, 0]
+    er = rng.integers(-2, 3, size=(S, A)).astype(np.float64)
+    base = rng.integers(-4, 5, size=(3, S)).astype(np.float64)
+    alpha = base[rng.integers(0, 3, size=V)]
+    b = np.zeros((B, S))
+    b[0, :] = 1.0 / S
+    b[1, :S // 2] = 2.0 / S
+    b[2, S // 2:] = 2.0 / S
+    want_rows, want_a, want_v = orc.backup_core(alpha, b, rs, rto, er, 0.5)
+    eng = Engine(S, A, O, R, rs, rto, er, dtype='f32')
+    eng.set_alpha(alpha)
+    eng.set_beliefs(b)
+    st = eng.run(0.5)
+    res = eng.fetch()
+    assert st['n_refined'] > 0 and st['n_refine_candidates'] >= 2 * st['n_refined']
+    assert np.array_equal(res.best_alpha_ind, want_v)
+    assert np.array_equal(res.actions, want_a)
+    np.testing.assert_array_equal(res.alpha, want_rows)
+    eng.close()
