@@ -70,6 +70,25 @@ __global__ void k_build_klists_f64(const uint8_t* __restrict__ nzA, const uint8_
     if (tid == 0) kcount[pair] = total;
 }
 
+// Longest lists first: blocks are dispatched in index order, so handing out the heavy tile pairs first leaves the
+// light ones to fill the tail (LPT scheduling).  One block; counting sort by list length (<= kt32), stable.
+__global__ void k_order_pairs_f64(const int* __restrict__ kcount, int pairs, int kt32, int* __restrict__ hist /* [kt32+2] zeroed */,
+                                  int* __restrict__ order) {
+    const int tid = threadIdx.x;
+    for (int p = tid; p < pairs; p += blockDim.x) atomicAdd(&hist[kt32 - kcount[p]], 1);      // bin 0 = longest
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int b = 0; b <= kt32; ++b) {
+            const int c = hist[b];
+            hist[b] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < pairs; p += blockDim.x) order[atomicAdd(&hist[kt32 - kcount[p]], 1)] = p;
+}
+
 // non-zero map of a double matrix at the f32 path's granularity: nz[row block of 256][32-column tile]
 __global__ void k_tile_nonzero_f64(const double* __restrict__ X, int ld, int rows, int kt32, uint8_t* __restrict__ nz) {
     const int tile = blockIdx.y;
@@ -95,11 +114,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64_mfma(const double* __res
                                                              const double* __restrict__ B, int ldb, int N,
                                                              double* __restrict__ C, int ldc, int tiles_m,
                                                              const int* __restrict__ klist,
-                                                             const int* __restrict__ kcount, int kt32) {
+                                                             const int* __restrict__ kcount, int kt32,
+                                                             const int* __restrict__ order) {
     extern __shared__ double lds_f64[];                    // [2][128 * D_LD] A then [2][128 * D_LD] B: 72 KiB (dynamic:
     double (*As)[D_BM * D_LD] = reinterpret_cast<double (*)[D_BM * D_LD]>(lds_f64);                 // above the 64 KiB
     double (*Bs)[D_BN * D_LD] = reinterpret_cast<double (*)[D_BN * D_LD]>(lds_f64 + 2 * D_BM * D_LD);   // static limit)
-    const int pair = blockIdx.x;
+    const int pair = order ? order[blockIdx.x] : (int)blockIdx.x;
     const int tm = pair % tiles_m, tn = pair / tiles_m;
     const int m0 = tm * D_BM, n0 = tn * D_BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -189,7 +209,9 @@ hipError_t launch_tile_nonzero_f64(const double* X, int ld, int rows, int kt32, 
 size_t gemm_f64_klist_ints(int M, int N, int kt32) {
     return (size_t)((M + D_BM - 1) / D_BM) * ((N + D_BN - 1) / D_BN) * kt32;
 }
+// kcount workspace: [pairs] list lengths, [pairs] dispatch order, [kt32 + 2] histogram
 size_t gemm_f64_pairs(int M, int N) { return (size_t)((M + D_BM - 1) / D_BM) * ((N + D_BN - 1) / D_BN); }
+size_t gemm_f64_kcount_ints(int M, int N, int kt32) { return 2 * gemm_f64_pairs(M, N) + (size_t)kt32 + 2; }
 
 hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,
                               int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
@@ -212,8 +234,13 @@ hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, 
         if (e != hipSuccess) return e;
         attr_done = true;
     }
+    int* order = kcount + pairs;
+    int* hist = order + pairs;
+    if ((e = hipMemsetAsync(hist, 0, (size_t)(kt32 + 2) * sizeof(int), stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_order_pairs_f64, dim3(1), dim3(1024), 0, stream, kcount, (int)pairs, kt32, hist, order);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(k_gemm_nt_f64_mfma, dim3((unsigned)pairs), dim3(256), lds_bytes, stream, A, lda, M, B, ldb, N, C,
-                       ldc, tiles_m, klist, kcount, kt32);
+                       ldc, tiles_m, klist, kcount, kt32, order);
     return hipGetLastError();
 }
 

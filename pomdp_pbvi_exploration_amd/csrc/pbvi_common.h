@@ -44,9 +44,11 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
 // streamk_ws layout: prefix[pairs+1], start_pair[nblocks], first_block[pairs], plan[2] = {steps per block, total steps}
 // fp64 MFMA GEMM (gemm_f64.hip): C[M][N] = A[M][K_pad] * B[N][K_pad]^T, one dense result slab, zero-tile lists
 // built from 32-column maps: nzA [ceil(M/256)][K_pad/32] (or nullptr), nzB [G+1][K_pad/32] per row group (or nullptr).
-// klist: gemm_f64_klist_ints(M, N, K_pad/32) ints, kcount: gemm_f64_pairs(M, N) ints of device workspace.
+// klist: gemm_f64_klist_ints(M, N, K_pad/32) ints, kcount: gemm_f64_kcount_ints(...) ints of device workspace (the
+// first gemm_f64_pairs(M, N) of them are the list lengths).
 size_t gemm_f64_klist_ints(int M, int N, int kt32);
 size_t gemm_f64_pairs(int M, int N);
+size_t gemm_f64_kcount_ints(int M, int N, int kt32);
 hipError_t launch_tile_nonzero_f64(const double* X, int ld, int rows, int kt32, uint8_t* nz, hipStream_t stream);
 hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,
                               int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
