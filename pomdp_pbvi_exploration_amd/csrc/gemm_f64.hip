@@ -127,26 +127,35 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64_mfma(const double* __res
     const int* kl = klist + (int64_t)pair * kt32;
     const int nsteps = kcount[pair] * 2;                   // 16-column steps
 
-    // staging: thread t moves 8 consecutive doubles of row t/2 (two threads per 128-byte row segment)
-    const int srow = tid >> 1, scol = (tid & 1) * 8;
-    const bool a_ok = m0 + srow < M, b_ok = n0 + srow < N;
-    const double* ap = A + (int64_t)(a_ok ? m0 + srow : 0) * lda + scol;
-    const double* bp = B + (int64_t)(b_ok ? n0 + srow : 0) * ldb + scol;
+    // staging: instruction c of thread t moves 16 bytes of row c*32 + t/8, column chunk t%8 -- a wave instruction
+    // covers eight whole 128-byte row segments (full cache lines)
+    const int srow = tid >> 3, scol = (tid & 7) * 2;
+    const double* ap[4];
+    const double* bp[4];
+    bool a_ok[4], b_ok[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int r = c * 32 + srow;
+        a_ok[c] = m0 + r < M;
+        b_ok[c] = n0 + r < N;
+        ap[c] = A + (int64_t)(a_ok[c] ? m0 + r : 0) * lda + scol;
+        bp[c] = B + (int64_t)(b_ok[c] ? n0 + r : 0) * ldb + scol;
+    }
     f64x2 ra[4], rb[4];
     auto fetch = [&](int step) {
         const int k0 = kl[step >> 1] * 32 + (step & 1) * D_BK;
         const f64x2 z = {0.0, 0.0};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            ra[c] = a_ok ? *(const f64x2*)(ap + k0 + 2 * c) : z;
-            rb[c] = b_ok ? *(const f64x2*)(bp + k0 + 2 * c) : z;
+            ra[c] = a_ok[c] ? *(const f64x2*)(ap[c] + k0) : z;
+            rb[c] = b_ok[c] ? *(const f64x2*)(bp[c] + k0) : z;
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            *(f64x2*)(&As[buf][srow * D_LD + scol + 2 * c]) = ra[c];
-            *(f64x2*)(&Bs[buf][srow * D_LD + scol + 2 * c]) = rb[c];
+            *(f64x2*)(&As[buf][(c * 32 + srow) * D_LD + scol]) = ra[c];
+            *(f64x2*)(&Bs[buf][(c * 32 + srow) * D_LD + scol]) = rb[c];
         }
     };
 
