@@ -77,35 +77,41 @@ class ShardedBackup:
 def gather_unique(dist, group, rows, count: int, index, actions, keep, n_total: int):
     """All-gather of deduplicated per-rank results.  Each rank contributes ``count`` unique alpha' rows
     (``rows[:count]``), its per-belief ``index`` into them, ``actions`` and ``keep``; blocks are padded to
-    the largest count so one ``all_gather_into_tensor`` per array suffices.  Returns the concatenated
+    the largest count; two ``all_gather_into_tensor`` calls in all (the per-belief integers and the row counts
+    travel together, then the rows).  Returns the concatenated
     unique rows ``[sum U_r, S]``, the global index ``[B]`` (offset per rank), actions and keep in belief
     order."""
     import torch
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     dev = rows.device
     S = rows.shape[1]
     per = index.shape[0]
-    cnt = torch.tensor([count], dtype=torch.int64, device=dev)
-    counts = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, cnt, group=group)
-    counts_h = counts.tolist()
+    # exchange 1: everything that is one int per belief, plus this rank's row count, in one message
+    meta = torch.empty(1 + 3 * per, dtype=torch.int32, device=dev)
+    meta[0] = count
+    meta[1:1 + per] = index
+    meta[1 + per:1 + 2 * per] = actions
+    meta[1 + 2 * per:] = keep
+    flat = torch.empty(world * (1 + 3 * per), dtype=torch.int32, device=dev)     # gloo wants a flat output
+    dist.all_gather_into_tensor(flat, meta, group=group)
+    all_meta = flat.view(world, 1 + 3 * per)
+    counts_h = all_meta[:, 0].tolist()
+    # exchange 2: the unique rows, padded to the largest count so one all-gather suffices
     umax = max(max(counts_h), 1)
-    send = torch.zeros((umax, S), dtype=rows.dtype, device=dev)
-    send[:count] = rows[:count]
+    if count == umax:
+        send = rows[:umax].contiguous()
+    else:
+        send = torch.zeros((umax, S), dtype=rows.dtype, device=dev)
+        send[:count] = rows[:count]
     all_rows = torch.empty((world * umax, S), dtype=rows.dtype, device=dev)
-    all_idx = torch.empty((world * per,), dtype=index.dtype, device=dev)
-    all_act = torch.empty((world * per,), dtype=actions.dtype, device=dev)
-    all_keep = torch.empty((world * per,), dtype=keep.dtype, device=dev)
     dist.all_gather_into_tensor(all_rows, send, group=group)
-    dist.all_gather_into_tensor(all_idx, index.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_act, actions.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_keep, keep.contiguous(), group=group)
     offs = [0]
     for c in counts_h[:-1]:
         offs.append(offs[-1] + c)
     uniq = torch.cat([all_rows[r * umax: r * umax + counts_h[r]] for r in range(world)], dim=0)
-    gidx = all_idx.view(world, per).to(torch.int64) + torch.tensor(offs, dtype=torch.int64, device=dev)[:, None]
+    gidx = all_meta[:, 1:1 + per].to(torch.int64) + torch.tensor(offs, dtype=torch.int64, device=dev)[:, None]
+    all_act = all_meta[:, 1 + per:1 + 2 * per].reshape(-1).to(actions.dtype)
+    all_keep = all_meta[:, 1 + 2 * per:].reshape(-1).to(keep.dtype)
     return uniq, gidx.reshape(-1)[:n_total], all_act[:n_total], all_keep[:n_total]
 
 
