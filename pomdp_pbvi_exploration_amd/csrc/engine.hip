@@ -256,7 +256,7 @@ class EngineT : public EngineBase {
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     DevBuf bp_, nzP_, pmag_, prd_;                          // belief-side formulation: projected beliefs, tile map, magnitudes, b.ER
     bool btl_valid_ = false;                                // btl_/btc_ describe the resident belief block
-    DevBuf rf_v_, rf_slot_, rf_sc_, rf_entry_, rf_n_, rf_tiles_, rf_emax_, rf_eidx_, rf_ibv_, rf_ibi_, rf_cnt_;   // refinement work list
+    DevBuf rf_v_, rf_slot_, rf_sc_, rf_entry_, rf_n_, rf_tiles_, rf_ibv_, rf_ibi_, rf_cnt_;   // refinement work list
     int formulation_ = 0;                                   // 0 auto, 1 project alpha-vectors, 2 project beliefs
     int last_formulation_ = 1;
     int64_t f64_pairs_ = 0;                                 // tile pairs of the last fp64 MFMA GEMM (0: plain kernel)
@@ -284,7 +284,7 @@ class EngineT : public EngineBase {
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &bp_, &nzP_, &pmag_, &prd_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
-                         &rf_emax_, &rf_eidx_, &rf_ibv_, &rf_ibi_, &rf_cnt_,
+                         &rf_ibv_, &rf_ibi_, &rf_cnt_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
