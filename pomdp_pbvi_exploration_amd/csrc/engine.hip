@@ -468,7 +468,7 @@ class EngineT : public EngineBase {
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(bel_.p, 0, (size_t)Bp * S_pad_ * sizeof(T), stream_));
         static const bool no_sort = getenv("PBVI_NO_BELIEF_SORT") != nullptr;     // debug / A-B only
-        sorted_ = kF32 && B > GEMM_BM && !no_sort;
+        sorted_ = B > (kF32 ? GEMM_BM : 128) && !no_sort;     // more than one row block of the score GEMM
         if (sorted_) {
             if ((rc = keys_.ensure((size_t)B * sizeof(int32_t), &bytes_))) return rc;
             if ((rc = perm_.ensure((size_t)B * sizeof(int32_t), &bytes_))) return rc;
