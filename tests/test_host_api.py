@@ -239,3 +239,112 @@ def test_value_function_file_round_trips(tmp_path):
                  ValueFunction.load_from_parquet(os.path.join(d, 'c.parquet'), model)):
         assert np.array_equal(back.alpha_vector_array, vf.alpha_vector_array)
         assert np.array_equal(back.actions, vf.actions)
+
+
+# --------------------------------------------------------------------------- #
+# Host-side logic of the GPU path, exercised on CPU with a NumPy stand-in for the device calls
+# (tests only: the product raises when the HIP library is missing, see test_gpu_request_never_falls_back)
+# --------------------------------------------------------------------------- #
+class _StubEngine:
+    """Stands in for engine.Engine in tests of the host bookkeeping around it: row stores, id tags, the
+    max-value cache and the belief walk; device kernels are replaced by NumPy on the stored rows."""
+
+    def __init__(self, model):
+        from pomdp_pbvi_exploration_amd.engine import Engine
+        self.model = model
+        self.S = model.state_count
+        self.rows = {'alpha': [], 'belief': []}
+        self._store_epoch = {'alpha': 0, 'belief': 0}
+        self._vmax_cache, self._vmax_epochs = [], None
+        self.pairs_scored = 0
+        # the real bookkeeping methods, bound to this object
+        for name in ('row_ids', 'max_value_objects', 'belief_tag'):
+            setattr(self, name, getattr(Engine, name).__get__(self))
+        self._VMAX_ENTRIES, self._BLOCK = Engine._VMAX_ENTRIES, Engine._BLOCK
+
+    def store_rows(self, which, rows):
+        first = len(self.rows[which])
+        self.rows[which].extend(np.asarray(rows, dtype=np.float64))
+        return first
+
+    def reset_store(self, which):
+        self.rows[which] = []
+        self._store_epoch[which] += 1
+
+    def _vmax_block(self, a_ids, b_ids):
+        a = np.array([self.rows['alpha'][i] for i in a_ids])
+        b = np.array([self.rows['belief'][i] for i in b_ids])
+        self.pairs_scored += len(a_ids) * len(b_ids)
+        return np.max(b @ a.T, axis=1)
+
+    def belief_walk(self, b0, actions, observations, restart=None):
+        out, b = [], Belief(self.model, np.asarray(b0))
+        start = b
+        for i, (a, o) in enumerate(zip(actions, observations)):
+            if restart is not None and restart[i]:
+                b = start
+            b = b.update(int(a), int(o))
+            out.append(b.values)
+        first = self.store_rows('belief', np.array(out))
+        return np.array(out), first
+
+
+def test_max_value_cache_scores_only_new_pairs():
+    """compute_change's bookkeeping (Engine.max_value_objects): values equal the from-scratch ones for every query
+    order of the solve loop, and only (known beliefs x new alpha rows) + (new beliefs x all alpha rows) are scored."""
+    from pomdp_pbvi_exploration_amd.mdp import AlphaVector
+    model, _ = load_POMDP_file(os.path.join(EXAMPLES, '4x3.95-no_loop_2_grid.POMDP'))
+    rng = np.random.default_rng(3)
+    S = model.state_count
+    alpha = rng.normal(size=(40, S))
+    bel = rng.random((30, S))
+    bel /= bel.sum(axis=1, keepdims=True)
+    A = [AlphaVector(r, 0) for r in alpha]
+    Bl = [Belief(model, r) for r in bel]
+    eng = _StubEngine(model)
+
+    def query(na, nb):
+        before = eng.pairs_scored
+        got = eng.max_value_objects(A[:na], Bl[:nb], lambda v: v.values, lambda x: x.values)
+        np.testing.assert_allclose(got, np.max(bel[:nb] @ alpha[:na].T, axis=1), rtol=1e-13)
+        return eng.pairs_scored - before
+
+    assert query(10, 12) == 10 * 12                    # cold
+    assert query(15, 20) == 5 * 12 + 15 * 8            # 5 new alpha rows on 12 known beliefs + 8 new beliefs on all 15
+    assert query(10, 20) == 10 * 8                     # the older alpha set again: only its 8 unseen beliefs
+    assert query(10, 20) == 0 and query(15, 20) == 0   # exact hits
+    assert query(15, 21) == 15                         # one more belief
+    got = eng.max_value_objects(A[20:25], Bl[:5], lambda v: v.values, lambda x: x.values)    # unrelated set
+    np.testing.assert_allclose(got, np.max(bel[:5] @ alpha[20:25].T, axis=1), rtol=1e-13)
+    eng.reset_store('alpha')                           # ids restart: nothing cached may be reused
+    for v in A:
+        v.__dict__.pop('_dev', None)
+    assert query(12, 6) == 12 * 6
+
+
+def test_device_walk_draws_the_same_trajectory_as_the_host_walk():
+    """PBVI_Solver._walk_device simulates the (a, o) trajectory first and updates the beliefs in one batched call; it
+    must consume the random streams exactly like the step-by-step host walk (same beliefs, same order)."""
+    from pomdp_pbvi_exploration_amd import FSVI_Solver
+    from pomdp_pbvi_exploration_amd.mdp import VI_Solver
+    model, _ = load_POMDP_file(os.path.join(EXAMPLES, '4x3.95-no_loop_2_grid.POMDP'))
+    model.end_states = [3, 6]
+    mdp_policy, _ = VI_Solver(gamma=0.95, eps=1e-6).solve(model, print_progress=False)
+    solver = FSVI_Solver(gamma=0.95, eps=1e-6)
+    for variant in ('fsvi', 'fsvi_eg'):
+        seqs = []
+        for device in (False, True):
+            np.random.seed(4)
+            random.seed(4)
+            m = model
+            if device:                                 # a model that claims GPU residency, backed by the stub
+                m = copy.copy(model)
+                m.is_on_gpu = True
+                m._engine = _StubEngine(model)
+            b0 = Belief(m)
+            fn = solver.expand_fsvi if variant == 'fsvi' else solver.expand_fsvi_eg
+            bs = fn(m, b0, mdp_policy, max_generation=60)
+            seqs.append((np.array([b.values for b in bs.belief_list]), np.random.random(), random.random()))
+        assert seqs[0][0].shape == seqs[1][0].shape == (60, model.state_count)
+        np.testing.assert_array_equal(seqs[0][0], seqs[1][0])
+        assert seqs[0][1:] == seqs[1][1:]              # both walks left the generators in the same state
