@@ -338,7 +338,49 @@ def gen_sim():
     print(f'tiger sim: mean steps {np.mean([len(h.actions) for h in hists]):.2f}')
 
 
+# --------------------------------------------------------------------------- #
+MODEL_ATTRS = ('transition_table', 'observation_table', 'immediate_reward_table', 'expected_rewards_table',
+               'reachable_states', 'reachable_probabilities', 'reachable_transitional_observation_table',
+               'start_probabilities')
+
+
+def gen_models():
+    """Every example .POMDP file the reference ships (Experiments/Example Models): the tables its loader builds, as
+    sha256 digests + shapes (pomdp_file_tables.json).  Files its loader rejects are listed with the error; files
+    whose tables it builds are stored whether or not they are stochastic (the test decides what to compare)."""
+    import glob
+    import gzip
+    import hashlib
+    import shutil
+    out = {}
+    dst = os.path.join(HERE, 'models')
+    for f in sorted(glob.glob(os.path.join(EXAMPLES, '*.POMDP')) + glob.glob(os.path.join(EXAMPLES, 'ejs', '*.POMDP'))):
+        name = os.path.relpath(f, EXAMPLES).replace(os.sep, '__')
+        if os.path.getsize(f) > 200000:                 # cit.POMDP: keep the fixture small
+            with open(f, 'rb') as src, gzip.open(os.path.join(dst, name + '.gz'), 'wb', compresslevel=9) as z:
+                shutil.copyfileobj(src, z)
+        else:
+            shutil.copyfile(f, os.path.join(dst, name))
+        try:
+            model, solver = quiet(ref.load_POMDP_file, f)
+        except Exception as e:                          # noqa: BLE001 -- recorded, not handled
+            out[name] = {'error': f'{type(e).__name__}: {e}'}
+            continue
+        entry = {'S': model.state_count, 'A': model.action_count, 'O': model.observation_count,
+                 'R': model.reachable_state_count, 'gamma': solver.gamma,
+                 'stochastic': bool(np.allclose(model.transition_table.sum(axis=2), 1.0) and
+                                    np.allclose(model.observation_table.sum(axis=2), 1.0)), 'tables': {}}
+        for attr in MODEL_ATTRS:
+            a = np.ascontiguousarray(getattr(model, attr))
+            entry['tables'][attr] = {'shape': list(a.shape), 'dtype': str(a.dtype),
+                                     'sha256': hashlib.sha256(a.tobytes()).hexdigest()}
+        out[name] = entry
+    with open(os.path.join(HERE, 'pomdp_file_tables.json'), 'w') as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print({k: ('error' if 'error' in v else ('ok' if v['stochastic'] else 'not stochastic')) for k, v in out.items()})
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['small', 'kat', 'c2']
     for w in which:
-        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim}[w]()
+        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models}[w]()
