@@ -240,6 +240,9 @@ int pbvi_mdp_value_iteration(int device, int32_t S, int32_t A, int32_t R, const 
  */
 int64_t pbvi_belief_walk(pbvi_engine_t* e, const double* b0, int64_t n, const int32_t* actions, const int32_t* observations,
                          const uint8_t* restart, double* out_beliefs);
+/* Optional fp64 copy of RTO ([S][A][O][R], as at creation) for pbvi_belief_walk on an f32 engine, so the fp64 belief
+ * values it returns do not depend on the engine's arithmetic type (f64 engines read their own table). */
+int pbvi_engine_set_rto_f64(pbvi_engine_t* e, const double* rto);
 
 /*
  * Which operand of the score GEMM is projected through the model (sparse mode; same scores, re-associated):

@@ -170,10 +170,11 @@ hipError_t launch_belief_update(const T* bel, int ldb, int B, ModelView<T> mv, c
                                 double* mass, T* out, int ldo, hipStream_t st);
 
 // one step of the belief walk: out64 [S] / out_store [S_pad] = normalised update of `base` (fp64 [S]) with (a, o);
-// unnorm [S], partial [ceil(S_pad/256)] fp64 scratch
+// unnorm [S], partial [ceil(S_pad/256)] fp64 scratch; rto64: fp64 copy of RTO in mv's layout, or nullptr = use mv.rto
 template <typename T>
-hipError_t launch_walk_step(const double* base, ModelView<T> mv, const int32_t* in_ptr, const int32_t* in_src, int a, int o,
-                            double* unnorm, double* partial, double* out64, T* out_store, hipStream_t st);
+hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* rto64, const int32_t* in_ptr,
+                            const int32_t* in_src, int a, int o, double* unnorm, double* partial, double* out64,
+                            T* out_store, hipStream_t st);
 
 // prune level 2: cnt[i] = #{j : alpha[j][s] >= alpha[i][s] for all s}
 template <typename T>

@@ -1248,22 +1248,23 @@ hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, const int3
 // the partials in the same fixed order, so the normaliser is deterministic; writes the fp64 row and the T row of
 // the device store).  Products and sums are not fused so the un-normalised values equal NumPy's bincount.
 // ------------------------------------------------------------------------- //
-template <typename T>
-__global__ void k_walk_push(const double* __restrict__ base, ModelView<T> mv, const int32_t* __restrict__ in_ptr,
-                            const int32_t* __restrict__ in_src, int a, int o, double* __restrict__ unnorm,
-                            double* __restrict__ partial) {
+// TT: type of the RTO table the walk reads (an f32 engine may hold an fp64 copy for it), T: type of the store rows
+template <typename TT>
+__global__ void k_walk_push(const double* __restrict__ base, const TT* __restrict__ rto_all, int S, int S_pad, int O, int R,
+                            const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src, int a, int o,
+                            double* __restrict__ unnorm, double* __restrict__ partial) {
 #pragma clang fp contract(off)
     __shared__ double red[4];
     const int sp = blockIdx.x * 256 + threadIdx.x;
     double u = 0.0;
-    if (sp < mv.S) {
-        const int32_t* ptr = in_ptr + (int64_t)a * (mv.S + 1);
-        const int32_t* src = in_src + (int64_t)a * mv.S * mv.R;
-        const T* rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
+    if (sp < S) {
+        const int32_t* ptr = in_ptr + (int64_t)a * (S + 1);
+        const int32_t* src = in_src + (int64_t)a * S * R;
+        const TT* rto = rto_all + (int64_t)(a * O + o) * R * S_pad;
         for (int j = ptr[sp]; j < ptr[sp + 1]; ++j) {
             const int e = src[j];
-            const int s = e / mv.R, r = e - s * mv.R;
-            const double w = (double)rto[(int64_t)r * mv.S_pad + s] * base[s];
+            const int s = e / R, r = e - s * R;
+            const double w = (double)rto[(int64_t)r * S_pad + s] * base[s];
             u = u + w;
         }
         unnorm[sp] = u;
@@ -1293,10 +1294,16 @@ __global__ void k_walk_norm(const double* __restrict__ unnorm, const double* __r
 }
 
 template <typename T>
-hipError_t launch_walk_step(const double* base, ModelView<T> mv, const int32_t* in_ptr, const int32_t* in_src, int a, int o,
-                            double* unnorm, double* partial, double* out64, T* out_store, hipStream_t st) {
+hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* rto64, const int32_t* in_ptr,
+                            const int32_t* in_src, int a, int o, double* unnorm, double* partial, double* out64,
+                            T* out_store, hipStream_t st) {
     const int blocks = (mv.S_pad + 255) / 256;
-    hipLaunchKernelGGL(k_walk_push<T>, dim3(blocks), dim3(256), 0, st, base, mv, in_ptr, in_src, a, o, unnorm, partial);
+    if (rto64 != nullptr)
+        hipLaunchKernelGGL(k_walk_push<double>, dim3(blocks), dim3(256), 0, st, base, rto64, mv.S, mv.S_pad, mv.O, mv.R,
+                           in_ptr, in_src, a, o, unnorm, partial);
+    else
+        hipLaunchKernelGGL(k_walk_push<T>, dim3(blocks), dim3(256), 0, st, base, mv.rto, mv.S, mv.S_pad, mv.O, mv.R, in_ptr,
+                           in_src, a, o, unnorm, partial);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_walk_norm<T>, dim3(blocks), dim3(256), 0, st, unnorm, partial, blocks, mv.S, mv.S_pad, out64,
@@ -1336,8 +1343,8 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const int32_t* 
                                                double, const T*, T*, int, double*, hipStream_t);                      \
     template hipError_t launch_rdot<T>(const T*, int, int, ModelView<T>, const int32_t*, const int32_t*, double*,      \
                                        hipStream_t);                                                                   \
-    template hipError_t launch_walk_step<T>(const double*, ModelView<T>, const int32_t*, const int32_t*, int, int,     \
-                                            double*, double*, double*, T*, hipStream_t);                               \
+    template hipError_t launch_walk_step<T>(const double*, ModelView<T>, const double*, const int32_t*, const int32_t*, \
+                                            int, int, double*, double*, double*, T*, hipStream_t);                     \
     template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
 PBVI_INST(float)
 PBVI_INST(double)

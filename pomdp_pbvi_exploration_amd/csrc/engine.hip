@@ -224,6 +224,7 @@ class EngineBase {
     virtual int belief_update(const int32_t* act, const int32_t* obs, void* out) = 0;
     virtual int beliefs_advance(const int32_t* act, const int32_t* obs, const uint8_t* keep, int64_t* out_B) = 0;
     virtual int beliefs_fetch(void* out) = 0;
+    virtual int set_rto_f64(const double* rto) = 0;
     virtual int64_t belief_walk(const double* b0, int64_t n, const int32_t* act, const int32_t* obs, const uint8_t* restart,
                                 double* out) = 0;
     virtual int64_t beliefs_count() const = 0;
@@ -251,7 +252,7 @@ class EngineT : public EngineBase {
     DevBuf rep_, uniq_, inv_, slot_, out_full_;            // K6 key dedup: out_ holds the unique rows
     DevBuf store_[2], ids_;                                // device row stores: [0] alpha-vectors, [1] beliefs
     int64_t store_rows_[2] = {0, 0};
-    DevBuf in_ptr_, in_src_, bu_act_, bu_obs_, bu_row_, bu_unnorm_, bu_mass_, bu_out_, walk64_;   // batched belief update
+    DevBuf in_ptr_, in_src_, bu_act_, bu_obs_, bu_row_, bu_unnorm_, bu_mass_, bu_out_, walk64_, rto64_;   // batched belief update
     std::vector<int32_t> h_rs_;                                // host copy of rs [A][R][S_pad] for the lazy CSC build
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     DevBuf bp_, nzP_, pmag_, prd_;                          // belief-side formulation: projected beliefs, tile map, magnitudes, b.ER
@@ -283,7 +284,7 @@ class EngineT : public EngineBase {
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
-                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &bp_, &nzP_, &pmag_, &prd_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
+                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &rf_ibv_, &rf_ibi_, &rf_cnt_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
@@ -698,6 +699,23 @@ class EngineT : public EngineBase {
         return PBVI_OK;
     }
 
+    // fp64 copy of RTO (reference layout [S][A][O][R]) for the belief walk of an f32 engine: the host mirror keeps
+    // fp64 belief values, and they should not depend on the engine's arithmetic type
+    int set_rto_f64(const double* rto) override {
+        if (!rto) FAIL(PBVI_EINVAL, "set_rto_f64: NULL table");
+        HIPCHK(hipSetDevice(device_));
+        std::vector<double> h((size_t)A_ * O_ * R_ * S_pad_, 0.0);
+        for (int s = 0; s < S_; ++s)
+            for (int a = 0; a < A_; ++a)
+                for (int o = 0; o < O_; ++o)
+                    for (int r = 0; r < R_; ++r)
+                        h[(((size_t)a * O_ + o) * R_ + r) * S_pad_ + s] = rto[(((size_t)s * A_ + a) * O_ + o) * R_ + r];
+        int rc = rto64_.ensure(h.size() * sizeof(double), &bytes_);
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(rto64_.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        return PBVI_OK;
+    }
+
     // FSVI-style walk: n chained Bayes updates on the device (fp64), every new belief appended to the belief store
     // and copied to `out` [n][S] fp64.  Returns the store id of the first new belief.
     int64_t belief_walk(const double* b0, int64_t n, const int32_t* act, const int32_t* obs, const uint8_t* restart,
@@ -720,7 +738,7 @@ class EngineT : public EngineBase {
         const ModelView<T> mv = view();
         for (int64_t i = 0; i < n; ++i) {
             const double* base = (restart && restart[i]) ? rows : rows + (size_t)i * S_;       // row i = b_i (row 0 = b0)
-            HIPCHK(launch_walk_step<T>(base, mv, in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), act[i], obs[i],
+            HIPCHK(launch_walk_step<T>(base, mv, rto64_.as<double>(), in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), act[i], obs[i],
                                        bu_unnorm_.as<double>(), bu_mass_.as<double>(), rows + (size_t)(i + 1) * S_,
                                        dst + (size_t)i * S_pad_, stream_));
         }
@@ -1637,6 +1655,11 @@ int64_t pbvi_belief_walk(pbvi_engine_t* e, const double* b0, int64_t n, const in
                          const uint8_t* restart, double* out_beliefs) {
     NEED(e);
     return e->impl->belief_walk(b0, n, actions, observations, restart, out_beliefs);
+}
+
+int pbvi_engine_set_rto_f64(pbvi_engine_t* e, const double* rto) {
+    NEED(e);
+    return e->impl->set_rto_f64(rto);
 }
 
 int pbvi_beliefs_fetch(pbvi_engine_t* e, void* out_beliefs) {

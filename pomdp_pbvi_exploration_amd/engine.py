@@ -28,7 +28,7 @@ EXPORTS = [
     'pbvi_alpha_store_append', 'pbvi_alpha_select', 'pbvi_alpha_store_reset',
     'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset', 'pbvi_debug_poison',
     'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
-    'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk',
+    'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk', 'pbvi_engine_set_rto_f64',
 ]
 
 
@@ -100,6 +100,7 @@ def load_library(path: str = LIB_PATH):
                                                C.c_double, C.c_double, C.c_int32, f64p, f64p, i32p]),
         'pbvi_set_formulation': (C.c_int, [vp, C.c_int]),
         'pbvi_belief_walk': (C.c_int64, [vp, f64p, C.c_int64, i32p, i32p, u8p, f64p]),
+        'pbvi_engine_set_rto_f64': (C.c_int, [vp, f64p]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -219,6 +220,11 @@ class Engine:
         self._store_epoch = {'alpha': 0, 'belief': 0}
         self.B = 0
         self._vmax_cache, self._vmax_epochs = [], None
+        if dtype == 'f32' and np.asarray(rto).dtype == np.float64:
+            # the belief walk returns fp64 belief values to the host containers: keep them independent of the
+            # engine's arithmetic type by giving it the fp64 table too (a few MB)
+            r64 = np.ascontiguousarray(rto, dtype=np.float64)
+            _check(lib.pbvi_engine_set_rto_f64(self._h, r64.ctypes.data_as(C.POINTER(C.c_double))))
 
     @classmethod
     def for_model(cls, model, dtype: str = 'f64', device: int = 0, mode: str = 'sparse') -> 'Engine':

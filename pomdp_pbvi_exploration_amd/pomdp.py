@@ -559,7 +559,11 @@ class PBVI_Solver(Solver):
         if ('fsvi' in self.expand_function or 'hsvi' in self.expand_function) and \
                 self.expand_function_params.get('mdp_policy') is None:
             log('[Warning] MDP solution not provided, running value iteration on the problem to retrieve it...')
-            mdp_solution, _ = VI_Solver(gamma=self.gamma, eps=self.eps).solve(model, use_gpu=use_gpu, print_progress=False)
+            # Device sweeps are bit-identical to the NumPy loop for R = 1 only; with several reachable states the sum
+            # over r may associate differently, and FSVI breaks exact Q-value ties (symmetric grids) by argmax --
+            # keep the reference's arithmetic there so seeded runs follow the reference's trajectory.
+            mdp_solution, _ = VI_Solver(gamma=self.gamma, eps=self.eps).solve(
+                model, use_gpu=use_gpu and model.reachable_state_count == 1, print_progress=False)
             self.expand_function_params['mdp_policy'] = mdp_solution
 
         max_allowed_change = self.eps * (self.gamma / (1 - self.gamma))

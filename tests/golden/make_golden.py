@@ -380,7 +380,36 @@ def gen_models():
     print({k: ('error' if 'error' in v else ('ok' if v['stochastic'] else 'not stochastic')) for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------- #
+SOLVE_MODELS = ('tiger-grid.POMDP', 'hallway.POMDP', 'cheese.95.POMDP', '4x4.95.POMDP', '4x3.95.POMDP', 'cit.POMDP')
+
+
+def gen_solve():
+    """FSVI solves of the reference on example models with many observations / dense transitions: per model the
+    belief-count and |V| trajectories and the final alpha set (cfg = expansions, max_belief_growth; seeds 0)."""
+    import random as pyrandom
+    out = {}
+    for name in SOLVE_MODELS:
+        model, solver = quiet(ref.load_POMDP_file, os.path.join(EXAMPLES, name))
+        np.random.seed(0)
+        pyrandom.seed(0)
+        t0 = time.time()
+        # (the reference's default 'ssea' expansion divides by zero-probability observations on all of these models
+        # and asserts; FSVI walks through actually reachable (state, observation) pairs)
+        exps, passes = (4, 12) if name == 'cit.POMDP' else (6, 12)
+        fsvi = ref.FSVI_Solver(gamma=solver.gamma, eps=1e-6)
+        vf, hist = quiet(fsvi.solve, model, expansions=exps, max_belief_growth=passes, print_progress=False)
+        key = name.replace('.POMDP', '').replace('.', '_').replace('-', '_')
+        out[f'{key}_alpha'] = np.array(vf.alpha_vector_array)
+        out[f'{key}_actions'] = np.asarray(vf.actions, dtype=np.int16)
+        out[f'{key}_beliefs'] = np.asarray(hist.beliefs_counts, dtype=np.int32)
+        out[f'{key}_alphas'] = np.asarray(hist.alpha_vector_counts, dtype=np.int32)
+        out[f'{key}_cfg'] = np.array([exps, passes])
+        print(f'{name}: S={model.state_count} |V|={len(vf)} beliefs={hist.beliefs_counts} in {time.time() - t0:.1f}s')
+    np.savez_compressed(os.path.join(HERE, 'example_solves.npz'), **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['small', 'kat', 'c2']
     for w in which:
-        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models}[w]()
+        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve}[w]()

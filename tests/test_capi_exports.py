@@ -15,7 +15,7 @@ HEADER = os.path.join(REPO, 'include', 'pbvi_hip.h')
 def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(pbvi_[a-z_]+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(pbvi_[a-z0-9_]+)\s*\(', text)))
 
 
 def test_library_is_built():

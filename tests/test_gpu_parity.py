@@ -728,3 +728,29 @@ def test_exact_ties_on_a_support_wider_than_the_lds_tile_list():
     assert np.array_equal(res.actions, want_a)
     np.testing.assert_array_equal(res.alpha, want_rows)
     eng.close()
+
+
+@pytest.mark.parametrize('name', ['tiger-grid.POMDP', 'hallway.POMDP', 'cheese.95.POMDP', '4x4.95.POMDP', '4x3.95.POMDP',
+                                  'cit.POMDP'])
+def test_fsvi_solves_of_example_models_match_reference_gpu(name, tmp_path):
+    """The reference's seeded FSVI solves of its example models (up to 28 observations, 56 reachable states per
+    (s, a)) through use_gpu=True: the fp64 engine reproduces the trajectories and the final alpha set; the f32 engine
+    runs the same loop and agrees on the value of the start belief to f32 accuracy."""
+    from test_host_api import solve_example
+    vf, hist, want = solve_example(name, tmp_path, use_gpu=True, engine_dtype='f64')
+    assert hist.beliefs_counts == list(want['beliefs'])
+    assert hist.alpha_vector_counts == list(want['alphas'])
+    # The alpha SET must be the reference's.  Its order may differ where two actions tie exactly at a belief (the
+    # symmetric 4x4 grid): the reference's pick then depends on its BLAS summation order, the engine's on its own.
+    got = np.asarray(vf.alpha_vector_array, dtype=np.float64)
+    key = lambda rows, acts: sorted((int(a),) + tuple(np.round(r, 8)) for r, a in zip(rows, acts))   # noqa: E731
+    assert key(got, vf.actions) == key(want['alpha'], want['actions'])
+    if name != '4x4.95.POMDP':
+        assert np.array_equal(np.asarray(vf.actions), want['actions'])
+        np.testing.assert_allclose(got, want['alpha'], rtol=1e-9, atol=1e-9)
+    vf32, hist32, _ = solve_example(name, tmp_path, use_gpu=True, engine_dtype='f32')
+    b0 = vf32.model.start_probabilities
+    v64 = float(np.max(want['alpha'] @ b0))
+    v32 = float(np.max(np.asarray(vf32.alpha_vector_array, dtype=np.float64) @ b0))
+    assert hist32.beliefs_counts == list(want['beliefs'])
+    assert abs(v32 - v64) <= 1e-4 * max(1.0, abs(v64))

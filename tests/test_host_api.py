@@ -390,3 +390,31 @@ def test_pomdp_file_loader_matches_reference_on_every_example_model(tmp_path):
             assert np.allclose(model.observation_table.sum(axis=2), 1.0), name
             fixed += 1
     assert compared == 20 and fixed == 2               # fixed: hanks.95, network.95
+
+
+SOLVE_MODELS = ('tiger-grid.POMDP', 'hallway.POMDP', 'cheese.95.POMDP', '4x4.95.POMDP', '4x3.95.POMDP', 'cit.POMDP')
+
+
+def solve_example(name, tmp_path, use_gpu=False, engine_dtype='f64'):
+    """The call make_golden.gen_solve made on the reference, on this package."""
+    z = load_npz('example_solves.npz')
+    key = name.replace('.POMDP', '').replace('.', '_').replace('-', '_')
+    model, solver = load_POMDP_file(_example_model_path(name, tmp_path))
+    np.random.seed(0)
+    random.seed(0)
+    exps, growth = (int(x) for x in z[f'{key}_cfg'])
+    vf, hist = FSVI_Solver(gamma=solver.gamma, eps=1e-6).solve(model, expansions=exps, max_belief_growth=growth,
+                                                               use_gpu=use_gpu, engine_dtype=engine_dtype, print_progress=False)
+    want = {k[len(key) + 1:]: z[k] for k in z if k.startswith(key + '_')}
+    return vf, hist, want
+
+
+@pytest.mark.parametrize('name', SOLVE_MODELS)
+def test_fsvi_solves_of_example_models_match_reference_host(name, tmp_path):
+    """Models with up to 28 observations and 56 reachable states per (s, a): trajectories and the final alpha set of
+    the reference's seeded FSVI solve, reproduced by the host mirror."""
+    vf, hist, want = solve_example(name, tmp_path)
+    assert hist.beliefs_counts == list(want['beliefs'])
+    assert hist.alpha_vector_counts == list(want['alphas'])
+    assert np.array_equal(np.asarray(vf.actions), want['actions'])
+    np.testing.assert_allclose(vf.alpha_vector_array, want['alpha'], rtol=1e-12, atol=1e-12)
