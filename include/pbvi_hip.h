@@ -77,7 +77,8 @@ typedef struct pbvi_stats {
     int64_t project_flops_executed; /* dense mode: MFMA flops issued by the projection GEMMs */
     int32_t split_k;        /* max K-chunks (partial slabs) per tile pair */
     int32_t formulation;    /* which operand was projected: 1 = alpha-vectors (Gamma), 2 = beliefs (pbvi_set_formulation) */
-    int64_t n_refine_candidates; /* f32 engines: alpha-vectors re-scored in fp64 over all refined triples */
+    int64_t n_refine_candidates; /* f32 engines: near-tie candidates listed over all refined triples (a triple that moves
+                                    to the GEMM path -- every alpha row re-scored -- stops listing) */
 } pbvi_stats_t;
 
 /* Library / device queries. */

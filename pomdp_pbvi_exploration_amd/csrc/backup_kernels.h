@@ -113,6 +113,16 @@ struct RefineWork {
     int* cnt = nullptr;                  // [2] items reserved, slots reserved
     int item_cap = 0, slot_cap = 0;
     size_t zero_bytes = 0;               // cnt, emax, eidx are one allocation starting at cnt: bytes to clear per launch
+    // Slots below w_slot_cap take the GEMM path instead of items: the entry's fp64 weight row (the belief pushed
+    // through (a, o), or the belief itself) against ALL alpha rows on the fp64 MFMA GEMM, then a first-max.
+    int w_slot_cap = 0;
+    double* W = nullptr;                 // [w_slot_cap][S_pad] weight rows
+    double* Cx = nullptr;                // [w_slot_cap][V] exact scores
+    uint8_t* nzW = nullptr;              // [ceil(w_slot_cap / 256)][S_pad / 32]
+    int* klistW = nullptr;               // workspace of launch_gemm_nt_f64_bf32
+    int* kcountW = nullptr;
+    const int32_t* in_ptr = nullptr;     // inverse transition lists (engine.hip::build_inverse_lists)
+    const int32_t* in_src = nullptr;
 };
 
 // fp64 re-decision of queued near-ties.  PROJ: scores are b . Gamma[a,o,v,:]; else b . alpha[v,:]

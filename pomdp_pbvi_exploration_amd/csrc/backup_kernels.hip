@@ -570,7 +570,7 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
                     if (sl >= work.slot_cap) sl = -1;
                 }
                 int ib = -1;
-                if (sl >= 0) {
+                if (sl >= work.w_slot_cap) {                 // item path (the GEMM path needs no items)
                     ib = atomicAdd(&work.cnt[0], ncand);
                     if (ib + ncand > work.item_cap) {        // no room: void whatever part of the range exists
                         for (int c = ib; c < work.item_cap && c < ib + ncand; ++c) work.items_slot[c] = -1;
@@ -582,14 +582,16 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
             }
             __syncthreads();
             const int sl = sh_slot, ib = sh_base;
-            if (sl >= 0 && slot < 0) {                       // first use of the slot: publish the entry and its tile list
-                for (int i = tid; i < n_tiles; i += 256) work.tiles[(int64_t)sl * k_tiles + i] = L[i];
+            if (sl >= 0 && slot < 0) {                       // first use of the slot: publish the entry (and its tile list)
+                if (sl >= work.w_slot_cap)
+                    for (int i = tid; i < n_tiles; i += 256) work.tiles[(int64_t)sl * k_tiles + i] = L[i];
                 if (tid == 0) {
                     work.slot_entry[sl] = e;
                     work.slot_n[sl] = n_tiles;
                 }
                 slot = sl;
             }
+            if (sl >= 0 && sl < work.w_slot_cap) break;      // GEMM path: every alpha row gets re-scored, nothing to list
             if (sl >= 0 && ib >= 0) {
                 for (int c = tid; c < ncand; c += 256) {
                     work.items_v[ib + c] = cand[c];
@@ -639,7 +641,9 @@ __global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict
                 bv = wbest[w];
                 bi = widx[w];
             }
-        if (slot >= 0) {                                     // merged with the work-list results in k_refine_merge
+        if (slot >= 0 && slot < work.w_slot_cap) {
+            // GEMM path: k_refine_slot_argmax decides from exact scores of all alpha rows
+        } else if (slot >= 0) {                              // merged with the work-list results in k_refine_merge
             work.ib_val[slot] = bv;
             work.ib_idx[slot] = bi;
         } else if (bi != 0x7fffffff) {
@@ -697,7 +701,7 @@ __global__ void k_refine_first(RefineWork work) {
 __global__ void k_refine_merge(RefineWork work, int32_t* __restrict__ best_v, double* __restrict__ best_score,
                                double* __restrict__ err) {
     const int n_slots = min(work.cnt[1], work.slot_cap);
-    for (int sl = blockIdx.x * blockDim.x + threadIdx.x; sl < n_slots; sl += gridDim.x * blockDim.x) {
+    for (int sl = work.w_slot_cap + blockIdx.x * blockDim.x + threadIdx.x; sl < n_slots; sl += gridDim.x * blockDim.x) {
         double bv = work.ib_val[sl];
         int bi = work.ib_idx[sl];
         if (work.emax[sl] != 0ull) {
@@ -712,6 +716,81 @@ __global__ void k_refine_merge(RefineWork work, int32_t* __restrict__ best_v, do
             const int e = work.slot_entry[sl];
             best_v[e] = bi;
             best_score[e] = bv;
+            err[e] = 0.0;
+        }
+    }
+}
+
+// GEMM path, step 1: the fp64 weight row of each slot's entry.  PROJ: w[s'] = gamma * sum_{(s,r)->s'} b[s] * RTO[s,a,o,r]
+// (pull over the inverse lists; products of fp32 values are exact in fp64), so that w . alpha_v is the entry's exact
+// score of alpha_v; plain: w = b.
+template <typename T, bool PROJ>
+__global__ void k_refine_weights(int G, const T* __restrict__ bel, int ldb, ModelView<T> mv, double gamma, RefineWork work) {
+    const int sl = blockIdx.y, sp = blockIdx.x * 256 + threadIdx.x;
+    if (sp >= mv.S_pad) return;
+    const int e = work.slot_entry[sl];
+    const int b = e / G, g = e % G;
+    const T* brow = bel + (int64_t)b * ldb;
+    double w = 0.0;
+    if (sp < mv.S) {
+        if constexpr (PROJ) {
+            const int a = g / mv.O, o = g % mv.O;
+            const int32_t* ptr = work.in_ptr + (int64_t)a * (mv.S + 1);
+            const int32_t* src = work.in_src + (int64_t)a * mv.S * mv.R;
+            const T* rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
+            for (int j = ptr[sp]; j < ptr[sp + 1]; ++j) {
+                const int en = src[j];
+                const int s = en / mv.R, r = en - s * mv.R;
+                w += (double)brow[s] * (double)rto[(int64_t)r * mv.S_pad + s];
+            }
+            w *= gamma;
+        } else {
+            w = (double)brow[sp];
+        }
+    }
+    work.W[(int64_t)sl * mv.S_pad + sp] = w;
+}
+
+// GEMM path, step 3: first maximum of the slot's exact scores over all V alpha rows
+__global__ void k_refine_slot_argmax(RefineWork work, int V, int32_t* __restrict__ best_v, double* __restrict__ best_score,
+                                     double* __restrict__ err) {
+    __shared__ double wv[4];
+    __shared__ int wi[4];
+    const int sl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const double* row = work.Cx + (int64_t)sl * V;
+    double m = -std::numeric_limits<double>::infinity();
+    int idx = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+        const double x = row[v];
+        if (x > m) {                                         // ascending v per thread: first maximum
+            m = x;
+            idx = v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double om = __shfl_xor(m, off, 64);
+        const int oi = __shfl_xor(idx, off, 64);
+        if (om > m || (om == m && oi < idx)) {
+            m = om;
+            idx = oi;
+        }
+    }
+    if (lane == 0) {
+        wv[wid] = m;
+        wi[wid] = idx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (wv[w] > m || (wv[w] == m && wi[w] < idx)) {
+                m = wv[w];
+                idx = wi[w];
+            }
+        if (idx != 0x7fffffff) {
+            const int e = work.slot_entry[sl];
+            best_v[e] = idx;
+            best_score[e] = m;
             err[e] = 0.0;
         }
     }
@@ -736,17 +815,44 @@ hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entrie
                            ldb, alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (work.items_v != nullptr) {
-        const int blocks = 2048;                           // 8192 waves: every SIMD of the chip has work in flight
-        if (proj)
-            hipLaunchKernelGGL((k_refine_items<T, true>), dim3(blocks), dim3(256), 0, st, G, bel, ldb, alpha, lda, mv, gamma,
-                               work);
-        else
-            hipLaunchKernelGGL((k_refine_items<T, false>), dim3(blocks), dim3(256), 0, st, G, bel, ldb, alpha, lda, mv,
-                               gamma, work);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_refine_first, dim3(1024), dim3(256), 0, st, work);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_refine_merge, dim3(64), dim3(256), 0, st, work, best_v, best_score, err);
+        // how much was deferred decides what is launched next (one 8-byte read-back; most launches defer nothing)
+        int h_cnt[2] = {0, 0};
+        if ((e = hipMemcpyAsync(h_cnt, work.cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+        const int n_items = h_cnt[0] < work.item_cap ? h_cnt[0] : work.item_cap;
+        const int n_slots = h_cnt[1] < work.slot_cap ? h_cnt[1] : work.slot_cap;
+        const int n_w = n_slots < work.w_slot_cap ? n_slots : work.w_slot_cap;
+        if (n_w > 0) {   // GEMM path: weights -> tile map -> [n_w x S] x [V x S]^T in fp64 on the MFMA -> first max
+            if constexpr (sizeof(T) == 4) {
+                dim3 wgrid((mv.S_pad + 255) / 256, n_w);
+                if (proj)
+                    hipLaunchKernelGGL((k_refine_weights<T, true>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
+                else
+                    hipLaunchKernelGGL((k_refine_weights<T, false>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                if ((e = launch_tile_nonzero_f64(work.W, mv.S_pad, n_w, mv.S_pad / 32, work.nzW, st)) != hipSuccess) return e;
+                if ((e = launch_gemm_nt_f64_bf32(work.W, mv.S_pad, n_w, (const float*)alpha, lda, V, work.Cx, V, mv.S_pad,
+                                                 work.nzW, work.klistW, work.kcountW, st)) != hipSuccess)
+                    return e;
+                hipLaunchKernelGGL(k_refine_slot_argmax, dim3(n_w), dim3(256), 0, st, work, V, best_v, best_score, err);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            } else {
+                return hipErrorInvalidValue;                 // refinement exists for f32 engines only
+            }
+        }
+        if (n_items > 0) {
+            const int blocks = 2048;                       // 8192 waves: every SIMD of the chip has work in flight
+            if (proj)
+                hipLaunchKernelGGL((k_refine_items<T, true>), dim3(blocks), dim3(256), 0, st, G, bel, ldb, alpha, lda, mv,
+                                   gamma, work);
+            else
+                hipLaunchKernelGGL((k_refine_items<T, false>), dim3(blocks), dim3(256), 0, st, G, bel, ldb, alpha, lda, mv,
+                                   gamma, work);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_refine_first, dim3(1024), dim3(256), 0, st, work);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (n_slots > n_w) hipLaunchKernelGGL(k_refine_merge, dim3(64), dim3(256), 0, st, work, best_v, best_score, err);
     }
     return hipGetLastError();
 }

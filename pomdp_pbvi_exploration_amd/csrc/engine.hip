@@ -257,7 +257,7 @@ class EngineT : public EngineBase {
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     DevBuf bp_, nzP_, pmag_, prd_;                          // belief-side formulation: projected beliefs, tile map, magnitudes, b.ER
     bool btl_valid_ = false;                                // btl_/btc_ describe the resident belief block
-    DevBuf rf_v_, rf_slot_, rf_sc_, rf_entry_, rf_n_, rf_tiles_, rf_ibv_, rf_ibi_, rf_cnt_;   // refinement work list
+    DevBuf rf_v_, rf_slot_, rf_sc_, rf_entry_, rf_n_, rf_tiles_, rf_ibv_, rf_ibi_, rf_cnt_, rf_W_, rf_Cx_, rf_nzW_, rf_klW_, rf_kcW_;   // refinement work list
     int formulation_ = 0;                                   // 0 auto, 1 project alpha-vectors, 2 project beliefs
     int last_formulation_ = 1;
     int64_t f64_pairs_ = 0;                                 // tile pairs of the last fp64 MFMA GEMM (0: plain kernel)
@@ -285,7 +285,7 @@ class EngineT : public EngineBase {
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
-                         &rf_ibv_, &rf_ibi_, &rf_cnt_,
+                         &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         for (auto& e : ev_)
@@ -950,6 +950,26 @@ class EngineT : public EngineBase {
         w->cnt = rf_cnt_.as<int>();
         w->item_cap = (int)items;
         w->slot_cap = (int)slots;
+        // GEMM path of the tie-heavy entries: fp64 weight rows for as many slots as ~2 GiB holds
+        int64_t w_slots = std::min<int64_t>(slots, ((int64_t)2 << 30) / ((int64_t)S_pad_ * sizeof(double)));
+        if (const char* c = getenv("PBVI_REFINE_W_SLOTS")) w_slots = std::min<int64_t>(slots, std::max<int64_t>(0, atoll(c)));   // tests
+        if (w_slots > 0) {
+            if ((rc = build_inverse_lists())) return rc;
+            const int kt32 = S_pad_ / GEMM_BK;
+            if ((rc = rf_W_.ensure((size_t)w_slots * S_pad_ * sizeof(double), &bytes_))) return rc;
+            if ((rc = rf_Cx_.ensure((size_t)w_slots * V * sizeof(double), &bytes_))) return rc;
+            if ((rc = rf_nzW_.ensure((size_t)((w_slots + 255) / 256) * kt32, &bytes_))) return rc;
+            if ((rc = rf_klW_.ensure(gemm_f64_klist_ints((int)w_slots, (int)V, kt32) * sizeof(int), &bytes_))) return rc;
+            if ((rc = rf_kcW_.ensure(gemm_f64_kcount_ints((int)w_slots, (int)V, kt32) * sizeof(int), &bytes_))) return rc;
+            w->W = rf_W_.as<double>();
+            w->Cx = rf_Cx_.as<double>();
+            w->nzW = rf_nzW_.as<uint8_t>();
+            w->klistW = rf_klW_.as<int>();
+            w->kcountW = rf_kcW_.as<int>();
+            w->in_ptr = in_ptr_.as<int32_t>();
+            w->in_src = in_src_.as<int32_t>();
+        }
+        w->w_slot_cap = (int)w_slots;
         return PBVI_OK;
     }
 

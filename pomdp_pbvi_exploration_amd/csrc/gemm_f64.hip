@@ -110,8 +110,18 @@ __global__ void k_tile_nonzero_f64(const double* __restrict__ X, int ld, int row
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f64x2 load2(const double* p) { return *(const f64x2*)p; }
+__device__ __forceinline__ f64x2 load2(const float* p) {
+    const f32x2 v = *(const f32x2*)p;
+    return f64x2{(double)v[0], (double)v[1]};
+}
+
+// TB: element type of B (double, or float widened on the way into LDS -- exact -- for the refinement's re-scoring
+// of fp32 alpha rows against fp64 weights)
+template <typename TB>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64_mfma(const double* __restrict__ A, int lda, int M,
-                                                             const double* __restrict__ B, int ldb, int N,
+                                                             const TB* __restrict__ B, int ldb, int N,
                                                              double* __restrict__ C, int ldc, int tiles_m,
                                                              const int* __restrict__ klist,
                                                              const int* __restrict__ kcount, int kt32,
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64_mfma(const double* __res
     // covers eight whole 128-byte row segments (full cache lines)
     const int srow = tid >> 3, scol = (tid & 7) * 2;
     const double* ap[4];
-    const double* bp[4];
+    const TB* bp[4];
     bool a_ok[4], b_ok[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64_mfma(const double* __res
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             ra[c] = a_ok[c] ? *(const f64x2*)(ap[c] + k0) : z;
-            rb[c] = b_ok[c] ? *(const f64x2*)(bp[c] + k0) : z;
+            rb[c] = b_ok[c] ? load2(bp[c] + k0) : z;
         }
     };
     auto stash = [&](int buf) {
@@ -222,9 +232,10 @@ size_t gemm_f64_klist_ints(int M, int N, int kt32) {
 size_t gemm_f64_pairs(int M, int N) { return (size_t)((M + D_BM - 1) / D_BM) * ((N + D_BN - 1) / D_BN); }
 size_t gemm_f64_kcount_ints(int M, int N, int kt32) { return 2 * gemm_f64_pairs(M, N) + (size_t)kt32 + 2; }
 
-hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,
-                              int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
-                              int* kcount, hipStream_t stream) {
+template <typename TB>
+static hipError_t launch_gemm_nt_f64_t(const double* A, int lda, int M, const TB* B, int ldb, int N, double* C, int ldc,
+                                       int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
+                                       int* kcount, hipStream_t stream) {
     if (M <= 0 || N <= 0) return hipSuccess;
     if (K_pad % 32 != 0) return hipErrorInvalidValue;
     const int kt32 = K_pad / 32;
@@ -239,7 +250,7 @@ hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, 
     constexpr size_t lds_bytes = (size_t)2 * (D_BM + D_BN) * D_LD * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {
-        e = hipFuncSetAttribute((const void*)k_gemm_nt_f64_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        e = hipFuncSetAttribute((const void*)k_gemm_nt_f64_mfma<TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
@@ -248,9 +259,20 @@ hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, 
     if ((e = hipMemsetAsync(hist, 0, (size_t)(kt32 + 2) * sizeof(int), stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_order_pairs_f64, dim3(1), dim3(1024), 0, stream, kcount, (int)pairs, kt32, hist, order);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_gemm_nt_f64_mfma, dim3((unsigned)pairs), dim3(256), lds_bytes, stream, A, lda, M, B, ldb, N, C,
+    hipLaunchKernelGGL(k_gemm_nt_f64_mfma<TB>, dim3((unsigned)pairs), dim3(256), lds_bytes, stream, A, lda, M, B, ldb, N, C,
                        ldc, tiles_m, klist, kcount, kt32, order);
     return hipGetLastError();
+}
+
+hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,
+                              int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
+                              int* kcount, hipStream_t stream) {
+    return launch_gemm_nt_f64_t<double>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nzB, G, v_group, klist, kcount, stream);
+}
+
+hipError_t launch_gemm_nt_f64_bf32(const double* A, int lda, int M, const float* B, int ldb, int N, double* C, int ldc,
+                                   int K_pad, const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream) {
+    return launch_gemm_nt_f64_t<float>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nullptr, 1, N, klist, kcount, stream);
 }
 
 }  // namespace pbvi

@@ -53,6 +53,9 @@ hipError_t launch_tile_nonzero_f64(const double* X, int ld, int rows, int kt32, 
 hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,
                               int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
                               int* kcount, hipStream_t stream);
+// same with an fp32 B operand widened exactly on the way into LDS (fp64 weights x fp32 alpha rows)
+hipError_t launch_gemm_nt_f64_bf32(const double* A, int lda, int M, const float* B, int ldb, int N, double* C, int ldc,
+                                   int K_pad, const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream);
 // Any-size reference GEMM (small f64 problems, A/B checks): C[m][n], no padding requirements.
 template <typename T>
 hipError_t launch_gemm_nt_simple(const T* A, int lda, const T* B, int ldb, T* C, int ldc,

@@ -650,7 +650,7 @@ def test_exact_ties_with_hundreds_of_candidates(formulation):
     eng.set_beliefs(b)
     st = eng.run(0.5)
     res = eng.fetch()
-    assert st['n_refine_candidates'] > 100 * st['n_refined'] > 0      # the long-list path really ran
+    assert st['n_refine_candidates'] > 8 * st['n_refined'] > 0        # every refined triple left the in-block path
     assert np.array_equal(res.best_alpha_ind, want_v)
     assert np.array_equal(res.actions, want_a)
     np.testing.assert_array_equal(res.alpha, want_rows)
