@@ -198,9 +198,29 @@ class BeliefSet:
         return self._uniqueness_dict
 
     def union(self, other: 'BeliefSet') -> 'BeliefSet':
-        merged = self.unique_belief_dict | other.unique_belief_dict
-        out = BeliefSet(self.model, list(merged.values()))
+        """``self.unique_belief_dict | other.unique_belief_dict`` (``src/pomdp.py:585-606``): this set's order, then
+        the other's beliefs that are new by bytes; on equal bytes the other's object takes the slot.  Both inputs
+        were validated when they were built, so the result is assembled directly; when every belief already lives
+        in an engine's belief store (``_dev``), the id array of the result is carried over instead of re-walking
+        the objects on the next device call."""
+        mine = self.unique_belief_dict
+        theirs = other.unique_belief_dict
+        added = [b for k, b in theirs.items() if k not in mine]
+        replaced = len(added) != len(theirs)
+        merged = dict(mine)
+        merged.update(theirs)
+        out = BeliefSet.__new__(BeliefSet)
+        out.model = self.model
+        out._belief_array = None
         out._uniqueness_dict = merged
+        out.is_on_gpu = self.is_on_gpu
+        out._belief_list = list(merged.values())
+        ids = getattr(self, '_dev_ids', None)
+        if ids is not None and not replaced and len(ids[1]) == len(mine) and len(self._belief_list) == len(mine):
+            tag = ids[0]
+            if all(getattr(b, '_dev', (None,))[0] == tag for b in added):
+                out._dev_ids = (tag, np.concatenate([ids[1], np.fromiter((b._dev[1] for b in added), dtype=np.int32,
+                                                                          count=len(added))]))
         return out
 
     def __len__(self) -> int:
