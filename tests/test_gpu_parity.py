@@ -754,3 +754,29 @@ def test_fsvi_solves_of_example_models_match_reference_gpu(name, tmp_path):
     v32 = float(np.max(np.asarray(vf32.alpha_vector_array, dtype=np.float64) @ b0))
     assert hist32.beliefs_counts == list(want['beliefs'])
     assert abs(v32 - v64) <= 1e-4 * max(1.0, abs(v64))
+
+
+@pytest.mark.parametrize('formulation', ['alpha', 'belief'])
+@pytest.mark.parametrize('R', [1, 5])
+def test_full_size_f64_engine_against_reference_summary(R, formulation):
+    """The same full-size reference fixture through the fp64 engine (fp64 MFMA GEMM, no windows, no refinement),
+    both operand formulations: indices exact, values to 1e-12."""
+    path = os.path.join(GOLDEN, f'olfactory_full_R{R}.npz')
+    if not os.path.exists(path):
+        pytest.skip('full-size fixture missing')
+    z = np.load(path, allow_pickle=False)
+    V, B = int(z['V']), int(z['B'])
+    m, alpha, beliefs = full_inputs(R, V, B)
+    if synth.checksum(m.reachable_states, m.rto, m.expected_rewards, alpha, beliefs) != str(z['inputs_sha256']):
+        pytest.skip('host regenerated different input bits than the fixture machine (exp/libm); parity unpinned here')
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f64')
+    eng.set_formulation(formulation)
+    res = eng.backup_full(alpha, beliefs, m.gamma, belief_dominance_prune=True)
+    assert res.stats['formulation'] == (1 if formulation == 'alpha' else 2)
+    mism = int(np.sum(res.best_alpha_ind != z['core_best']))
+    assert mism == 0, f'{mism} of {res.best_alpha_ind.size} best_alpha_ind differ'
+    assert np.array_equal(res.actions, z['core_actions'])
+    np.testing.assert_allclose(res.alpha.sum(axis=1), z['row_sum'], rtol=1e-12)
+    np.testing.assert_allclose(np.sum(beliefs * res.alpha, axis=1), z['b_dot'], rtol=1e-12)
+    np.testing.assert_allclose(res.alpha[z['sample_b'], z['sample_s']], z['sample_val'], rtol=1e-12, atol=1e-15)
+    eng.close()
