@@ -241,7 +241,8 @@ hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB
 // nzB are non-zero -- for the "goal" observation that is one tile instead of |S| states.
 template <typename T>
 __global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, const uint8_t* __restrict__ nzB,
-                       int k_tiles, uint8_t* __restrict__ dead, int32_t* __restrict__ btl, int32_t* __restrict__ btc) {
+                       int k_tiles, uint8_t* __restrict__ dead, int32_t* __restrict__ btl, int32_t* __restrict__ btc,
+                       int* __restrict__ dead_count) {
     extern __shared__ uint8_t dsm[];
     uint8_t* tz = dsm;                                  // [k_tiles] belief has a non-zero in tile
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -287,7 +288,10 @@ __global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, cons
             }
             found = __any(f);
         }
-        if (lane == 0) dead[(int64_t)b * AO + ao] = found ? 0 : 1;
+        if (lane == 0) {
+            dead[(int64_t)b * AO + ao] = found ? 0 : 1;
+            if (!found && dead_count != nullptr) atomicAdd(dead_count, 1);
+        }
     }
 }
 
@@ -336,9 +340,10 @@ hipError_t launch_belief_tiles(const T* bel, int ldb, int B, int S, int k_tiles,
 
 template <typename T>
 hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const uint8_t* nzB, int k_tiles, uint8_t* dead,
-                       int32_t* btl, int32_t* btc, hipStream_t st) {
+                       int32_t* btl, int32_t* btc, int* dead_count, hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dead<T>, dim3(B), dim3(256), (size_t)k_tiles, st, bel, ldb, mv, nzB, k_tiles, dead, btl, btc);
+    hipLaunchKernelGGL(k_dead<T>, dim3(B), dim3(256), (size_t)k_tiles, st, bel, ldb, mv, nzB, k_tiles, dead, btl, btc,
+                       dead_count);
     return hipGetLastError();
 }
 
@@ -1424,7 +1429,7 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
                                           hipStream_t);                                                                \
     template hipError_t launch_tail_rows<T>(ModelView<T>, T*, int, hipStream_t);                                       \
     template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const uint8_t*, int, uint8_t*, int32_t*,      \
-                                       int32_t*, hipStream_t);                                                         \
+                                       int32_t*, int*, hipStream_t);                                                   \
     template hipError_t launch_belief_tiles<T>(const T*, int, int, int, int, int32_t*, int32_t*, hipStream_t);         \
     template hipError_t launch_argmax<T>(SlabView<T>, int, int, int, const uint8_t*, double, double, const int*, int,  \
                                          int32_t*, double*, double*, int32_t*, int*, hipStream_t);                     \

@@ -1184,7 +1184,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         if ((rc = btc_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = val_exact_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
         HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(),
-                              btl_.as<int32_t>(), btc_.as<int32_t>(), side));
+                              btl_.as<int32_t>(), btc_.as<int32_t>(), counters_.as<int>() + 5, side));
         btl_valid_ = true;
     }
     if (use_push) {   // b . ER[:,a] in f64 (the alpha-side gets it from Gamma's reward rows)
@@ -1318,14 +1318,15 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     } else {
         HIPCHK(hipMemsetAsync(keep_.p, 1, (size_t)B_, stream_));
     }
-    int h_ucount = 0;
-    HIPCHK(hipMemcpyAsync(&h_ucount, ucount, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    int h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // all counters in the one read-back that precedes the final sync
+    HIPCHK(hipMemcpyAsync(h_cnt, counters_.p, sizeof(h_cnt), hipMemcpyDeviceToHost, stream_));
     full_valid_ = false;
     res_sorted_ = sorted_;
     HIPCHK(hipEventRecord(ev_[7], stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     have_result_ = true;
     res_B_ = B_;
+    const int h_ucount = h_cnt[3];
     res_unique_ = h_ucount;
 
     if (st) {
@@ -1346,20 +1347,13 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         st->ms_dominance = el(6, 7);
         st->ms_total = el(0, 7);
         st->n_pairs = pairs;
-        int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        HIPCHK(hipMemcpy(h, counters_.p, sizeof(h), hipMemcpyDeviceToHost));
+        const int* h = h_cnt;
         st->n_refine_candidates = h[4];
         st->n_refined = h[0];
         st->n_refined_actions = h[1];
         st->n_unique = h_ucount;
         st->formulation = last_formulation_;
-        if (kF32) {
-            std::vector<uint8_t> hd((size_t)pairs);
-            HIPCHK(hipMemcpy(hd.data(), dead_.p, (size_t)pairs, hipMemcpyDeviceToHost));
-            int64_t nd = 0;
-            for (uint8_t d : hd) nd += d;
-            st->n_dead = nd;
-        }
+        st->n_dead = kF32 ? h[5] : 0;                        // counted by k_dead
         if (mode_ == PBVI_DENSE) {
             st->project_flops = 2LL * AO * V_ * (int64_t)S_ * S_;
             st->project_flops_executed = st->project_flops;

@@ -379,8 +379,7 @@ class Engine:
         elif len(hit['vals']) < n_ids:
             hit['vals'] = np.concatenate([hit['vals'], np.full(n_ids - len(hit['vals']), np.nan)])
         hit['vals'][b_ids] = vals
-        self._vmax_cache.remove(hit)
-        self._vmax_cache.append(hit)                 # most recent last
+        self._vmax_cache = [c for c in self._vmax_cache if c is not hit] + [hit]    # most recent last
         del self._vmax_cache[:-self._VMAX_ENTRIES]
         return vals
 
