@@ -524,6 +524,30 @@ class SimulationHistory:
     def __len__(self) -> int:
         return len(self.states)
 
+    # -- on-disk form (src/mdp.py:1847-1885): one row per visited state, the last row has no action / reward -- #
+    def to_dataframe(self):
+        import pandas as pd
+        pts = self.grid_point_sequence
+        return pd.DataFrame({'States': self.states,
+                             'State_grid_x': [p[0] for p in pts],
+                             'State_grid_y': [p[1] for p in pts],
+                             'Actions': list(self.actions) + [None],
+                             'Rewards': list(self.rewards) + [None]})
+
+    @staticmethod
+    def _csv_target(path: str, file_name: Union[str, None]) -> str:
+        if not os.path.exists(path):
+            print('Folder does not exist yet, creating it...')
+            os.makedirs(path)
+        if file_name is None:
+            file_name = datetime.now().strftime('%Y%m%d_%H%M%S') + '_simulation.csv'
+        if not file_name.endswith('.csv'):
+            file_name += '.csv'
+        return path + '/' + file_name
+
+    def save(self, path: str = './Simulations', file_name: Union[str, None] = None) -> None:
+        self.to_dataframe().to_csv(self._csv_target(path, file_name), index=False)
+
 
 class Simulation:
     """One agent walking the model (``src/mdp.py:1888-1977``): hidden state, done flag."""

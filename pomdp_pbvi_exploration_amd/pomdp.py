@@ -703,6 +703,25 @@ class SimulationHistory(MDP_SimulationHistory):
         self._beliefs.append(next_belief)
         self.observations.append(observation)
 
+    def to_dataframe(self, include_beliefs: bool = False):
+        """The MDP columns plus ``Observations`` and, on request, one ``B_<state>`` column per state
+        (``src/pomdp.py:2664-2686``)."""
+        import pandas as pd
+        df = super().to_dataframe()
+        df['Observations'] = list(self.observations) + [None]
+        if include_beliefs:
+            rows = np.array([b.values.tolist() for b in self.beliefs])
+            df = pd.concat([df, pd.DataFrame(rows, columns=[f'B_{sl}' for sl in self.model.state_labels])], axis=1)
+        return df
+
+    def save(self, path: str = './Simulations', file_name: Union[str, None] = None, include_beliefs: bool = False) -> None:
+        target = self._csv_target(path, file_name)
+        if not include_beliefs:
+            print('[Warning] Beliefs not saved with simulation history but the belief sequence can be recreated from '
+                  'the actions and observations.')
+        self.to_dataframe(include_beliefs=include_beliefs).to_csv(target, index=False)
+        print(f'Saved to: {target}')
+
 
 class Simulation(MDP_Simulation):
     """One hidden-state walk with observations (``src/pomdp.py:2756-2815``)."""

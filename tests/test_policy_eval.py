@@ -227,3 +227,22 @@ def test_beliefs_advance_matches_host_update(dtype, B):
     with pytest.raises(ValueError):
         eng.max_value_resident()
     eng.close()
+
+
+def test_simulation_history_dataframe_and_csv(tmp_path, capsys):
+    """SimulationHistory.to_dataframe / save in the reference's column layout (src/mdp.py:1847-1885,
+    src/pomdp.py:2664-2715)."""
+    import pandas as pd
+    _, model, agent = olfactory_agent(1)
+    np.random.seed(2)
+    h = agent.simulate(Simulation(model), max_steps=6, print_progress=False, print_stats=False)
+    df = h.to_dataframe()
+    assert list(df.columns) == ['States', 'State_grid_x', 'State_grid_y', 'Actions', 'Rewards', 'Observations']
+    assert len(df) == len(h.states) and pd.isna(df['Actions'].iloc[-1]) and pd.isna(df['Observations'].iloc[-1])
+    full = h.to_dataframe(include_beliefs=True)
+    assert full.shape[1] == 6 + model.state_count and full.columns[6] == 'B_s_0'
+    np.testing.assert_array_equal(full.iloc[-1, 6:].to_numpy(dtype=float), h.beliefs[-1].values)
+    h.save(str(tmp_path / 'sims'), 'run1')
+    back = pd.read_csv(tmp_path / 'sims' / 'run1.csv')
+    assert list(back['States']) == [int(s) for s in h.states]
+    assert 'Saved to:' in capsys.readouterr().out
