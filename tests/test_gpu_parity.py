@@ -547,10 +547,10 @@ def test_device_value_iteration_random_mdp(seed):
 @pytest.mark.parametrize('dtype', ['f32', 'f64'])
 @pytest.mark.parametrize('R', [1, 5])
 def test_formulations_agree_and_auto_picks_by_shape(R, dtype):
-    if dtype == 'f64' and os.environ.get('PBVI_F64_SIMPLE'):
-        pytest.skip('debug mode: the plain fp64 GEMM has no belief-side formulation')
     """Projecting the beliefs instead of the alpha-vectors re-associates the same sums: indices identical, values
     within 1e-6 of the oracle, on both; the automatic choice takes the belief side only when B << V."""
+    if dtype == 'f64' and os.environ.get('PBVI_F64_SIMPLE'):
+        pytest.skip('debug mode: the plain fp64 GEMM has no belief-side formulation')
     z = load_npz(f'olfactory_small_R{R}.npz')
     rs, rto, er = z['reachable_states'], z['rto'].astype(np.float64), z['expected_rewards'].astype(np.float64)
     S, A, O, Rr = rto.shape[0], rto.shape[1], rto.shape[2], rto.shape[3]
@@ -761,10 +761,10 @@ def test_fsvi_solves_of_example_models_match_reference_gpu(name, tmp_path):
 @pytest.mark.parametrize('formulation', ['alpha', 'belief'])
 @pytest.mark.parametrize('R', [1, 5])
 def test_full_size_f64_engine_against_reference_summary(R, formulation):
-    if formulation == 'belief' and os.environ.get('PBVI_F64_SIMPLE'):
-        pytest.skip('debug mode: the plain fp64 GEMM has no belief-side formulation')
     """The same full-size reference fixture through the fp64 engine (fp64 MFMA GEMM, no windows, no refinement),
     both operand formulations: indices exact, values to 1e-12."""
+    if formulation == 'belief' and os.environ.get('PBVI_F64_SIMPLE'):
+        pytest.skip('debug mode: the plain fp64 GEMM has no belief-side formulation')
     path = os.path.join(GOLDEN, f'olfactory_full_R{R}.npz')
     if not os.path.exists(path):
         pytest.skip('full-size fixture missing')
