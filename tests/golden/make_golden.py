@@ -357,7 +357,8 @@ def gen_models():
     for f in sorted(glob.glob(os.path.join(EXAMPLES, '*.POMDP')) + glob.glob(os.path.join(EXAMPLES, 'ejs', '*.POMDP'))):
         name = os.path.relpath(f, EXAMPLES).replace(os.sep, '__')
         if os.path.getsize(f) > 200000:                 # cit.POMDP: keep the fixture small
-            with open(f, 'rb') as src, gzip.open(os.path.join(dst, name + '.gz'), 'wb', compresslevel=9) as z:
+            with open(f, 'rb') as src, open(os.path.join(dst, name + '.gz'), 'wb') as raw, \
+                    gzip.GzipFile(filename='', mode='wb', fileobj=raw, compresslevel=9, mtime=0) as z:   # reproducible bytes
                 shutil.copyfileobj(src, z)
         else:
             shutil.copyfile(f, os.path.join(dst, name))
