@@ -370,14 +370,25 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
     // one pass: running maximum (first index) and runner-up value per lane, merged across the wave
     T m = -std::numeric_limits<T>::infinity(), m2 = -std::numeric_limits<T>::infinity();
     int idx = 0x7fffffff;
-    for (int v = lane; v < V; v += 64) {
-        const T sc = sv.score(b, g, V, v);
-        if (sc > m || idx == 0x7fffffff) {
-            m2 = (idx == 0x7fffffff) ? m2 : m;
-            m = sc;
-            idx = v;
-        } else if (sc > m2) {
-            m2 = sc;                                        // includes sc == m (a later exact tie)
+    for (int v0 = lane; v0 < V; v0 += 256) {               // four independent score reads in flight per lane
+        T sc4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int v = v0 + 64 * j;
+            sc4[j] = v < V ? sv.score(b, g, V, v) : T(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int v = v0 + 64 * j;
+            if (v >= V) break;
+            const T sc = sc4[j];
+            if (sc > m || idx == 0x7fffffff) {
+                m2 = (idx == 0x7fffffff) ? m2 : m;
+                m = sc;
+                idx = v;
+            } else if (sc > m2) {
+                m2 = sc;                                    // includes sc == m (a later exact tie)
+            }
         }
     }
 #pragma unroll
