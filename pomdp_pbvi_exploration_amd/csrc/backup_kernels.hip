@@ -1295,7 +1295,7 @@ template <typename T>
 __global__ void k_push_project(const T* __restrict__ bel, int ldb, int B, ModelView<T> mv,
                                const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src, double gamma,
                                const T* __restrict__ amax, T* __restrict__ bp, int ldp, double* __restrict__ mag) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int sp = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, a = blockIdx.z;
     const int G = mv.A * mv.O;
     const T* brow = bel + (int64_t)b * ldb;
@@ -1308,7 +1308,7 @@ __global__ void k_push_project(const T* __restrict__ bel, int ldb, int B, ModelV
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int j = j0; j < j1; ++j) {
             const int e = src[j];                           // e = s * R + r
-            const int s = e / mv.R, r = e - s * mv.R;
+            const int s = mv.R == 1 ? e : e / mv.R, r = e - s * mv.R;
             const double bs = (double)brow[s];
             if (bs != 0.0) {
 #pragma unroll
@@ -1316,15 +1316,28 @@ __global__ void k_push_project(const T* __restrict__ bel, int ldb, int B, ModelV
                     if (q < no) acc[q] += bs * (double)mv.rto[((int64_t)(a * mv.O + o0 + q) * mv.R + r) * mv.S_pad + s];
             }
         }
+        double mg[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q >= no) break;                             // uniform across the block
-            const int g = a * mv.O + o0 + q;
             const T val = (T)(gamma * acc[q]);
             const int64_t row = ((int64_t)(o0 + q) * mv.A + a) * B + b;     // observation-major (see SlabView)
             if (sp < ldp) bp[row * ldp + sp] = val;                         // pad columns get exact zeros
-            const double part = block_sum(fabs((double)val) * am, red);
-            if (threadIdx.x == 0 && part != 0.0) atomicAdd(&mag[(int64_t)b * G + g], part);
+            mg[q] = fabs((double)val) * am;
+        }
+        // magnitudes: one barrier for all (up to four) observations of this pass
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mg[q] = wave_sum(mg[q]);
+        __syncthreads();                                    // red[] of the previous pass has been read
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[(threadIdx.x >> 6) * 4 + q] = mg[q];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < no) {
+            const int q = threadIdx.x;
+            const double part = ((red[q] + red[4 + q]) + red[8 + q]) + red[12 + q];
+            if (part != 0.0) atomicAdd(&mag[(int64_t)b * G + a * mv.O + o0 + q], part);
         }
     }
 }
