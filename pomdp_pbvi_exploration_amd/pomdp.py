@@ -324,6 +324,8 @@ class PBVI_Solver(Solver):
     # ------------------------------------------------------------------ #
     # hot path
     # ------------------------------------------------------------------ #
+    BELIEF_BLOCK = 32768      # beliefs per engine call on the GPU path
+
     def backup(self, model: Model, belief_set: BeliefSet, value_function: ValueFunction,
                append: bool = False, belief_dominance_prune: bool = True) -> ValueFunction:
         """One point-based backup (``src/pomdp.py:1447-1524``): B beliefs x V
@@ -334,9 +336,19 @@ class PBVI_Solver(Solver):
             # runs the backup, and only the distinct new rows come back.
             eng = value_function.model.engine
             eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values, owner=value_function)
-            eng.sync_rows('belief', belief_set.belief_list, lambda b: b.values, owner=belief_set)
-            eng.run(self.gamma, belief_dominance_prune)
-            alpha_new, actions = eng.fetch().value_function_rows(use_keep=belief_dominance_prune)
+            beliefs = belief_set.belief_list
+            if len(beliefs) <= self.BELIEF_BLOCK:
+                eng.sync_rows('belief', beliefs, lambda b: b.values, owner=belief_set)
+                eng.run(self.gamma, belief_dominance_prune)
+                alpha_new, actions = eng.fetch().value_function_rows(use_keep=belief_dominance_prune)
+            else:   # beliefs are independent: larger sets go through the engine in blocks (it takes 65535 at a time)
+                parts = []
+                for i0 in range(0, len(beliefs), self.BELIEF_BLOCK):
+                    eng.sync_rows('belief', beliefs[i0:i0 + self.BELIEF_BLOCK], lambda b: b.values)
+                    eng.run(self.gamma, belief_dominance_prune)
+                    parts.append(eng.fetch().value_function_rows(use_keep=belief_dominance_prune))
+                alpha_new = np.concatenate([p[0] for p in parts])
+                actions = np.concatenate([p[1] for p in parts])
             new_vf = ValueFunction(value_function.model, alpha_new, actions)
         else:
             alpha_new, actions = self._backup_numpy(model, belief_set.belief_array, value_function.alpha_vector_array,

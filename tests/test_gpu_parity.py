@@ -784,3 +784,20 @@ def test_full_size_f64_engine_against_reference_summary(R, formulation):
     np.testing.assert_allclose(np.sum(beliefs * res.alpha, axis=1), z['b_dot'], rtol=1e-12)
     np.testing.assert_allclose(res.alpha[z['sample_b'], z['sample_s']], z['sample_val'], rtol=1e-12, atol=1e-15)
     eng.close()
+
+
+def test_backup_of_a_belief_set_larger_than_one_engine_block():
+    """PBVI_Solver.backup splits belief sets beyond BELIEF_BLOCK into engine calls; rows and actions equal the
+    single-call result (here with a block of 20 on the 64-belief small fixture)."""
+    z = load_npz('olfactory_small_R1.npz')
+    m = synth.olfactory_model(H=int(z['H']), W=int(z['W']), R=1)
+    from test_policy_eval import mirror_model
+    model = mirror_model(m).to_gpu('f32')
+    vf = ValueFunction(model, z['alpha'].astype(np.float64), z['alpha_actions'].astype(int))
+    bs = BeliefSet(model, z['beliefs'].astype(np.float64))
+    solver = PBVI_Solver(gamma=float(z['gamma']))
+    whole = solver.backup(model, bs, vf, belief_dominance_prune=False)
+    solver.BELIEF_BLOCK = 20
+    parts = solver.backup(model, bs, vf, belief_dominance_prune=False)
+    assert np.array_equal(whole.alpha_vector_array, parts.alpha_vector_array)
+    assert np.array_equal(whole.actions, parts.actions)
