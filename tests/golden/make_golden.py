@@ -410,7 +410,36 @@ def gen_solve():
     np.savez_compressed(os.path.join(HERE, 'example_solves.npz'), **out)
 
 
+# --------------------------------------------------------------------------- #
+def gen_e2e():
+    """The reference's FSVI solve loop at the headline scale (S=30000 synthetic olfactory model, 40 expansions of
+    <= 100 beliefs, seeds 0): belief-count and |V| trajectories, per-backup value-function changes, the value of
+    the start belief and a digest of the final alpha set.  Takes minutes on CPU."""
+    import hashlib
+    import random as pyrandom
+    m = synth.olfactory_model(R=1, f32=False)
+    model = quiet(ref.Model, states=m.S, actions=m.A, observations=m.O, reachable_states=m.reachable_states,
+                  observation_table=m.observation_table, end_states=[m.goal], start_probabilities=list(m.start_belief))
+    np.random.seed(0)
+    pyrandom.seed(0)
+    t0 = time.time()
+    solver = ref.FSVI_Solver(gamma=m.gamma, eps=1e-6)
+    vf, hist = quiet(solver.solve, model, expansions=40, max_belief_growth=100, print_progress=False)
+    alpha = np.array(vf.alpha_vector_array)
+    b0 = np.asarray(model.start_probabilities)
+    print(f'e2e: |V|={len(vf)} |B|={hist.beliefs_counts[-1]} in {time.time() - t0:.0f}s; backup mean {np.mean(hist.backup_times):.2f}s')
+    np.savez_compressed(os.path.join(HERE, 'olfactory_e2e_fsvi40.npz'),
+                        beliefs=np.asarray(hist.beliefs_counts, dtype=np.int32),
+                        alphas=np.asarray(hist.alpha_vector_counts, dtype=np.int32),
+                        changes=np.asarray(hist.value_function_changes, dtype=np.float64),
+                        actions=np.asarray(vf.actions, dtype=np.int8),
+                        value_b0=float(np.max(alpha @ b0)),
+                        row_sums=alpha.sum(axis=1), row_b0=alpha @ b0,
+                        sha256=hashlib.sha256(np.ascontiguousarray(alpha).tobytes()).hexdigest(),
+                        ref_backup_mean_s=float(np.mean(hist.backup_times)))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['small', 'kat', 'c2']
     for w in which:
-        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve}[w]()
+        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve, 'e2e': gen_e2e}[w]()
