@@ -100,6 +100,30 @@ class Model(MDP_Model):
         return int(np.random.choice(a=self.observations, size=1, p=self.observation_table[s_p, a])[0])
 
 
+class _RowKey:
+    """Dictionary key with the semantics of the row's bytes (the reference keys its dedup dictionaries on
+    ``values.tobytes()``, ``src/pomdp.py:562-571``) without hashing a quarter of a megabyte per belief: the hash is the
+    wrapping integer sum of the row's bit patterns (equal bytes give equal sums; one single-threaded pass, no BLAS),
+    equality compares the bytes -- which only happens when two keys land on the same hash, i.e. practically only
+    for equal rows."""
+    __slots__ = ('row', 'h')
+
+    def __init__(self, row: np.ndarray):
+        self.row = row
+        size = row.dtype.itemsize
+        if row.flags.c_contiguous and size in (4, 8):
+            bits = row.view(np.uint64 if size == 8 else np.uint32)
+            self.h = int(np.add.reduce(bits, dtype=np.uint64))
+        else:
+            self.h = hash(row.tobytes())
+
+    def __hash__(self) -> int:
+        return self.h
+
+    def __eq__(self, other) -> bool:
+        return self.h == other.h and (self.row is other.row or self.row.tobytes() == other.row.tobytes())
+
+
 class Belief:
     """Probability distribution over states; Bayes update through the
     reachable-state tables (``src/pomdp.py:311-421``)."""
@@ -107,6 +131,7 @@ class Belief:
     def __new__(cls, *args, **kwargs):
         inst = super().__new__(cls)
         inst._bytes_repr = None
+        inst._key = None
         inst._successors = {}
         return inst
 
@@ -130,6 +155,12 @@ class Belief:
         if self._bytes_repr is None:
             self._bytes_repr = self.values.tobytes()
         return self._bytes_repr
+
+    @property
+    def key(self) -> _RowKey:
+        if self._key is None:
+            self._key = _RowKey(self.values)
+        return self._key
 
     def __eq__(self, other) -> bool:
         return self.bytes_repr == other.bytes_repr
@@ -163,6 +194,7 @@ class BeliefSet:
         self.model = model
         self._belief_array = None
         self._uniqueness_dict = None
+        self._key_dict = None
         self.is_on_gpu = bool(getattr(model, 'is_on_gpu', False))
         if isinstance(beliefs, list):
             assert all(len(b.values) == model.state_count for b in beliefs), \
@@ -193,9 +225,16 @@ class BeliefSet:
 
     @property
     def unique_belief_dict(self) -> dict:
+        """Beliefs keyed by their bytes, as the reference exposes them (built on demand)."""
         if self._uniqueness_dict is None:
             self._uniqueness_dict = {b.bytes_repr: b for b in self.belief_list}
         return self._uniqueness_dict
+
+    @property
+    def _unique_by_key(self) -> dict:
+        if self._key_dict is None:
+            self._key_dict = {b.key: b for b in self.belief_list}
+        return self._key_dict
 
     def union(self, other: 'BeliefSet') -> 'BeliefSet':
         """``self.unique_belief_dict | other.unique_belief_dict`` (``src/pomdp.py:585-606``): this set's order, then
@@ -203,8 +242,8 @@ class BeliefSet:
         were validated when they were built, so the result is assembled directly; when every belief already lives
         in an engine's belief store (``_dev``), the id array of the result is carried over instead of re-walking
         the objects on the next device call."""
-        mine = self.unique_belief_dict
-        theirs = other.unique_belief_dict
+        mine = self._unique_by_key                           # same dedup as the bytes-keyed dictionaries, cheaper keys
+        theirs = other._unique_by_key
         added = [b for k, b in theirs.items() if k not in mine]
         replaced = len(added) != len(theirs)
         merged = dict(mine)
@@ -212,7 +251,8 @@ class BeliefSet:
         out = BeliefSet.__new__(BeliefSet)
         out.model = self.model
         out._belief_array = None
-        out._uniqueness_dict = merged
+        out._uniqueness_dict = None
+        out._key_dict = merged
         out.is_on_gpu = self.is_on_gpu
         out._belief_list = list(merged.values())
         ids = getattr(self, '_dev_ids', None)
