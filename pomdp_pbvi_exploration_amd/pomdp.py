@@ -23,7 +23,7 @@ import numpy as np
 from .mdp import AlphaVector, ValueFunction, VI_Solver, log, _log, set_quiet   # noqa: F401
 from .mdp import Model as MDP_Model
 from .mdp import Solver as MDP_Solver
-from .mdp import RewardSet                                   # noqa: F401
+from .mdp import RewardSet, _RowKey                          # noqa: F401
 from .mdp import SimulationHistory as MDP_SimulationHistory
 from .mdp import Simulation as MDP_Simulation
 
@@ -98,30 +98,6 @@ class Model(MDP_Model):
 
     def observe(self, s_p: int, a: int) -> int:
         return int(np.random.choice(a=self.observations, size=1, p=self.observation_table[s_p, a])[0])
-
-
-class _RowKey:
-    """Dictionary key with the semantics of the row's bytes (the reference keys its dedup dictionaries on
-    ``values.tobytes()``, ``src/pomdp.py:562-571``) without hashing a quarter of a megabyte per belief: the hash is the
-    wrapping integer sum of the row's bit patterns (equal bytes give equal sums; one single-threaded pass, no BLAS),
-    equality compares the bytes -- which only happens when two keys land on the same hash, i.e. practically only
-    for equal rows."""
-    __slots__ = ('row', 'h')
-
-    def __init__(self, row: np.ndarray):
-        self.row = row
-        size = row.dtype.itemsize
-        if row.flags.c_contiguous and size in (4, 8):
-            bits = row.view(np.uint64 if size == 8 else np.uint32)
-            self.h = int(np.add.reduce(bits, dtype=np.uint64))
-        else:
-            self.h = hash(row.tobytes())
-
-    def __hash__(self) -> int:
-        return self.h
-
-    def __eq__(self, other) -> bool:
-        return self.h == other.h and (self.row is other.row or self.row.tobytes() == other.row.tobytes())
 
 
 class Belief:
