@@ -47,7 +47,7 @@ void set_error(const std::string& msg) { g_err = msg; }
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    // grow-only; contents are NOT preserved on growth.  A buffer that grows again gets 25 % headroom: in a solve
+    // grow-only; contents are NOT preserved on growth.  A buffer that grows again doubles (25 % if that fails): in a solve
     // loop the alpha set gains a few rows per backup, and re-allocating a multi-GB buffer (hipFree + hipMalloc,
     // both synchronising, hundreds of ms at 20 GB) on every call would dwarf the backup itself.
     int ensure(size_t bytes, int64_t* total) {
@@ -60,18 +60,19 @@ struct DevBuf {
             cap = 0;
         }
         if (regrow) {
-            const size_t want = bytes + bytes / 4;
-            if (hipMalloc(&p, want) == hipSuccess) {
-                cap = want;
-                *total += (int64_t)want;
-                if (poison_enabled()) {
-                    if (hipMemset(p, 0xFF, want) != hipSuccess) (void)hipGetLastError();
-                    (void)hipDeviceSynchronize();
+            for (const size_t want : {bytes * 2, bytes + bytes / 4}) {     // HBM is plentiful; re-allocations are not
+                if (hipMalloc(&p, want) == hipSuccess) {
+                    cap = want;
+                    *total += (int64_t)want;
+                    if (poison_enabled()) {
+                        if (hipMemset(p, 0xFF, want) != hipSuccess) (void)hipGetLastError();
+                        (void)hipDeviceSynchronize();
+                    }
+                    return PBVI_OK;
                 }
-                return PBVI_OK;
+                (void)hipGetLastError();                 // no room for that much headroom: try less, then the exact size
+                p = nullptr;
             }
-            (void)hipGetLastError();                     // no room for the headroom: fall through to the exact size
-            p = nullptr;
         }
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
