@@ -465,6 +465,13 @@ class Engine:
         _check(self._lib.pbvi_prune_dominated(self._h, keep.ctypes.data_as(C.POINTER(C.c_uint8))))
         return keep.astype(bool)
 
+    def prune_dominated_objects(self, objects, values_of, owner=None) -> np.ndarray:
+        """Same for a list of AlphaVector objects: rows already in the device store are not uploaded again."""
+        self.sync_rows('alpha', objects, values_of, owner)
+        keep = np.empty(len(objects), dtype=np.uint8)
+        _check(self._lib.pbvi_prune_dominated(self._h, keep.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return keep.astype(bool)
+
     def max_value(self, alpha: np.ndarray, beliefs: np.ndarray):
         """``(max_v b.alpha_v [B] f64, argmax [B])`` (compute_change, ``src/pomdp.py:2165``)."""
         self._ensure_alpha(alpha)

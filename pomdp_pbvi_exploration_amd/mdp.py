@@ -417,19 +417,26 @@ class ValueFunction:
         if level >= 3:
             raise NotImplementedError("LP pruning (level 3) is broken in the reference (src/mdp.py:872) and not provided")
         if level >= 2 and self._pruning_level < 2:
-            arr = self.alpha_vector_array
-            if self.is_on_gpu:
-                keep = self.model.engine.prune_dominated(arr)
+            if self.is_on_gpu:      # on the objects: kept vectors keep their device-store rows, nothing is re-stacked
+                vecs = self.alpha_vector_list
+                keep = self.model.engine.prune_dominated_objects(vecs, lambda v: v.values, owner=self)
+                items = list(self._uniqueness_dict.items())
+                if len(items) == len(vecs):
+                    self._uniqueness_dict = {k: v for (k, v), kp in zip(items, keep) if kp}
+                else:                                        # list holds duplicates the dictionary folded: rebuild
+                    self._uniqueness_dict = {v.values.tobytes(): v for v, kp in zip(vecs, keep) if kp}
+                self._vector_list = list(self._uniqueness_dict.values())
+                self._vector_array = None
+                self._actions = None
             else:
+                arr = self.alpha_vector_array
                 keep = np.zeros(arr.shape[0], dtype=bool)
                 for i, v in enumerate(arr):
                     keep[i] = np.count_nonzero(np.all(arr >= v, axis=1)) == 1
-            self._vector_array = arr[keep]
-            self._actions = self._actions[keep]
-            self._vector_list = None
-            self._dev_ids = None
-            self._uniqueness_dict = {r.tobytes(): AlphaVector(r, a) for r, a in zip(self._vector_array, self._actions)}
-            self._vector_list = list(self._uniqueness_dict.values())
+                self._vector_array = arr[keep]
+                self._actions = self._actions[keep]
+                self._uniqueness_dict = {r.tobytes(): AlphaVector(r, a) for r, a in zip(self._vector_array, self._actions)}
+                self._vector_list = list(self._uniqueness_dict.values())
             self._dev_ids = None
         self._pruning_level = level
 

@@ -830,3 +830,24 @@ def test_end_to_end_fsvi_at_headline_scale_matches_reference():
     assert abs(v_b0 - float(z['value_b0'])) <= 1e-9 * abs(float(z['value_b0']))
     print(f'end to end: |V|={len(vf)} backup mean {np.mean(hist.backup_times) * 1e3:.2f} ms '
           f'(reference on the fixture machine: {float(z["ref_backup_mean_s"]):.2f} s)')
+
+
+def test_value_function_prune_level2_on_gpu_objects():
+    """ValueFunction.prune(2) with the set on the GPU works on the AlphaVector objects (kept vectors keep their
+    device rows) and keeps exactly what the host loop of src/mdp.py:857-866 keeps."""
+    rng = np.random.default_rng(8)
+    model, _ = load_POMDP_file(os.path.join(GOLDEN, 'models', '4x3.95-no_loop_2_grid.POMDP'))
+    base = rng.normal(size=(30, model.state_count))
+    rows = np.concatenate([base, base[:10] - rng.random((10, model.state_count)), base[5:8]])   # dominated + duplicates
+    acts = rng.integers(0, model.action_count, size=len(rows))
+    host = ValueFunction(model, rows.copy(), acts)
+    host.prune(2)
+    gm = model.to_gpu('f64')
+    dev = ValueFunction(gm, rows.copy(), acts)
+    n_before = len(dev)
+    dev.prune(2)
+    assert len(dev) == len(host) < n_before
+    assert np.array_equal(dev.alpha_vector_array, host.alpha_vector_array)
+    assert np.array_equal(dev.actions, host.actions)
+    dev.prune(2)                                          # already at that level: unchanged
+    assert len(dev) == len(host)
