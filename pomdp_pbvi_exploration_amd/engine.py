@@ -354,11 +354,12 @@ class Engine:
         epochs = (self._store_epoch['alpha'], self._store_epoch['belief'])
         if self._vmax_epochs != epochs:
             self._vmax_cache, self._vmax_epochs = [], epochs
-        aset = frozenset(a_ids.tolist())
-        hit = next((e for e in self._vmax_cache if e['aset'] == aset), None)
+        aset = np.unique(a_ids)                             # sorted ids: set algebra stays in NumPy
+        hit = next((e for e in self._vmax_cache if np.array_equal(e['aset'], aset)), None)
         base = hit
         if base is None:     # largest cached subset of this alpha set
-            subs = [e for e in self._vmax_cache if e['aset'] <= aset]
+            subs = [e for e in self._vmax_cache
+                    if len(e['aset']) <= len(aset) and np.isin(e['aset'], aset, assume_unique=True).all()]
             base = max(subs, key=lambda e: len(e['aset'])) if subs else None
         n_ids = int(b_ids.max()) + 1 if len(b_ids) else 0
         vals = np.full(len(b_ids), np.nan)
@@ -368,7 +369,7 @@ class Engine:
             vals[inside] = have[b_ids[inside]]
         known = ~np.isnan(vals)
         if base is not None and base is not hit and known.any():
-            fresh = np.array([i for i in a_ids.tolist() if i not in base['aset']], dtype=np.int32)
+            fresh = np.setdiff1d(aset, base['aset'], assume_unique=True).astype(np.int32)
             if len(fresh):
                 vals[known] = np.maximum(vals[known], self._vmax_block(fresh, b_ids[known]))
         if (~known).any():
