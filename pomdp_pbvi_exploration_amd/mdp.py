@@ -318,7 +318,6 @@ class ValueFunction:
                 self._vector_array = np.zeros((0, self.model.state_count))
             else:
                 self._vector_array = np.array([v.values for v in self._vector_list])
-            self._actions = np.array([v.action for v in self._vector_list], dtype=int)
 
     @property
     def alpha_vector_array(self) -> np.ndarray:
@@ -327,7 +326,9 @@ class ValueFunction:
 
     @property
     def actions(self) -> np.ndarray:
-        self._materialise()
+        # on its own: asking for the actions (the simulators do, every step) must not re-stack the whole V x S matrix
+        if self._actions is None:
+            self._actions = np.array([v.action for v in self.alpha_vector_list], dtype=int)
         return self._actions
 
     def __len__(self) -> int:
@@ -434,7 +435,7 @@ class ValueFunction:
                 for i, v in enumerate(arr):
                     keep[i] = np.count_nonzero(np.all(arr >= v, axis=1)) == 1
                 self._vector_array = arr[keep]
-                self._actions = self._actions[keep]
+                self._actions = self.actions[keep]
                 self._uniqueness_dict = {r.tobytes(): AlphaVector(r, a) for r, a in zip(self._vector_array, self._actions)}
                 self._vector_list = list(self._uniqueness_dict.values())
             self._dev_ids = None
