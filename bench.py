@@ -85,7 +85,7 @@ def main():
 
     from pomdp_pbvi_exploration_amd import synth
     from pomdp_pbvi_exploration_amd.engine import Engine
-    from pomdp_pbvi_exploration_amd.dist import EngineShard, gather_unique
+    from pomdp_pbvi_exploration_amd.dist import EngineShard, gather_keys, gather_unique
 
     H, W = (int(x) for x in args.grid.split('x'))
     m = synth.olfactory_model(H=H, W=W, R=args.reach)
@@ -100,10 +100,19 @@ def main():
     eng.set_beliefs(beliefs)
     shard = EngineShard(eng, m.gamma)
 
+    exchange_rows = os.environ.get('PBVI_EXCHANGE') == 'rows'       # A-B only
+
     def step():
-        if distributed:   # local backup, then ONE logical exchange: all-gather of the deduplicated alpha' rows
-            rows, count, idx, acts, keep, st = shard.run_resident_unique()
-            gather_unique(dist, None, rows, count, idx, acts, keep, B * world)
+        if distributed:
+            # local backup, then ONE all-gather of integers: per-belief index / action / keep and the keys
+            # (a*, v*[a*, :]) of this rank's distinct alpha' rows; every rank rebuilds all rows from the keys against
+            # its replica of the alpha set (dist.gather_keys).  PBVI_EXCHANGE=rows moves the rows themselves instead.
+            if exchange_rows:
+                rows, count, idx, acts, keep, st = shard.run_resident_unique()
+                gather_unique(dist, None, rows, count, idx, acts, keep, B * world)
+            else:
+                keys, count, idx, acts, keep, st = shard.run_resident_keys()
+                gather_keys(dist, None, keys, count, idx, acts, keep, B * world, shard.assemble)
             return st
         return eng.run(m.gamma)
 
@@ -150,7 +159,7 @@ def main():
             'config': {'workload': f'olfactory-{m.S} {"reachable-sparse" if args.mode == "sparse" else "dense-projection"} R={m.R} backup (S={m.S}, A={m.A}, O={m.O}), '
                                    f'V={args.alphas} alpha-vectors, B={B} beliefs per GPU',
                        'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': args.alphas, 'B_per_gpu': B,
-                       'parallelism': f'belief-sharded x{world}, 1 all-gather of alpha rows' if distributed else 'single GPU'},
+                       'parallelism': (f'belief-sharded x{world}, 1 all-gather of ' + ('alpha rows' if exchange_rows else 'row keys (rows rebuilt per rank)')) if distributed else 'single GPU'},
             'roofline': {'bound': 'mfma', 'kernel': f'{gemm_name} (belief x Gamma score GEMM, non-zero tiles)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': None,

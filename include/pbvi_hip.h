@@ -162,6 +162,17 @@ int64_t pbvi_backup_unique_count(const pbvi_engine_t* e);
 int pbvi_backup_fetch_unique(pbvi_engine_t* e, void* out_rows, int32_t* out_index);
 
 /*
+ * Keys instead of rows (multi-GPU exchange).  The alpha' row of a belief is a function of its key
+ * (a*, v*[a*, 0..O-1]) and of the replicated alpha set and model only (src/pomdp.py:1497-1506), so ranks exchange
+ * keys -- (1+O) ints per distinct row -- and every rank assembles the rows it did not compute itself:
+ *   pbvi_backup_fetch_unique_keys : out_keys [U][1+O] int32 of the last backup's U distinct rows (host or device)
+ *   pbvi_assemble_rows            : out_rows [n][S] T (host or device) from n keys against the RESIDENT alpha set;
+ *                                   byte-identical to the rows the producing rank holds.  1 <= n <= 65535.
+ */
+int pbvi_backup_fetch_unique_keys(pbvi_engine_t* e, int32_t* out_keys);
+int pbvi_assemble_rows(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows);
+
+/*
  * Device addresses of the last run's results, for the multi-GPU layer to hand to
  * RCCL (all-gather of the new alpha rows) without a host round trip.
  *   *d_alpha [B][S] T (row stride S), *d_action [B] int32, *d_keep [B] uint8.

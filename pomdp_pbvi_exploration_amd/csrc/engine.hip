@@ -103,6 +103,35 @@ struct DevBuf {
 // out[s] = max_v |alpha[v][s]| (out zeroed by the caller).  Row chunks of 128 run as separate blocks and meet in an
 // atomic max on the bit pattern (non-negative IEEE values order like unsigned integers): with one block per
 // column strip the 5000 dependent loads of a grown alpha set made this latency-bound (0.6 ms at V = 4500).
+// keys of the unique rows of the last backup: key[u] = (a*, v*[a*, 0..O-1]) of the u-th distinct (a*, v*) pair
+__global__ void k_gather_keys(int U, int A, int O, const int32_t* __restrict__ uniq, const int32_t* __restrict__ action,
+                              const int32_t* __restrict__ best_v, int32_t* __restrict__ keys) {
+    const int u = blockIdx.x * 64 + threadIdx.x;
+    if (u >= U) return;
+    const int b = uniq[u], a = action[b];
+    keys[(int64_t)u * (1 + O)] = a;
+    for (int o = 0; o < O; ++o) keys[(int64_t)u * (1 + O) + 1 + o] = best_v[((int64_t)b * A + a) * O + o];
+}
+
+// the inverse: per-row action / best-alpha arrays in the layout k_assemble reads (only the winning action's entries)
+__global__ void k_scatter_keys(int n, int A, int O, int V, const int32_t* __restrict__ keys, int32_t* __restrict__ action,
+                               int32_t* __restrict__ best_v, int* __restrict__ bad) {
+    const int u = blockIdx.x * 64 + threadIdx.x;
+    if (u >= n) return;
+    const int a = keys[(int64_t)u * (1 + O)];
+    if (a < 0 || a >= A) {
+        atomicAdd(bad, 1);
+        action[u] = 0;
+        return;
+    }
+    action[u] = a;
+    for (int o = 0; o < O; ++o) {
+        const int v = keys[(int64_t)u * (1 + O) + 1 + o];
+        if (v < 0 || v >= V) atomicAdd(bad, 1);
+        best_v[((int64_t)u * A + a) * O + o] = (v < 0 || v >= V) ? 0 : v;
+    }
+}
+
 template <typename T>
 __global__ void k_col_absmax(const T* __restrict__ alpha, int lda, int V, int S_pad, T* __restrict__ out) {
     const int s = blockIdx.x * 256 + threadIdx.x;
@@ -214,6 +243,8 @@ class EngineBase {
     virtual int device_results(void** d_alpha, int32_t** d_action, uint8_t** d_keep) = 0;
     virtual int64_t unique_count() const = 0;
     virtual int fetch_unique(void* out_rows, int32_t* out_index) = 0;
+    virtual int fetch_unique_keys(int32_t* out_keys) = 0;
+    virtual int assemble_keys(double gamma, int64_t n, const int32_t* keys, void* out_rows) = 0;
     virtual int prune_dominated(uint8_t* keep) = 0;
     virtual int value_max(double* out_value, int32_t* out_index) = 0;
     virtual int set_tie_window(double rel) = 0;
@@ -258,6 +289,7 @@ class EngineT : public EngineBase {
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     DevBuf bp_, nzP_, pmag_, prd_;                          // belief-side formulation: projected beliefs, tile map, magnitudes, b.ER
     bool btl_valid_ = false;                                // btl_/btc_ describe the resident belief block
+    DevBuf keys_tmp_, keys_act_, keys_best_, keys_rows_;    // unique-row keys out / rows from keys in (multi-GPU exchange)
     DevBuf rf_v_, rf_slot_, rf_sc_, rf_entry_, rf_n_, rf_tiles_, rf_ibv_, rf_ibi_, rf_cnt_, rf_W_, rf_Cx_, rf_nzW_, rf_klW_, rf_kcW_;   // refinement work list
     int formulation_ = 0;                                   // 0 auto, 1 project alpha-vectors, 2 project beliefs
     int last_formulation_ = 1;
@@ -285,7 +317,7 @@ class EngineT : public EngineBase {
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
-                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
+                         &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
@@ -847,6 +879,49 @@ class EngineT : public EngineBase {
         if (out_index)
             HIPCHK(hipMemcpyAsync(out_index, inv_.p, (size_t)res_B_ * sizeof(int32_t), hipMemcpyDefault, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
+        return PBVI_OK;
+    }
+
+    // (a*, v*[a*,:]) of every unique row of the last backup: [U][1+O] int32, host or device destination
+    int fetch_unique_keys(int32_t* out_keys) override {
+        if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch_unique_keys: no backup result resident");
+        if (!out_keys) FAIL(PBVI_EINVAL, "backup_fetch_unique_keys: NULL destination");
+        if (res_unique_ <= 0) return PBVI_OK;
+        HIPCHK(hipSetDevice(device_));
+        int rc = keys_tmp_.ensure((size_t)res_unique_ * (1 + O_) * sizeof(int32_t), &bytes_);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gather_keys, dim3((unsigned)((res_unique_ + 63) / 64)), dim3(64), 0, stream_, (int)res_unique_, A_, O_,
+                           uniq_.as<int32_t>(), res_action_, res_best_, keys_tmp_.as<int32_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out_keys, keys_tmp_.p, (size_t)res_unique_ * (1 + O_) * sizeof(int32_t), hipMemcpyDefault, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        return PBVI_OK;
+    }
+
+    // alpha' rows from keys against the RESIDENT alpha set (K3 of src/pomdp.py:1497-1506 for given winners): what a
+    // rank needs to rebuild the rows other ranks found, since the alpha set and the model are replicated.
+    int assemble_keys(double gamma, int64_t n, const int32_t* keys, void* out_rows) override {
+        if (V_ <= 0) FAIL(PBVI_EINVAL, "assemble_keys: no alpha set resident");
+        if (n <= 0 || n > 65535 || !keys || !out_rows) FAIL(PBVI_EINVAL, "assemble_keys: bad arguments (1 <= n <= 65535)");
+        HIPCHK(hipSetDevice(device_));
+        int rc;
+        if ((rc = keys_tmp_.ensure((size_t)n * (1 + O_) * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = keys_act_.ensure((size_t)(n + 1) * sizeof(int32_t), &bytes_))) return rc;      // [n] actions + 1 error counter
+        if ((rc = keys_best_.ensure((size_t)n * A_ * O_ * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = keys_rows_.ensure((size_t)n * S_ * sizeof(T), &bytes_))) return rc;
+        int* bad = keys_act_.as<int>() + n;
+        HIPCHK(hipMemcpyAsync(keys_tmp_.p, keys, (size_t)n * (1 + O_) * sizeof(int32_t), hipMemcpyDefault, stream_));
+        HIPCHK(hipMemsetAsync(bad, 0, sizeof(int), stream_));
+        hipLaunchKernelGGL(k_scatter_keys, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream_, (int)n, A_, O_, (int)V_,
+                           keys_tmp_.as<int32_t>(), keys_act_.as<int32_t>(), keys_best_.as<int32_t>(), bad);
+        HIPCHK(hipGetLastError());
+        HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, view(), gamma, keys_act_.as<int32_t>(), keys_best_.as<int32_t>(), nullptr,
+                                  nullptr, (int)n, keys_rows_.as<T>(), S_, stream_));
+        int h_bad = 0;
+        HIPCHK(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipMemcpyAsync(out_rows, keys_rows_.p, (size_t)n * S_ * sizeof(T), hipMemcpyDefault, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        if (h_bad) FAIL(PBVI_EINVAL, "assemble_keys: action or alpha index out of range");
         return PBVI_OK;
     }
 
@@ -1613,6 +1688,14 @@ int pbvi_backup_run(pbvi_engine_t* e, double gamma, int flags, pbvi_stats_t* sta
 int pbvi_backup_fetch(pbvi_engine_t* e, void* out_alpha, int32_t* out_action, int32_t* out_best_alpha, uint8_t* out_keep) {
     NEED(e);
     return e->impl->backup_fetch(out_alpha, out_action, out_best_alpha, out_keep);
+}
+int pbvi_backup_fetch_unique_keys(pbvi_engine_t* e, int32_t* out_keys) {
+    NEED(e);
+    return e->impl->fetch_unique_keys(out_keys);
+}
+int pbvi_assemble_rows(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows) {
+    NEED(e);
+    return e->impl->assemble_keys(gamma, n, keys, out_rows);
 }
 int pbvi_backup_device_results(pbvi_engine_t* e, void** d_alpha, int32_t** d_action, uint8_t** d_keep) {
     NEED(e);

@@ -115,6 +115,40 @@ def gather_unique(dist, group, rows, count: int, index, actions, keep, n_total: 
     return uniq, gidx.reshape(-1)[:n_total], all_act[:n_total], all_keep[:n_total]
 
 
+def gather_keys(dist, group, keys, count: int, index, actions, keep, n_total: int, assemble):
+    """The exchange without rows.  A rank's alpha' rows are functions of their keys ``(a*, v*[a*, :])`` and of the
+    replicated alpha set and model, so ONE ``all_gather_into_tensor`` of integers suffices: per rank its count, the
+    per-belief ``index`` / ``actions`` / ``keep`` and the keys of its (at most ``per``) distinct rows.  Every rank then
+    rebuilds all rows with ``assemble(all_keys [sum U_r, 1+O]) -> [sum U_r, S]`` (``pbvi_assemble_rows``: byte-identical
+    to the rows the producing rank holds).  At C4 that is 28 KB per rank on the wire instead of 8 MB.
+    Returns the same tuple as ``gather_unique``."""
+    import torch
+    world = dist.get_world_size(group)
+    dev = index.device
+    per = index.shape[0]
+    kw = keys.shape[1]
+    n_meta = 1 + 3 * per + per * kw
+    meta = torch.zeros(n_meta, dtype=torch.int32, device=dev)
+    meta[0] = count
+    meta[1:1 + per] = index
+    meta[1 + per:1 + 2 * per] = actions
+    meta[1 + 2 * per:1 + 3 * per] = keep
+    meta[1 + 3 * per:1 + 3 * per + count * kw] = keys[:count].reshape(-1)
+    flat = torch.empty(world * n_meta, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(flat, meta, group=group)
+    all_meta = flat.view(world, n_meta)
+    counts_h = all_meta[:, 0].tolist()
+    all_keys = torch.cat([all_meta[r, 1 + 3 * per:1 + 3 * per + counts_h[r] * kw].view(counts_h[r], kw) for r in range(world)], dim=0)
+    uniq = assemble(all_keys.contiguous())
+    offs = [0]
+    for c in counts_h[:-1]:
+        offs.append(offs[-1] + c)
+    gidx = all_meta[:, 1:1 + per].to(torch.int64) + torch.tensor(offs, dtype=torch.int64, device=dev)[:, None]
+    all_act = all_meta[:, 1 + per:1 + 2 * per].reshape(-1).to(actions.dtype)
+    all_keep = all_meta[:, 1 + 2 * per:1 + 3 * per].reshape(-1).to(keep.dtype)
+    return uniq, gidx.reshape(-1)[:n_total], all_act[:n_total], all_keep[:n_total]
+
+
 class EngineShard:
     """Per-rank adapter: HIP engine results copied device-to-device into torch CUDA
     tensors that RCCL can send (torch is only the carrier of device memory here)."""
@@ -127,6 +161,7 @@ class EngineShard:
         self.prune = belief_dominance_prune
         self.device = torch.device('cuda', engine.device)
         self._bufs = None
+        self._keys = None
 
     def buffers(self, b: int):
         t = self.torch
@@ -152,6 +187,27 @@ class EngineShard:
         self.engine.fetch_into(0, acts.data_ptr(), keep.data_ptr())
         self.engine.fetch_unique_into(rows.data_ptr(), idx.data_ptr())
         return rows, self.engine.unique_count, idx, acts, keep, stats
+
+    def run_resident_keys(self):
+        """For ``gather_keys``: ``(keys[B,1+O] (first U valid), U, index[B], actions[B], keep[B], stats)``; no alpha'
+        row leaves the engine."""
+        t = self.torch
+        stats = self.engine.run(self.gamma, self.prune)
+        _, acts, keep, idx = self.buffers(self.engine.B)
+        if self._keys is None or self._keys.shape[0] != self.engine.B:
+            self._keys = t.zeros((self.engine.B, 1 + self.engine.O), dtype=t.int32, device=self.device)
+        self.engine.fetch_into(0, acts.data_ptr(), keep.data_ptr())
+        self.engine.fetch_unique_into(0, idx.data_ptr())
+        self.engine.fetch_unique_keys_into(self._keys.data_ptr())
+        return self._keys, self.engine.unique_count, idx, acts, keep, stats
+
+    def assemble(self, keys):
+        """Rows for a device tensor of keys (device in, device out)."""
+        t = self.torch
+        dt = t.float32 if self.engine.dtype == 'f32' else t.float64
+        out = t.empty((keys.shape[0], self.engine.S), dtype=dt, device=self.device)
+        self.engine.assemble_rows_into(keys.data_ptr(), keys.shape[0], self.gamma, out.data_ptr())
+        return out
 
     def __call__(self, beliefs_local: np.ndarray):
         self.engine.set_beliefs(beliefs_local)

@@ -28,7 +28,7 @@ EXPORTS = [
     'pbvi_alpha_store_append', 'pbvi_alpha_select', 'pbvi_alpha_store_reset',
     'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset', 'pbvi_debug_poison',
     'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
-    'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk', 'pbvi_engine_set_rto_f64',
+    'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk', 'pbvi_engine_set_rto_f64', 'pbvi_backup_fetch_unique_keys', 'pbvi_assemble_rows',
 ]
 
 
@@ -101,6 +101,8 @@ def load_library(path: str = LIB_PATH):
         'pbvi_set_formulation': (C.c_int, [vp, C.c_int]),
         'pbvi_belief_walk': (C.c_int64, [vp, f64p, C.c_int64, i32p, i32p, u8p, f64p]),
         'pbvi_engine_set_rto_f64': (C.c_int, [vp, f64p]),
+        'pbvi_backup_fetch_unique_keys': (C.c_int, [vp, vp]),
+        'pbvi_assemble_rows': (C.c_int, [vp, C.c_double, C.c_int64, vp, vp]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -430,6 +432,30 @@ class Engine:
         """Copy unique rows [U,S] / index [B] to raw (host or device) addresses."""
         _check(self._lib.pbvi_backup_fetch_unique(self._h, C.c_void_p(rows_ptr) if rows_ptr else None,
                                                   C.cast(index_ptr, C.POINTER(C.c_int32)) if index_ptr else None))
+
+    def fetch_unique_keys(self) -> np.ndarray:
+        """``[U, 1+O]`` int32: (a*, v*[a*, :]) of each distinct alpha' row of the last backup."""
+        U = self.unique_count
+        keys = np.empty((U, 1 + self.O), dtype=np.int32)
+        if U:
+            _check(self._lib.pbvi_backup_fetch_unique_keys(self._h, _ptr(keys)))
+        return keys
+
+    def fetch_unique_keys_into(self, keys_ptr: int) -> None:
+        _check(self._lib.pbvi_backup_fetch_unique_keys(self._h, C.c_void_p(keys_ptr)))
+
+    def assemble_rows(self, keys: np.ndarray, gamma: float) -> np.ndarray:
+        """alpha' rows ``[n, S]`` for ``keys [n, 1+O]`` against the resident alpha set (``pbvi_assemble_rows``)."""
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        if k.ndim != 2 or k.shape[1] != 1 + self.O:
+            raise ValueError(f'keys must be [n, {1 + self.O}]')
+        out = np.empty((k.shape[0], self.S), dtype=self.np_dtype)
+        if k.shape[0]:
+            _check(self._lib.pbvi_assemble_rows(self._h, float(gamma), k.shape[0], _ptr(k), _ptr(out)))
+        return out
+
+    def assemble_rows_into(self, keys_ptr: int, n: int, gamma: float, out_ptr: int) -> None:
+        _check(self._lib.pbvi_assemble_rows(self._h, float(gamma), int(n), C.c_void_p(keys_ptr), C.c_void_p(out_ptr)))
 
     def fetch_into(self, alpha_ptr: int, action_ptr: int, keep_ptr: int) -> None:
         """Copy the last run's alpha rows / actions / keep mask to raw addresses (host or

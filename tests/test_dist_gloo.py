@@ -101,3 +101,43 @@ def test_gather_unique_world2(tmp_path):
     port = _free_port()
     mp.spawn(_worker_unique, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / 'uok0') and os.path.exists(tmp_path / 'uok1')
+
+
+def _worker_keys(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pomdp_pbvi_exploration_amd.dist import gather_keys
+        S, per, O = 6, 5, 3
+        count = rank + 2                                     # ragged unique counts
+        keys = torch.zeros((per, 1 + O), dtype=torch.int32)
+        keys[:count, 0] = rank                               # action
+        keys[:count, 1:] = (torch.arange(count, dtype=torch.int32)[:, None] * 10 + torch.arange(O, dtype=torch.int32)[None, :]
+                            + 1000 * rank)
+        idx = torch.arange(per, dtype=torch.int32) % count
+        acts = torch.full((per,), rank, dtype=torch.int32)
+        keep = (torch.arange(per) % 2).to(torch.uint8)
+
+        def assemble(all_keys):                              # stand-in for pbvi_assemble_rows: a row made of its key
+            assert all_keys.shape == (2 + 3, 1 + O)
+            return all_keys[:, 1:2].double().repeat(1, S) + all_keys[:, 0:1].double() / 10
+
+        uniq, gidx, a, k = gather_keys(dist, None, keys, count, idx, acts, keep, world * per - 1, assemble)
+        assert uniq.shape == (5, S) and gidx.shape == (world * per - 1,)
+        full = uniq[gidx][:, 0]
+        exp = torch.cat([((torch.arange(per) % (r + 2)) * 10 + 1000 * r).double() + r / 10 for r in range(world)])[: world * per - 1]
+        assert torch.equal(full, exp)
+        assert a.tolist() == ([0] * per + [1] * per)[: world * per - 1]
+        assert k.tolist() == ([0, 1, 0, 1, 0] * world)[: world * per - 1]
+        open(os.path.join(out_dir, f'kok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_keys_world2(tmp_path):
+    """The key exchange of bench.py --gpus N: one all-gather of integers, rows rebuilt locally from the keys."""
+    port = _free_port()
+    mp.spawn(_worker_keys, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / 'kok0') and os.path.exists(tmp_path / 'kok1')

@@ -851,3 +851,30 @@ def test_value_function_prune_level2_on_gpu_objects():
     assert np.array_equal(dev.actions, host.actions)
     dev.prune(2)                                          # already at that level: unchanged
     assert len(dev) == len(host)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_rows_rebuilt_from_keys_are_the_rows_of_the_backup(dtype):
+    """pbvi_backup_fetch_unique_keys + pbvi_assemble_rows (what ranks exchange instead of rows): keys are
+    (a*, v*[a*, :]) of each distinct row, and assembling them against the resident alpha set gives the same bytes."""
+    z = load_npz('olfactory_small_R5.npz')
+    rs, rto, er = z['reachable_states'], z['rto'].astype(np.float64), z['expected_rewards'].astype(np.float64)
+    alpha, b = z['alpha'].astype(np.float64), z['beliefs'].astype(np.float64)
+    gamma = float(z['gamma'])
+    eng = Engine(rto.shape[0], rto.shape[1], rto.shape[2], rto.shape[3], rs, rto, er, dtype=dtype)
+    eng.set_alpha(alpha)
+    eng.set_beliefs(b)
+    eng.run(gamma)
+    res = eng.fetch()
+    keys = eng.fetch_unique_keys()
+    assert keys.shape == (res.unique_alpha.shape[0], 1 + rto.shape[2])
+    first = np.array([np.flatnonzero(res.index == u)[0] for u in range(len(keys))])
+    assert np.array_equal(keys[:, 0], res.actions[first])
+    assert np.array_equal(keys[:, 1:], res.best_alpha_ind[first, res.actions[first], :])
+    rebuilt = eng.assemble_rows(keys[::-1], gamma)            # any order, any subset
+    assert np.array_equal(rebuilt, res.unique_alpha[::-1])
+    with pytest.raises(ValueError):
+        bad = keys.copy()
+        bad[0, 1] = alpha.shape[0] + 5
+        eng.assemble_rows(bad, gamma)
+    eng.close()
