@@ -85,7 +85,7 @@ def main():
 
     from pomdp_pbvi_exploration_amd import synth
     from pomdp_pbvi_exploration_amd.engine import Engine
-    from pomdp_pbvi_exploration_amd.dist import EngineShard, gather_keys, gather_unique
+    from pomdp_pbvi_exploration_amd.dist import EngineShard, gather_packed, gather_unique
 
     H, W = (int(x) for x in args.grid.split('x'))
     m = synth.olfactory_model(H=H, W=W, R=args.reach)
@@ -106,13 +106,13 @@ def main():
         if distributed:
             # local backup, then ONE all-gather of integers: per-belief index / action / keep and the keys
             # (a*, v*[a*, :]) of this rank's distinct alpha' rows; every rank rebuilds all rows from the keys against
-            # its replica of the alpha set (dist.gather_keys).  PBVI_EXCHANGE=rows moves the rows themselves instead.
+            # its replica of the alpha set (dist.gather_packed).  PBVI_EXCHANGE=rows moves the rows themselves instead.
             if exchange_rows:
                 rows, count, idx, acts, keep, st = shard.run_resident_unique()
                 gather_unique(dist, None, rows, count, idx, acts, keep, B * world)
             else:
-                keys, count, idx, acts, keep, st = shard.run_resident_keys()
-                gather_keys(dist, None, keys, count, idx, acts, keep, B * world, shard.assemble)
+                meta, per, kw, st = shard.run_resident_packed()
+                gather_packed(dist, None, meta, per, kw, B * world, shard.assemble)
             return st
         return eng.run(m.gamma)
 

@@ -170,6 +170,9 @@ int pbvi_backup_fetch_unique(pbvi_engine_t* e, void* out_rows, int32_t* out_inde
  *                                   byte-identical to the rows the producing rank holds.  1 <= n <= 65535.
  */
 int pbvi_backup_fetch_unique_keys(pbvi_engine_t* e, int32_t* out_keys);
+/* Everything a rank contributes to the exchange in one int32 buffer of 1 + 3B + B(1+O) entries (host or device):
+ *   [0] U | index [B] | actions [B] | keep [B] | keys of the U distinct rows, padded with zeros to [B][1+O]. */
+int pbvi_backup_fetch_exchange(pbvi_engine_t* e, int32_t* out);
 int pbvi_assemble_rows(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows);
 
 /*

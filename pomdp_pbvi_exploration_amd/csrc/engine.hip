@@ -103,6 +103,16 @@ struct DevBuf {
 // out[s] = max_v |alpha[v][s]| (out zeroed by the caller).  Row chunks of 128 run as separate blocks and meet in an
 // atomic max on the bit pattern (non-negative IEEE values order like unsigned integers): with one block per
 // column strip the 5000 dependent loads of a grown alpha set made this latency-bound (0.6 ms at V = 4500).
+// true iff ptr is device memory (hipMalloc'ed) rather than ordinary or pinned host memory
+static bool is_device_pointer(const void* ptr) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();                         // unregistered host memory
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice;
+}
+
 // keys of the unique rows of the last backup: key[u] = (a*, v*[a*, 0..O-1]) of the u-th distinct (a*, v*) pair
 __global__ void k_gather_keys(int U, int A, int O, const int32_t* __restrict__ uniq, const int32_t* __restrict__ action,
                               const int32_t* __restrict__ best_v, int32_t* __restrict__ keys) {
@@ -111,6 +121,27 @@ __global__ void k_gather_keys(int U, int A, int O, const int32_t* __restrict__ u
     const int b = uniq[u], a = action[b];
     keys[(int64_t)u * (1 + O)] = a;
     for (int o = 0; o < O; ++o) keys[(int64_t)u * (1 + O) + 1 + o] = best_v[((int64_t)b * A + a) * O + o];
+}
+
+// everything a rank contributes to the exchange, in one int32 buffer:
+//   [0] U | [1, 1+B) index | [1+B, 1+2B) action | [1+2B, 1+3B) keep | [1+3B, 1+3B+B*(1+O)) keys of the U distinct rows (rest 0)
+__global__ void k_pack_exchange(int B, int U, int A, int O, const int32_t* __restrict__ inv, const int32_t* __restrict__ action,
+                                const uint8_t* __restrict__ keep, const int32_t* __restrict__ uniq,
+                                const int32_t* __restrict__ best_v, int32_t* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0) out[0] = U;
+    if (c >= B) return;
+    out[1 + c] = inv[c];
+    out[1 + B + c] = action[c];
+    out[1 + 2 * B + c] = keep[c];
+    int32_t* k = out + 1 + 3 * (int64_t)B + (int64_t)c * (1 + O);
+    if (c < U) {
+        const int b = uniq[c], a = action[b];
+        k[0] = a;
+        for (int o = 0; o < O; ++o) k[1 + o] = best_v[((int64_t)b * A + a) * O + o];
+    } else {
+        for (int o = 0; o <= O; ++o) k[o] = 0;
+    }
 }
 
 // the inverse: per-row action / best-alpha arrays in the layout k_assemble reads (only the winning action's entries)
@@ -244,6 +275,7 @@ class EngineBase {
     virtual int64_t unique_count() const = 0;
     virtual int fetch_unique(void* out_rows, int32_t* out_index) = 0;
     virtual int fetch_unique_keys(int32_t* out_keys) = 0;
+    virtual int fetch_exchange(int32_t* out) = 0;
     virtual int assemble_keys(double gamma, int64_t n, const int32_t* keys, void* out_rows) = 0;
     virtual int prune_dominated(uint8_t* keep) = 0;
     virtual int value_max(double* out_value, int32_t* out_index) = 0;
@@ -894,6 +926,28 @@ class EngineT : public EngineBase {
                            uniq_.as<int32_t>(), res_action_, res_best_, keys_tmp_.as<int32_t>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out_keys, keys_tmp_.p, (size_t)res_unique_ * (1 + O_) * sizeof(int32_t), hipMemcpyDefault, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        return PBVI_OK;
+    }
+
+    // one buffer with everything this rank contributes to the multi-GPU exchange (layout: k_pack_exchange)
+    int fetch_exchange(int32_t* out) override {
+        if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch_exchange: no backup result resident");
+        if (!out) FAIL(PBVI_EINVAL, "backup_fetch_exchange: NULL destination");
+        HIPCHK(hipSetDevice(device_));
+        const size_t n = 1 + 3 * (size_t)res_B_ + (size_t)res_B_ * (1 + O_);
+        int32_t* dst = out;
+        const bool direct = is_device_pointer(out);
+        if (!direct) {
+            int rc = keys_tmp_.ensure(n * sizeof(int32_t), &bytes_);
+            if (rc) return rc;
+            dst = keys_tmp_.as<int32_t>();
+        }
+        hipLaunchKernelGGL(k_pack_exchange, dim3((unsigned)((res_B_ + 255) / 256)), dim3(256), 0, stream_, (int)res_B_,
+                           (int)res_unique_, A_, O_, inv_.as<int32_t>(), res_action_, keep_.as<uint8_t>(), uniq_.as<int32_t>(),
+                           res_best_, dst);
+        HIPCHK(hipGetLastError());
+        if (!direct) HIPCHK(hipMemcpyAsync(out, dst, n * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
         return PBVI_OK;
     }
@@ -1692,6 +1746,10 @@ int pbvi_backup_fetch(pbvi_engine_t* e, void* out_alpha, int32_t* out_action, in
 int pbvi_backup_fetch_unique_keys(pbvi_engine_t* e, int32_t* out_keys) {
     NEED(e);
     return e->impl->fetch_unique_keys(out_keys);
+}
+int pbvi_backup_fetch_exchange(pbvi_engine_t* e, int32_t* out) {
+    NEED(e);
+    return e->impl->fetch_exchange(out);
 }
 int pbvi_assemble_rows(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows) {
     NEED(e);

@@ -115,38 +115,49 @@ def gather_unique(dist, group, rows, count: int, index, actions, keep, n_total: 
     return uniq, gidx.reshape(-1)[:n_total], all_act[:n_total], all_keep[:n_total]
 
 
-def gather_keys(dist, group, keys, count: int, index, actions, keep, n_total: int, assemble):
+def pack_exchange(keys, count: int, index, actions, keep):
+    """The per-rank message of ``gather_packed`` from separate tensors (the engine writes it in one kernel,
+    ``pbvi_backup_fetch_exchange``): ``[U | index[B] | actions[B] | keep[B] | keys[B][1+O] (first U valid)]`` int32."""
+    import torch
+    per = index.shape[0]
+    body = torch.zeros((per, keys.shape[1]), dtype=torch.int32, device=index.device)
+    body[:count] = keys[:count]
+    head = torch.tensor([count], dtype=torch.int32, device=index.device)
+    return torch.cat([head, index.to(torch.int32), actions.to(torch.int32), keep.to(torch.int32), body.reshape(-1)])
+
+
+def gather_packed(dist, group, meta, per: int, key_width: int, n_total: int, assemble):
     """The exchange without rows.  A rank's alpha' rows are functions of their keys ``(a*, v*[a*, :])`` and of the
-    replicated alpha set and model, so ONE ``all_gather_into_tensor`` of integers suffices: per rank its count, the
-    per-belief ``index`` / ``actions`` / ``keep`` and the keys of its (at most ``per``) distinct rows.  Every rank then
-    rebuilds all rows with ``assemble(all_keys [sum U_r, 1+O]) -> [sum U_r, S]`` (``pbvi_assemble_rows``: byte-identical
-    to the rows the producing rank holds).  At C4 that is 28 KB per rank on the wire instead of 8 MB.
-    Returns the same tuple as ``gather_unique``."""
+    replicated alpha set and model, so ONE ``all_gather_into_tensor`` of integers suffices: per rank the packed
+    message of ``pack_exchange``.  Every rank then rebuilds all rows with
+    ``assemble(all_keys [sum U_r, 1+O]) -> [sum U_r, S]`` (``pbvi_assemble_rows``: byte-identical to the rows the
+    producing rank holds).  At C4 that is 28 KB per rank on the wire instead of 8 MB.
+    Returns ``(unique rows [sum U_r, S], global index [n_total], actions [n_total], keep [n_total])``."""
     import torch
     world = dist.get_world_size(group)
-    dev = index.device
-    per = index.shape[0]
-    kw = keys.shape[1]
-    n_meta = 1 + 3 * per + per * kw
-    meta = torch.zeros(n_meta, dtype=torch.int32, device=dev)
-    meta[0] = count
-    meta[1:1 + per] = index
-    meta[1 + per:1 + 2 * per] = actions
-    meta[1 + 2 * per:1 + 3 * per] = keep
-    meta[1 + 3 * per:1 + 3 * per + count * kw] = keys[:count].reshape(-1)
+    dev = meta.device
+    n_meta = meta.shape[0]
+    assert n_meta == 1 + 3 * per + per * key_width
     flat = torch.empty(world * n_meta, dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(flat, meta, group=group)
     all_meta = flat.view(world, n_meta)
     counts_h = all_meta[:, 0].tolist()
-    all_keys = torch.cat([all_meta[r, 1 + 3 * per:1 + 3 * per + counts_h[r] * kw].view(counts_h[r], kw) for r in range(world)], dim=0)
+    k0 = 1 + 3 * per
+    all_keys = torch.cat([all_meta[r, k0:k0 + counts_h[r] * key_width].view(counts_h[r], key_width) for r in range(world)], dim=0)
     uniq = assemble(all_keys.contiguous())
     offs = [0]
     for c in counts_h[:-1]:
         offs.append(offs[-1] + c)
     gidx = all_meta[:, 1:1 + per].to(torch.int64) + torch.tensor(offs, dtype=torch.int64, device=dev)[:, None]
-    all_act = all_meta[:, 1 + per:1 + 2 * per].reshape(-1).to(actions.dtype)
-    all_keep = all_meta[:, 1 + 2 * per:1 + 3 * per].reshape(-1).to(keep.dtype)
+    all_act = all_meta[:, 1 + per:1 + 2 * per].reshape(-1)
+    all_keep = all_meta[:, 1 + 2 * per:1 + 3 * per].reshape(-1).to(torch.uint8)
     return uniq, gidx.reshape(-1)[:n_total], all_act[:n_total], all_keep[:n_total]
+
+
+def gather_keys(dist, group, keys, count: int, index, actions, keep, n_total: int, assemble):
+    """``gather_packed`` for callers that hold the pieces separately."""
+    return gather_packed(dist, group, pack_exchange(keys, count, index, actions, keep), index.shape[0], keys.shape[1],
+                         n_total, assemble)
 
 
 class EngineShard:
@@ -188,18 +199,18 @@ class EngineShard:
         self.engine.fetch_unique_into(rows.data_ptr(), idx.data_ptr())
         return rows, self.engine.unique_count, idx, acts, keep, stats
 
-    def run_resident_keys(self):
-        """For ``gather_keys``: ``(keys[B,1+O] (first U valid), U, index[B], actions[B], keep[B], stats)``; no alpha'
-        row leaves the engine."""
+    def run_resident_packed(self):
+        """For ``gather_packed``: the engine packs count, index, actions, keep and the keys of its distinct rows into one
+        device int32 buffer (``pbvi_backup_fetch_exchange``); no alpha' row leaves the engine.  Returns
+        ``(meta, B, 1+O, stats)``."""
         t = self.torch
         stats = self.engine.run(self.gamma, self.prune)
-        _, acts, keep, idx = self.buffers(self.engine.B)
-        if self._keys is None or self._keys.shape[0] != self.engine.B:
-            self._keys = t.zeros((self.engine.B, 1 + self.engine.O), dtype=t.int32, device=self.device)
-        self.engine.fetch_into(0, acts.data_ptr(), keep.data_ptr())
-        self.engine.fetch_unique_into(0, idx.data_ptr())
-        self.engine.fetch_unique_keys_into(self._keys.data_ptr())
-        return self._keys, self.engine.unique_count, idx, acts, keep, stats
+        B, kw = self.engine.B, 1 + self.engine.O
+        n = 1 + 3 * B + B * kw
+        if self._keys is None or self._keys.shape[0] != n:
+            self._keys = t.empty(n, dtype=t.int32, device=self.device)
+        self.engine.fetch_exchange_into(self._keys.data_ptr())
+        return self._keys, B, kw, stats
 
     def assemble(self, keys):
         """Rows for a device tensor of keys (device in, device out)."""

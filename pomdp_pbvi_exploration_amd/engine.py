@@ -29,6 +29,7 @@ EXPORTS = [
     'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset', 'pbvi_debug_poison',
     'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
     'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk', 'pbvi_engine_set_rto_f64', 'pbvi_backup_fetch_unique_keys', 'pbvi_assemble_rows',
+    'pbvi_backup_fetch_exchange',
 ]
 
 
@@ -103,6 +104,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_engine_set_rto_f64': (C.c_int, [vp, f64p]),
         'pbvi_backup_fetch_unique_keys': (C.c_int, [vp, vp]),
         'pbvi_assemble_rows': (C.c_int, [vp, C.c_double, C.c_int64, vp, vp]),
+        'pbvi_backup_fetch_exchange': (C.c_int, [vp, vp]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -443,6 +445,10 @@ class Engine:
 
     def fetch_unique_keys_into(self, keys_ptr: int) -> None:
         _check(self._lib.pbvi_backup_fetch_unique_keys(self._h, C.c_void_p(keys_ptr)))
+
+    def fetch_exchange_into(self, ptr: int) -> None:
+        """``[U | index[B] | actions[B] | keep[B] | keys[B][1+O]]`` int32 at a raw (host or device) address."""
+        _check(self._lib.pbvi_backup_fetch_exchange(self._h, C.c_void_p(ptr)))
 
     def assemble_rows(self, keys: np.ndarray, gamma: float) -> np.ndarray:
         """alpha' rows ``[n, S]`` for ``keys [n, 1+O]`` against the resident alpha set (``pbvi_assemble_rows``)."""
