@@ -873,6 +873,15 @@ def test_rows_rebuilt_from_keys_are_the_rows_of_the_backup(dtype):
     assert np.array_equal(keys[:, 1:], res.best_alpha_ind[first, res.actions[first], :])
     rebuilt = eng.assemble_rows(keys[::-1], gamma)            # any order, any subset
     assert np.array_equal(rebuilt, res.unique_alpha[::-1])
+    # the packed exchange message holds the same pieces: [U | index | actions | keep | keys padded to B rows]
+    B, U, kw = len(b), len(keys), keys.shape[1]
+    packed = np.full(1 + 3 * B + B * kw, -7, dtype=np.int32)
+    eng.fetch_exchange_into(packed.ctypes.data)
+    assert packed[0] == U
+    assert np.array_equal(packed[1:1 + B], res.index) and np.array_equal(packed[1 + B:1 + 2 * B], res.actions)
+    assert np.array_equal(packed[1 + 2 * B:1 + 3 * B], res.keep.astype(np.int32))
+    body = packed[1 + 3 * B:].reshape(B, kw)
+    assert np.array_equal(body[:U], keys) and not body[U:].any()
     with pytest.raises(ValueError):
         bad = keys.copy()
         bad[0, 1] = alpha.shape[0] + 5
