@@ -321,6 +321,8 @@ class EngineT : public EngineBase {
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     DevBuf bp_, nzP_, pmag_, prd_;                          // belief-side formulation: projected beliefs, tile map, magnitudes, b.ER
     bool btl_valid_ = false;                                // btl_/btc_ describe the resident belief block
+    void* host_stage_ = nullptr;                            // pinned bounce buffer for rows going to pageable host memory
+    size_t host_stage_cap_ = 0;
     DevBuf keys_tmp_, keys_act_, keys_best_, keys_rows_;    // unique-row keys out / rows from keys in (multi-GPU exchange)
     DevBuf rf_v_, rf_slot_, rf_sc_, rf_entry_, rf_n_, rf_tiles_, rf_ibv_, rf_ibi_, rf_cnt_, rf_W_, rf_Cx_, rf_nzW_, rf_klW_, rf_kcW_;   // refinement work list
     int formulation_ = 0;                                   // 0 auto, 1 project alpha-vectors, 2 project beliefs
@@ -353,6 +355,7 @@ class EngineT : public EngineBase {
                          &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
+        if (host_stage_) (void)hipHostFree(host_stage_);
         for (auto& e : ev_)
             if (e) (void)hipEventDestroy(e);
         if (ev_fork_) (void)hipEventDestroy(ev_fork_);
@@ -807,8 +810,9 @@ class EngineT : public EngineBase {
                                        bu_unnorm_.as<double>(), bu_mass_.as<double>(), rows + (size_t)(i + 1) * S_,
                                        dst + (size_t)i * S_pad_, stream_));
         }
-        HIPCHK(hipMemcpyAsync(out, rows + S_, (size_t)n * S_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIPCHK(hipStreamSynchronize(stream_));
+        if ((rc = out_begin())) return rc;
+        if ((rc = out_add(out, rows + S_, (size_t)n * S_ * sizeof(double)))) return rc;
+        if ((rc = out_finish())) return rc;
         const int64_t first = store_rows_[1];
         store_rows_[1] = first + n;
         return first;
@@ -889,16 +893,16 @@ class EngineT : public EngineBase {
         if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch: no backup result resident (call pbvi_backup_run first)");
         HIPCHK(hipSetDevice(device_));
         const size_t B = (size_t)res_B_;
+        int rc;
+        if ((rc = out_begin())) return rc;
         if (out_alpha) {
-            int rc = ensure_full();
-            if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(out_alpha, out_full_.p, B * S_ * sizeof(T), hipMemcpyDefault, stream_));
+            if ((rc = ensure_full())) return rc;
+            if ((rc = out_add(out_alpha, out_full_.p, B * S_ * sizeof(T)))) return rc;
         }
-        if (out_action) HIPCHK(hipMemcpyAsync(out_action, res_action_, B * sizeof(int32_t), hipMemcpyDefault, stream_));
-        if (out_best) HIPCHK(hipMemcpyAsync(out_best, res_best_, B * A_ * O_ * sizeof(int32_t), hipMemcpyDefault, stream_));
-        if (out_keep) HIPCHK(hipMemcpyAsync(out_keep, keep_.p, B, hipMemcpyDefault, stream_));
-        HIPCHK(hipStreamSynchronize(stream_));
-        return PBVI_OK;
+        if (out_action && (rc = out_add(out_action, res_action_, B * sizeof(int32_t)))) return rc;
+        if (out_best && (rc = out_add(out_best, res_best_, B * A_ * O_ * sizeof(int32_t)))) return rc;
+        if (out_keep && (rc = out_add(out_keep, keep_.p, B))) return rc;
+        return out_finish();
     }
 
     int64_t unique_count() const override { return have_result_ ? res_unique_ : -1; }
@@ -906,13 +910,66 @@ class EngineT : public EngineBase {
     int fetch_unique(void* out_rows, int32_t* out_index) override {
         if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch_unique: no backup result resident");
         HIPCHK(hipSetDevice(device_));
-        if (out_rows)
-            HIPCHK(hipMemcpyAsync(out_rows, out_.p, (size_t)res_unique_ * S_ * sizeof(T), hipMemcpyDefault, stream_));
-        if (out_index)
-            HIPCHK(hipMemcpyAsync(out_index, inv_.p, (size_t)res_B_ * sizeof(int32_t), hipMemcpyDefault, stream_));
-        HIPCHK(hipStreamSynchronize(stream_));
+        int rc;
+        if ((rc = out_begin())) return rc;
+        if (out_rows && (rc = out_add(out_rows, out_.p, (size_t)res_unique_ * S_ * sizeof(T)))) return rc;
+        if (out_index && (rc = out_add(out_index, inv_.p, (size_t)res_B_ * sizeof(int32_t)))) return rc;
+        return out_finish();
+    }
+
+    // ---- device -> host results ------------------------------------------------------------------------------------ //
+    // Results bound for ordinary (pageable) host memory go through one long-lived pinned buffer and a CPU memcpy:
+    // the DMA never targets memory the driver has to register first.  Device destinations are copied directly.
+    // (The caller should not map fresh host memory per call either: see HostArena in engine.py.)
+    struct OutItem {
+        void* dst;
+        size_t off, bytes;
+    };
+    std::vector<OutItem> out_items_;
+    size_t out_used_ = 0;
+
+    int out_begin() {
+        out_items_.clear();
+        out_used_ = 0;
         return PBVI_OK;
     }
+    int out_flush() {
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (const OutItem& it : out_items_) std::memcpy(it.dst, (const char*)host_stage_ + it.off, it.bytes);
+        out_items_.clear();
+        out_used_ = 0;
+        return PBVI_OK;
+    }
+    int out_add(void* dst, const void* src_dev, size_t bytes) {
+        if (bytes == 0) return PBVI_OK;
+        if (is_device_pointer(dst)) {
+            HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToDevice, stream_));
+            return PBVI_OK;
+        }
+        const size_t need = (out_used_ + 255) / 256 * 256 + bytes;
+        if (need > host_stage_cap_) {
+            int rc = out_flush();                            // nothing staged may be lost when the buffer moves
+            if (rc) return rc;
+            if (bytes > host_stage_cap_) {
+                if (host_stage_) (void)hipHostFree(host_stage_);
+                host_stage_ = nullptr;
+                host_stage_cap_ = 0;
+                const size_t want = std::max<size_t>(bytes * 2, (size_t)64 << 20);
+                if (hipHostMalloc(&host_stage_, want, hipHostMallocDefault) != hipSuccess) {
+                    (void)hipGetLastError();
+                    host_stage_ = nullptr;
+                    FAIL(PBVI_ENOMEM, "pinned staging allocation failed");
+                }
+                host_stage_cap_ = want;
+            }
+        }
+        const size_t off = (out_used_ + 255) / 256 * 256;
+        HIPCHK(hipMemcpyAsync((char*)host_stage_ + off, src_dev, bytes, hipMemcpyDeviceToHost, stream_));
+        out_items_.push_back({dst, off, bytes});
+        out_used_ = off + bytes;
+        return PBVI_OK;
+    }
+    int out_finish() { return out_flush(); }
 
     // (a*, v*[a*,:]) of every unique row of the last backup: [U][1+O] int32, host or device destination
     int fetch_unique_keys(int32_t* out_keys) override {
@@ -1025,9 +1082,10 @@ class EngineT : public EngineBase {
             dv = tv.data();
             di = ti.data();
         }
-        if (out_value) HIPCHK(hipMemcpyAsync(dv, bs2_.p, (size_t)B_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        if (out_index) HIPCHK(hipMemcpyAsync(di, bv2_.p, (size_t)B_ * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        HIPCHK(hipStreamSynchronize(stream_));
+        if ((rc = out_begin())) return rc;
+        if (out_value && (rc = out_add(dv, bs2_.p, (size_t)B_ * sizeof(double)))) return rc;
+        if (out_index && (rc = out_add(di, bv2_.p, (size_t)B_ * sizeof(int32_t)))) return rc;
+        if ((rc = out_finish())) return rc;
         if (sorted_)
             for (int64_t i = 0; i < B_; ++i) {
                 if (out_value) out_value[h_perm_[(size_t)i]] = tv[(size_t)i];
