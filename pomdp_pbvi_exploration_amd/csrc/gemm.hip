@@ -188,10 +188,15 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_mfma(
 // --------------------------------------------------------------------------- //
 // scheduler 2: stream-K, persistent
 // --------------------------------------------------------------------------- //
-// plan[0] = q (tile-steps per block), plan[1] = T (total listed tile-steps)
+// Shares are equal in COST, not in tile-steps: every non-empty pair carries `ovh` extra units in front of its list
+// (zeroing the accumulators, the exposed latency of its first operand tiles, the 256 KiB slab store), so a block
+// whose share crosses many one-tile lists (a rarely-seen observation) is not the last one to finish.  Unit u of a
+// pair maps to list entry max(0, u - ovh); a block whose part of a pair lies wholly inside the overhead units
+// multiplies nothing and stores nothing.
+// plan[0] = q (cost units per block, an upper bound of the tile-steps of any chain), plan[1] = T (total cost units)
 __global__ void k_streamk_plan(const int* __restrict__ kcount, int pairs, int nblocks, int k_tiles, int max_split,
-                               int* __restrict__ prefix, int* __restrict__ start_pair, int* __restrict__ first_block,
-                               int* __restrict__ nchunks, int* __restrict__ plan) {
+                               int ovh, int* __restrict__ prefix, int* __restrict__ start_pair,
+                               int* __restrict__ first_block, int* __restrict__ nchunks, int* __restrict__ plan) {
     __shared__ int part[256];
     __shared__ int q_sh;
     const int tid = threadIdx.x;
@@ -199,7 +204,10 @@ __global__ void k_streamk_plan(const int* __restrict__ kcount, int pairs, int nb
     const int p0 = (tid * per < pairs) ? tid * per : pairs;
     const int p1 = (p0 + per < pairs) ? p0 + per : pairs;
     int sum = 0;
-    for (int p = p0; p < p1; ++p) sum += kcount[p];
+    for (int p = p0; p < p1; ++p) {
+        const int cnt = kcount[p];
+        sum += cnt > 0 ? cnt + ovh : 0;
+    }
     part[tid] = sum;
     for (int i = tid; i < nblocks; i += 256) start_pair[i] = -1;
     __syncthreads();
@@ -211,7 +219,7 @@ __global__ void k_streamk_plan(const int* __restrict__ kcount, int pairs, int nb
             run += v;
         }
         int q = (run + nblocks - 1) / nblocks;
-        const int qmin = (k_tiles + max_split - 1) / max_split;   // a pair spans at most max_split+1 blocks
+        const int qmin = (k_tiles + ovh + max_split - 1) / max_split;   // a pair spans at most max_split+1 blocks
         if (q < qmin) q = qmin;
         if (q < 1) q = 1;
         q_sh = q;
@@ -226,16 +234,18 @@ __global__ void k_streamk_plan(const int* __restrict__ kcount, int pairs, int nb
         const int cnt = kcount[p];
         prefix[p] = run;
         if (cnt > 0) {
-            const int fb = run / q, lb = (run + cnt - 1) / q;
-            first_block[p] = fb;
-            nchunks[p] = lb - fb + 1;
+            const int cost = cnt + ovh;
+            const int fb = run / q, lb = (run + cost - 1) / q;
+            const int fw = (run + ovh) / q;                                // first block that reaches a list entry
+            first_block[p] = fw;
+            nchunks[p] = lb - fw + 1;
             for (int i = fb; i <= lb; ++i)
                 if ((int64_t)i * q >= run) start_pair[i] = p;          // block i's share begins inside pair p
+            run += cost;
         } else {
             first_block[p] = 0;
             nchunks[p] = 0;
         }
-        run += cnt;
     }
 }
 
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
     int64_t slab_stride, int tiles_m, int pairs, int k_tiles, const int* __restrict__ klist,
     const int* __restrict__ kcount, const int* __restrict__ prefix, const int* __restrict__ start_pair,
-    const int* __restrict__ first_block, const int* __restrict__ plan) {
+    const int* __restrict__ first_block, const int* __restrict__ plan, int ovh) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // XCD-contiguous logical ids: consecutive shares (which walk the same n-tile's pairs) on one XCD.
     const int nb = gridDim.x;
@@ -267,16 +277,20 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk(
             ++p;
             continue;
         }
-        const int lo = (int)(pos - prefix[p]);
+        const int u_lo = (int)(pos - prefix[p]);         // cost units of this pair inside the share
         const int64_t room = end - pos;
-        const int hi = (lo + room < cnt) ? (int)(lo + room) : cnt;
-        const int tm = p % tiles_m, tn = p / tiles_m;
-        f32x16 acc[4][2];
-        tile_zero(acc);
-        tile_run(t, lds, A + (int64_t)tm * 256 * lda, lda, B + (int64_t)tn * 256 * ldb, ldb,
-                 klist + (int64_t)p * k_tiles, lo, hi, acc);
-        tile_store(t, C + (int64_t)(L - first_block[p]) * slab_stride, ldc, tm, tn, acc);
-        pos += hi - lo;
+        const int u_hi = (u_lo + room < cnt + ovh) ? (int)(u_lo + room) : cnt + ovh;
+        const int lo = u_lo > ovh ? u_lo - ovh : 0;
+        const int hi = u_hi > ovh ? u_hi - ovh : 0;
+        if (hi > lo) {
+            const int tm = p % tiles_m, tn = p / tiles_m;
+            f32x16 acc[4][2];
+            tile_zero(acc);
+            tile_run(t, lds, A + (int64_t)tm * 256 * lda, lda, B + (int64_t)tn * 256 * ldb, ldb,
+                     klist + (int64_t)p * k_tiles, lo, hi, acc);
+            tile_store(t, C + (int64_t)(L - first_block[p]) * slab_stride, ldc, tm, tn, acc);
+        }
+        pos += u_hi - u_lo;
         ++p;
     }
 }
@@ -426,13 +440,14 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
         int* start_pair = prefix + pairs + 1;            // [nblocks]
         int* first_block = start_pair + pl.nblocks;      // [pairs]
         int* plan = first_block + pairs;                 // [2]
+        static const int ovh = getenv("PBVI_STREAMK_OVH") ? atoi(getenv("PBVI_STREAMK_OVH")) : 1;   // per-pair fixed cost, in tile-steps
         hipLaunchKernelGGL(k_streamk_plan, dim3(1), dim3(256), 0, stream, kcount, pairs, pl.nblocks, pl.k_tiles,
-                           pl.max_chunks - 1, prefix, start_pair, first_block, nchunks, plan);
+                           pl.max_chunks - 1, ovh, prefix, start_pair, first_block, nchunks, plan);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_gemm_nt_f32_streamk, dim3(pl.nblocks), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B, ldb, C,
                            pl.ldc, pl.slab_stride, pl.tiles_m, pairs, pl.k_tiles, klist, kcount, prefix, start_pair,
-                           first_block, plan);
+                           first_block, plan, ovh);
         return hipGetLastError();
     }
     const int64_t groups = ((int64_t)pl.tiles_n * pl.max_chunks + 7) / 8 * 8;
