@@ -339,7 +339,7 @@ class EngineT : public EngineBase {
     int64_t rows_pad_s_ = 0, dense_pairs_ = 0;
     std::vector<int> h_kcountD_;
     hipStream_t stream2_ = nullptr;                  // belief-only kernels run beside projection + GEMM
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_lists_ = nullptr;
     GemmPlan plan_ = {};
     hipEvent_t ev_[9] = {};
     bool have_result_ = false, res_sorted_ = false;
@@ -360,6 +360,7 @@ class EngineT : public EngineBase {
             if (e) (void)hipEventDestroy(e);
         if (ev_fork_) (void)hipEventDestroy(ev_fork_);
         if (ev_join_) (void)hipEventDestroy(ev_join_);
+        if (ev_lists_) (void)hipEventDestroy(ev_lists_);
         if (stream2_) (void)hipStreamDestroy(stream2_);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
@@ -396,6 +397,7 @@ class EngineT : public EngineBase {
         for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
         HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_lists_, hipEventDisableTiming));
 
         // re-tile the reference's [S][A][R] / [S][A][O][R] / [S][A] tables to s-contiguous planes
         const size_t n_rs = (size_t)A * R * S_pad_, n_rto = (size_t)A * O * R * S_pad_, n_er = (size_t)A * S_pad_;
@@ -874,7 +876,7 @@ class EngineT : public EngineBase {
     // G row groups of v_group rows with support nzB (nullptr = dense Y).
     // scores of X rows (default: the resident belief block) against the rows of Y
     int score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv,
-                   const T* X = nullptr, int64_t x_rows = 0, const uint8_t* nzX = nullptr);
+                   const T* X = nullptr, int64_t x_rows = 0, const uint8_t* nzX = nullptr, hipStream_t list_stream = nullptr);
 
     int project_dense(double gamma);   // K1-dense: Gamma = gamma * alpha . D_ao^T as A*O (batched) GEMMs
     int backup_run(double gamma, int flags, pbvi_stats_t* st) override;
@@ -1182,7 +1184,7 @@ class EngineT : public EngineBase {
 
 template <typename T>
 int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv,
-                           const T* X, int64_t x_rows, const uint8_t* nzX) {
+                           const T* X, int64_t x_rows, const uint8_t* nzX, hipStream_t list_stream) {
     int rc;
     const int64_t m_rows = X ? x_rows : B_;
     const int64_t m_pad = X ? round_up(x_rows, GEMM_BM) : B_pad_;
@@ -1202,7 +1204,7 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
         if ((rc = skws_.ensure(streamk_workspace_ints(plan_) * sizeof(int), &bytes_))) return rc;
         HIPCHK(launch_gemm_nt_f32((const float*)X, S_pad_, (const float*)Y, S_pad_, slabs_.as<float>(), plan_,
                                   nzX, nzB, G, v_group, (int)rows_y, klist_.as<int>(), kcount_.as<int>(),
-                                  nchunks_.as<int>(), stream_, 1, 0, 0, skws_.as<int>()));
+                                  nchunks_.as<int>(), stream_, 1, 0, 0, skws_.as<int>(), list_stream, ev_lists_));
         sv->slabs = slabs_.as<T>();
         sv->slab_stride = plan_.slab_stride;
         sv->ldc = plan_.ldc;
@@ -1435,7 +1437,8 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     HIPCHK(launch_tail_rows<T>(mv, gam_.as<T>() + (size_t)(AO * Vt) * S_pad_, S_pad_, stream_));
     HIPCHK(hipEventRecord(ev_[1], stream_));
     // K2: scores
-    if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv))) return rc;
+    // (its tile lists and stream-K plan are built on the side stream, beside the projection)
+    if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv, nullptr, 0, nullptr, no_side ? nullptr : side))) return rc;
     }
     HIPCHK(hipEventRecord(ev_[2], stream_));
     HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));       // dead flags + rdot ready

@@ -50,7 +50,7 @@ struct TileThread {
     __device__ __forceinline__ void init() {
         const int tid = threadIdx.x;
         lane = tid & 63;
-        wid = tid >> 6;
+        wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the LDS-DMA base (M0) of every stage load becomes an s_add
         i = lane & 31;
         h = lane >> 5;
         wr = wid >> 2;
@@ -113,15 +113,21 @@ __device__ __forceinline__ void tile_compute(const TileThread& t, const float* l
 __device__ __forceinline__ void tile_run(const TileThread& t, float* lds, const float* Ablk, int lda, const float* Bblk,
                                          int ldb, const int* __restrict__ kl, int i0, int i1, f32x16 (&acc)[4][2]) {
     tile_stage(t, lds, 0, Ablk, lda, Bblk, ldb, kl[i0]);
+    int k_next = (i0 + 1 < i1) ? kl[i0 + 1] : 0;         // list entries are read one step ahead of their use
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     for (int it = i0; it < i1; ++it) {
-        if (it + 1 < i1) tile_stage(t, lds, buf ^ 1, Ablk, lda, Bblk, ldb, kl[it + 1]);
+        int k_after = 0;
+        if (it + 1 < i1) {
+            tile_stage(t, lds, buf ^ 1, Ablk, lda, Bblk, ldb, k_next);
+            if (it + 2 < i1) k_after = kl[it + 2];
+        }
         tile_compute(t, lds, buf, acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         buf ^= 1;
+        k_next = k_after;
     }
 }
 
@@ -424,13 +430,16 @@ static hipError_t set_lds_attr() {
 hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, const GemmPlan& pl,
                               const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
                               int* kcount, int* nchunks, hipStream_t stream, int batch, int64_t batch_stride_b,
-                              int64_t batch_stride_c, int* streamk_ws) {
+                              int64_t batch_stride_c, int* streamk_ws, hipStream_t list_stream, hipEvent_t list_event) {
     hipError_t e = set_lds_attr();
     if (e != hipSuccess) return e;
     if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
     const int pairs = pl.tiles_m * pl.tiles_n;
     static const int force_dense = getenv("PBVI_GEMM_DENSE") ? atoi(getenv("PBVI_GEMM_DENSE")) : 0;   // debug / A-B only
-    hipLaunchKernelGGL(k_build_klists, dim3(pairs, batch), dim3(256), 0, stream, nzA, nzB, G, v_group, n_rows,
+    // The tile lists and the stream-K plan depend on the zero maps only, not on the operands' values: with a
+    // list_stream they are built beside whatever `stream` is still doing (the Gamma projection) and the GEMM waits.
+    hipStream_t ls = (list_stream != nullptr && list_event != nullptr) ? list_stream : stream;
+    hipLaunchKernelGGL(k_build_klists, dim3(pairs, batch), dim3(256), 0, ls, nzA, nzB, G, v_group, n_rows,
                        pl.tiles_m, pl.k_tiles, pl.chunk_len, force_dense, klist, kcount, nchunks);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -441,14 +450,22 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
         int* first_block = start_pair + pl.nblocks;      // [pairs]
         int* plan = first_block + pairs;                 // [2]
         static const int ovh = getenv("PBVI_STREAMK_OVH") ? atoi(getenv("PBVI_STREAMK_OVH")) : 1;   // per-pair fixed cost, in tile-steps
-        hipLaunchKernelGGL(k_streamk_plan, dim3(1), dim3(256), 0, stream, kcount, pairs, pl.nblocks, pl.k_tiles,
+        hipLaunchKernelGGL(k_streamk_plan, dim3(1), dim3(256), 0, ls, kcount, pairs, pl.nblocks, pl.k_tiles,
                            pl.max_chunks - 1, ovh, prefix, start_pair, first_block, nchunks, plan);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+        if (ls != stream) {
+            if ((e = hipEventRecord(list_event, ls)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(stream, list_event, 0)) != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(k_gemm_nt_f32_streamk, dim3(pl.nblocks), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B, ldb, C,
                            pl.ldc, pl.slab_stride, pl.tiles_m, pairs, pl.k_tiles, klist, kcount, prefix, start_pair,
                            first_block, plan, ovh);
         return hipGetLastError();
+    }
+    if (ls != stream) {
+        if ((e = hipEventRecord(list_event, ls)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, list_event, 0)) != hipSuccess) return e;
     }
     const int64_t groups = ((int64_t)pl.tiles_n * pl.max_chunks + 7) / 8 * 8;
     const int64_t total = groups * pl.tiles_m;

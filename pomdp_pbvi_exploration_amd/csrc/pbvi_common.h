@@ -40,7 +40,10 @@ hipError_t launch_tile_nonzero_f32(const float* X, int ld, int rows_pad, int k_t
 hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, const GemmPlan& pl,
                               const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
                               int* kcount, int* nchunks, hipStream_t stream, int batch = 1,
-                              int64_t batch_stride_b = 0, int64_t batch_stride_c = 0, int* streamk_ws = nullptr);
+                              int64_t batch_stride_b = 0, int64_t batch_stride_c = 0, int* streamk_ws = nullptr,
+                              hipStream_t list_stream = nullptr, hipEvent_t list_event = nullptr);
+// list_stream + list_event: build the tile lists / stream-K plan on that stream (they need the zero maps only) and
+// make `stream` wait for them before the GEMM kernel.
 // streamk_ws layout: prefix[pairs+1], start_pair[nblocks], first_block[pairs], plan[2] = {steps per block, total steps}
 // fp64 MFMA GEMM (gemm_f64.hip): C[M][N] = A[M][K_pad] * B[N][K_pad]^T, one dense result slab, zero-tile lists
 // built from 32-column maps: nzA [ceil(M/256)][K_pad/32] (or nullptr), nzB [G+1][K_pad/32] per row group (or nullptr).
