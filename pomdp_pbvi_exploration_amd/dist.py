@@ -217,6 +217,8 @@ class EngineShard:
         t = self.torch
         dt = t.float32 if self.engine.dtype == 'f32' else t.float64
         out = t.empty((keys.shape[0], self.engine.S), dtype=dt, device=self.device)
+        # `keys` was produced on torch's stream; the engine reads it on its own (non-blocking) stream
+        t.cuda.current_stream(self.device).synchronize()
         self.engine.assemble_rows_into(keys.data_ptr(), keys.shape[0], self.gamma, out.data_ptr())
         return out
 
