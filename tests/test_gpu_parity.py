@@ -892,35 +892,12 @@ def test_rows_rebuilt_from_keys_are_the_rows_of_the_backup(dtype):
 def test_rccl_exchange_single_rank_matches_direct_fetch():
     """The multi-GPU step of bench.py --gpus N (EngineShard.run_resident_packed -> one all_gather_into_tensor of the
     packed integers -> rows rebuilt from the keys with pbvi_assemble_rows on device tensors) through a real RCCL
-    process group of one rank: the rebuilt rows, index, actions and keep equal what the engine returns directly."""
-    import socket
-    import torch
-    import torch.distributed as dist
-    from pomdp_pbvi_exploration_amd.dist import EngineShard, gather_packed, gather_unique
-    z, rs, rto, er = small(5)
-    gamma = float(z['gamma'])
-    eng = Engine(rto.shape[0], rto.shape[1], rto.shape[2], rto.shape[3], rs, rto, er, dtype='f32')
-    eng.set_alpha(z['alpha'])
-    eng.set_beliefs(z['beliefs'])
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    torch.cuda.set_device(0)
-    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
-                            device_id=torch.device('cuda', 0))
-    try:
-        shard = EngineShard(eng, gamma)
-        meta, per, kw, _ = shard.run_resident_packed()
-        uniq, gidx, acts, keep = gather_packed(dist, None, meta, per, kw, per, shard.assemble)
-        res = eng.fetch()
-        assert np.array_equal(uniq.cpu().numpy(), res.unique_alpha)
-        assert np.array_equal(gidx.cpu().numpy(), res.index)
-        assert np.array_equal(acts.cpu().numpy(), res.actions)
-        assert np.array_equal(keep.cpu().numpy().astype(bool), res.keep.astype(bool))
-        # the row exchange (PBVI_EXCHANGE=rows) gives the same rows
-        rows, count, idx, a2, k2, _ = shard.run_resident_unique()
-        u2, g2, _, _ = gather_unique(dist, None, rows, count, idx, a2, k2, per)
-        assert np.array_equal(u2.cpu().numpy(), res.unique_alpha) and np.array_equal(g2.cpu().numpy(), res.index)
-    finally:
-        dist.destroy_process_group()
-        eng.close()
+    process group of one rank: the rebuilt rows, index, actions and keep equal what the engine returns directly.
+    Runs in a child process, torch first: torch brings its own HIP runtime, which has to be the one that opens the
+    device (bench.py imports in the same order)."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'rccl_single_rank_check.py')
+    out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert 'rccl single-rank exchange ok' in out.stdout
