@@ -17,6 +17,7 @@ raises -- there is no silent CPU fallback.
 from __future__ import annotations
 
 import os
+import pickle
 import random
 from datetime import datetime
 from typing import Tuple, Union
@@ -208,6 +209,36 @@ class Model:
         if self.rewards_are_probabilistic:
             return 1 if random.random() < r else 0
         return r
+
+    def get_coords(self, item):
+        """Grid position(s) of a state id or a list of ids on ``state_grid`` (``src/mdp.py:467-484``)."""
+        ids = [item] if isinstance(item, int) else item
+        coords = [np.argwhere(self.cpu_model.state_grid == s)[0] for s in ids]
+        return coords[0] if isinstance(item, int) else coords
+
+    # -- persistence (src/mdp.py:487-530): the host model as a pickle ------- #
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_alt_model'] = None           # the GPU twin and its engine handle are rebuilt on demand
+        state['_engine'] = None
+        state['_engine_dtype'] = None
+        state['is_on_gpu'] = False
+        return state
+
+    def save(self, file_name: str, path: str = './Models') -> None:
+        if not os.path.exists(path):
+            print('Folder does not exist yet, creating it...')
+            os.makedirs(path)
+        if not file_name.endswith('.pck'):
+            file_name += '.pck'
+        with open(path + '/' + file_name, 'wb') as fh:
+            pickle.dump(self.cpu_model, fh)
+
+    @classmethod
+    def load_from_file(cls, file: str) -> 'Model':
+        """Load a model written by ``save``.  Only for files you wrote yourself: a pickle runs code when loaded."""
+        with open(file, 'rb') as fh:
+            return pickle.load(fh)
 
     # -- residency ------------------------------------------------------- #
     def to_gpu(self, dtype: str = 'f64', device: int = 0) -> 'Model':
@@ -461,6 +492,11 @@ class SolverHistory:
             self.value_function_changes.append(float(value_function_change))
         if self.tracking_level >= 2:
             self.value_functions.append(value_function)
+
+    @property
+    def solution(self):
+        assert self.tracking_level >= 2, "Tracking level is set too low, increase it to 2 if you want to have value function tracking as well."
+        return self.value_functions[-1]
 
     @property
     def summary(self) -> str:

@@ -252,6 +252,57 @@ class BeliefSet:
         return BeliefSet(cm, [Belief(cm, b.values) for b in self.belief_list])
 
 
+class BeliefValueMapping:
+    """Upper bound of the value function as (belief, value) points over the corner values, evaluated with the
+    sawtooth interpolation (``src/pomdp.py:786-895``; used by the HSVI expansion only).  Host-side: the points
+    are a few hundred rows at most."""
+
+    def __init__(self, model, corner_belief_values: ValueFunction) -> None:
+        self.model = model
+        self.corner_belief_values = corner_belief_values
+        self.corner_values = np.max(corner_belief_values.alpha_vector_array, axis=0)
+        self.beliefs = []
+        self.belief_value_mapping = {}
+        self._belief_array = None
+        self._value_array = None
+
+    def add(self, b: Belief, v: float) -> None:
+        """Record ``v`` at ``b``; a belief that is already a point keeps its first value."""
+        if b.bytes_repr not in self.belief_value_mapping:
+            self.beliefs.append(b)
+            self.belief_value_mapping[b.bytes_repr] = v
+
+    def update(self) -> None:
+        """Re-stack the cached point arrays (``evaluate`` reads the cache, so points added since the last call
+        are not seen until this runs -- the reference's behaviour, ``src/pomdp.py:863-870``)."""
+        self._belief_array = np.array([b.values for b in self.beliefs])
+        self._value_array = np.array(list(self.belief_value_mapping.values()))
+
+    @property
+    def belief_array(self) -> np.ndarray:
+        if self._belief_array is None:
+            self._belief_array = np.array([b.values for b in self.beliefs])
+        return self._belief_array
+
+    @property
+    def value_array(self) -> np.ndarray:
+        if self._value_array is None:
+            self._value_array = np.array(list(self.belief_value_mapping.values()))
+        return self._value_array
+
+    def evaluate(self, belief: Belief) -> float:
+        hit = self.belief_value_mapping.get(belief.bytes_repr)
+        if hit is not None:
+            return hit
+        v0 = np.dot(belief.values, self.corner_values)
+        if len(self.beliefs) == 0:
+            return float(v0)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            gap = self.value_array - np.dot(self.belief_array, self.corner_values)
+            vb = v0 + gap * np.min(belief.values / self.belief_array, axis=1)
+        return float(np.min(np.append(vb, v0)))
+
+
 class SolverHistory:
     """Times and sizes of a PBVI run (subset of ``src/pomdp.py:898-1117``)."""
 
@@ -306,6 +357,11 @@ class SolverHistory:
         return self.value_functions[-1]
 
     @property
+    def explored_beliefs(self) -> BeliefSet:
+        assert self.tracking_level >= 2, "Tracking level is set too low, increase it to 2 if you want to have belief sets tracking as well."
+        return self.belief_sets[-1]
+
+    @property
     def summary(self) -> str:
         n_b, n_e = len(self.backup_times), len(self.expansion_times)
         s = f'Summary of Point Based Value Iteration run\n'
@@ -336,6 +392,39 @@ class PBVI_Solver(Solver):
         self.eps = eps
         self.expand_function = expand_function
         self.expand_function_params = expand_function_params
+
+    def test_n_simulations(self, model: Model, value_function: ValueFunction, n: int = 1000, horizon: int = 300,
+                           print_progress: bool = False):
+        """Roll the greedy policy of ``value_function`` out in ``n`` simulations advanced together
+        (``src/pomdp.py:1338-1444``).  Unlike ``Agent.run_n_simulations_parallel`` every simulation keeps being
+        stepped after it reached an end state (its rewards are masked instead).  Returns ``(start_states,
+        done_at_step, rewards, discounted_rewards)`` -- the last two are lists of ``[n]`` arrays, one per step.
+        With the value function on the GPU the belief block lives in the HIP engine for the whole run."""
+        on_gpu = value_function.is_on_gpu
+        model = model.gpu_model if on_gpu else model.cpu_model
+        beliefs = np.repeat(Belief(model).values[None, :], n, axis=0)
+        sims = SimulationSet(model.cpu_model)
+        start_states = sims.initialize_simulations(n)
+        block = (_DeviceBeliefBlock if on_gpu else _HostBeliefBlock)(model, value_function, beliefs)
+        everyone = np.ones(n, dtype=bool)
+        end_states = np.array(model.end_states)
+        done_at_step = np.full(n, -1)
+        actions_of = np.asarray(value_function.actions)
+        discount = self.gamma
+        rewards, discounted_rewards = [], []
+        for i in range(horizon):
+            was_done = sims.is_done.copy()
+            best_actions = actions_of[block.best_vectors()]
+            step_rewards, observations = sims.run_actions(best_actions)
+            block.advance(best_actions, observations, everyone)
+            rewards.append(step_rewards)
+            discounted_rewards.append(step_rewards * discount)
+            are_done = np.isin(sims.agent_states, end_states)
+            done_at_step[was_done ^ are_done] = i + 1
+            discount *= self.gamma
+            if np.all(sims.is_done):
+                break
+        return start_states, done_at_step, rewards, discounted_rewards
 
     # ------------------------------------------------------------------ #
     # hot path
@@ -465,6 +554,42 @@ class PBVI_Solver(Solver):
                         * err[b_i[:, None], a_i[:, None], model.observations[None, :]], axis=1)
         return BeliefSet(model, succ[b_i[:, None], a_i[:, None], o_i[:, None], model.states[None, :]])
 
+    def expand_hsvi(self, model, b: Belief, value_function: ValueFunction, upper_bound_belief_value_map: BeliefValueMapping,
+                    conv_term: Union[float, None] = None, max_generation: int = 10) -> BeliefSet:
+        """HSVI descent (``src/pomdp.py:1768-1868``): from ``b`` take the action that is greedy for the upper bound,
+        then the observation with the largest probability-weighted gap between the bounds, until the gap falls under
+        ``eps / gamma^depth`` or ``max_generation`` beliefs are out.  The deepest belief comes first in the result.
+        The lower bound ``max_v alpha_v . b`` is one small matrix-vector product per observation and stays on the host."""
+        rto = model.reachable_transitional_observation_table
+        alpha = value_function.alpha_vector_array
+        conv = self.eps if conv_term is None else conv_term
+        chain = []
+        while True:
+            conv /= self.gamma
+            best_q, best_a = -np.inf, -1
+            for a in model.actions:
+                p_o = np.einsum('sor,s->o', rto[:, a, :, :], b.values)
+                tail = 0
+                for o in model.observations:
+                    tail += p_o[o] * upper_bound_belief_value_map.evaluate(b.update(a, o))
+                q = float(np.dot(model.expected_rewards_table[:, a], b.values) + self.gamma * tail)
+                if q > best_q:
+                    best_q, best_a = q, a
+            p_o = np.einsum('sor,s->o', rto[:, best_a, :, :], b.values)
+            top, gap_at_top, nxt = -np.inf, -np.inf, b
+            for o in model.observations:
+                bao = b.update(best_a, o)
+                gap = upper_bound_belief_value_map.evaluate(bao) - np.max(np.dot(alpha, bao.values))
+                if p_o[o] * gap > top:
+                    top, gap_at_top, nxt = p_o[o] * gap, gap, bao
+            chain.append(nxt)
+            if gap_at_top < conv or max_generation <= 1:
+                break
+            upper_bound_belief_value_map.add(b, best_q)
+            b = nxt
+            max_generation -= 1
+        return BeliefSet(model, chain[::-1])
+
     def _walk_device(self, model, b0: Belief, policy_action, max_generation: int) -> BeliefSet:
         """``_walk`` with the beliefs on the device.  The (action, observation) trajectory is simulated in the underlying
         MDP and does not depend on the beliefs, so it is drawn first (same random draws, same order), then the n
@@ -551,7 +676,12 @@ class PBVI_Solver(Solver):
         if f in 'expand_ger':
             return self.expand_ger(model, belief_set, params['value_function'], max_generation)
         if f in 'expand_hsvi':
-            raise NotImplementedError('HSVI expansion (BeliefValueMapping upper bound) is outside the accelerated path; see SURVEY.md 2.1 rows 10-11')
+            if not hasattr(self, '_upper_bound'):          # kept on the solver across calls, like src/pomdp.py:2112-2115
+                self._upper_bound = BeliefValueMapping(model, params['mdp_policy'])
+            else:
+                self._upper_bound.update()
+            return self.expand_hsvi(model, belief_set.belief_list[0], params['value_function'], self._upper_bound,
+                                    max_generation=max_generation)
         if f in 'expand_fsvi':
             return self.expand_fsvi(model, belief_set.belief_list[0], params['mdp_policy'], max_generation)
         if f in 'expand_fsvi_eg':
@@ -698,10 +828,20 @@ class FSVI_EG_Solver(FSVI_Solver):
 
 
 class HSVI_Solver(PBVI_Solver):
-    """HSVI preset (``src/pomdp.py:2416-2467``); its expansion is not provided here."""
+    """Heuristic Search Value Iteration preset (``src/pomdp.py:2416-2478``)."""
 
-    def __init__(self, gamma: float = 0.99, eps: float = 0.001, mdp_policy=None):
-        super().__init__(gamma, eps, 'hsvi', mdp_policy=mdp_policy)
+    def __init__(self, gamma: float = 0.99, eps: float = 0.001, mdp_solution: Union[ValueFunction, None] = None):
+        super().__init__(gamma, eps, 'hsvi', mdp_policy=mdp_solution)
+
+    def solve(self, model, expansions, max_belief_growth: int = 10, initial_belief=None, initial_value_function=None,
+              prune_level: int = 1, prune_interval: int = 10, limit_value_function_size: int = -1, use_gpu: bool = False,
+              history_tracking_level: int = 1, print_progress: bool = True, engine_dtype: str = 'f64'):
+        return super().solve(model=model, expansions=expansions, full_backup=False, update_passes=1,
+                             max_belief_growth=max_belief_growth, initial_belief=initial_belief,
+                             initial_value_function=initial_value_function, prune_level=prune_level,
+                             prune_interval=prune_interval, limit_value_function_size=limit_value_function_size,
+                             use_gpu=use_gpu, history_tracking_level=history_tracking_level,
+                             print_progress=print_progress, engine_dtype=engine_dtype)
 
 
 # --------------------------------------------------------------------------- #

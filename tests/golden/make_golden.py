@@ -439,7 +439,66 @@ def gen_e2e():
                         ref_backup_mean_s=float(np.mean(hist.backup_times)))
 
 
+# --------------------------------------------------------------------------- #
+def gen_hsvi():
+    """API rows beside the backup that the notebooks call: the reference's HSVI solve (deterministic: greedy descent
+    on the bound gap) on tiger and the 4x3 grid and on the S=600 olfactory model, the sawtooth upper bound evaluated at
+    probe beliefs, and PBVI_Solver.test_n_simulations seeded on the S=600 models."""
+    import random as pyrandom
+    out = {}
+    cases = [('tiger', os.path.join(EXAMPLES, 'tiger.95.POMDP'), 12, 8), ('grid4x3', os.path.join(EXAMPLES, '4x3.95-no_loop_2_grid.POMDP'), 10, 10)]
+    for key, path, exps, growth in cases:
+        model, pbvi = quiet(ref.load_POMDP_file, path)
+        solver = ref.HSVI_Solver(gamma=pbvi.gamma, eps=1e-6)
+        np.random.seed(0)
+        pyrandom.seed(0)
+        vf, hist = quiet(solver.solve, model, expansions=exps, max_belief_growth=growth, print_progress=False)
+        ub = solver._upper_bound
+        out[f'{key}_alpha'] = np.array(vf.alpha_vector_array)
+        out[f'{key}_actions'] = np.asarray(vf.actions, dtype=np.int16)
+        out[f'{key}_beliefs'] = np.asarray(hist.beliefs_counts, dtype=np.int32)
+        out[f'{key}_alphas'] = np.asarray(hist.alpha_vector_counts, dtype=np.int32)
+        out[f'{key}_changes'] = np.asarray(hist.value_function_changes, dtype=np.float64)
+        out[f'{key}_cfg'] = np.array([exps, growth])
+        out[f'{key}_ub_points'] = np.array([b.values for b in ub.beliefs])
+        out[f'{key}_ub_values'] = np.array(list(ub.belief_value_mapping.values()), dtype=np.float64)
+        rng = np.random.RandomState(3)
+        probes = rng.random((16, model.state_count))
+        probes /= probes.sum(axis=1)[:, None]
+        ub.update()
+        out[f'{key}_ub_probes'] = probes
+        out[f'{key}_ub_probe_values'] = np.array([ub.evaluate(ref.Belief(model, p)) for p in probes])
+        print(f'hsvi {key}: |V|={len(vf)} beliefs={hist.beliefs_counts} ub points={len(ub.beliefs)}')
+    for R in (1, 5):
+        m = synth.olfactory_model(H=15, W=40, R=R, f32=False)
+        model = ref_model_from_synth(m)
+        solver = ref.HSVI_Solver(gamma=m.gamma, eps=1e-6)
+        np.random.seed(0)
+        pyrandom.seed(0)
+        vf, hist = quiet(solver.solve, model, expansions=8, max_belief_growth=12, print_progress=False)
+        out[f'olf{R}_alpha'] = np.array(vf.alpha_vector_array)
+        out[f'olf{R}_actions'] = np.asarray(vf.actions, dtype=np.int16)
+        out[f'olf{R}_beliefs'] = np.asarray(hist.beliefs_counts, dtype=np.int32)
+        out[f'olf{R}_alphas'] = np.asarray(hist.alpha_vector_counts, dtype=np.int32)
+        out[f'olf{R}_cfg'] = np.array([8, 12])
+        print(f'hsvi olfactory R={R}: |V|={len(vf)} beliefs={hist.beliefs_counts}')
+        # test_n_simulations of the reference, seeded (R=5: short horizon, the reference's successor indexing raises
+        # once fewer than R simulations remain -- it never filters here, so any horizon works; keep it short anyway)
+        np.random.seed(21)
+        pyrandom.seed(21)
+        n, horizon = (64, 50) if R == 1 else (64, 12)
+        starts, done_at, rewards, disc = quiet(ref.PBVI_Solver(gamma=m.gamma).test_n_simulations, model, vf, n=n, horizon=horizon)
+        out[f'olf{R}_tns_cfg'] = np.array([n, horizon, 21])
+        out[f'olf{R}_tns_starts'] = np.asarray(starts, dtype=np.int32)
+        out[f'olf{R}_tns_done_at'] = np.asarray(done_at, dtype=np.int32)
+        out[f'olf{R}_tns_rewards'] = np.asarray(rewards, dtype=np.float64)
+        out[f'olf{R}_tns_discounted'] = np.asarray(disc, dtype=np.float64)
+        print(f'test_n_simulations R={R}: steps run {len(rewards)}, done {int(np.sum(np.asarray(done_at) >= 0))}/{n}')
+        out[f'olf{R}_coords'] = np.array(model.get_coords([0, 41, 599]))
+    np.savez_compressed(os.path.join(HERE, 'hsvi_and_rollouts.npz'), **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['small', 'kat', 'c2']
     for w in which:
-        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve, 'e2e': gen_e2e}[w]()
+        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve, 'e2e': gen_e2e, 'hsvi': gen_hsvi}[w]()
