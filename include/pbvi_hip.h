@@ -162,6 +162,15 @@ int64_t pbvi_backup_unique_count(const pbvi_engine_t* e);
 int pbvi_backup_fetch_unique(pbvi_engine_t* e, void* out_rows, int32_t* out_index);
 
 /*
+ * The new alpha-vectors join the value function (ValueFunction.extend, src/mdp.py:763-779; append=True in
+ * PBVI_Solver.backup, src/pomdp.py:1521-1522): append n of the last backup's distinct rows -- unique_idx[i] in
+ * [0, U), in that order -- to the engine's alpha store, device to device.  Returns the store id of the first
+ * appended row (ids are consecutive), or a negative error code.  The caller tags its AlphaVector objects with the
+ * ids, so the next pbvi_alpha_select needs no upload of rows the engine computed itself.
+ */
+int64_t pbvi_backup_store_unique(pbvi_engine_t* e, const int32_t* unique_idx, int64_t n);
+
+/*
  * Keys instead of rows (multi-GPU exchange).  The alpha' row of a belief is a function of its key
  * (a*, v*[a*, 0..O-1]) and of the replicated alpha set and model only (src/pomdp.py:1497-1506), so ranks exchange
  * keys -- (1+O) ints per distinct row -- and every rank assembles the rows it did not compute itself:

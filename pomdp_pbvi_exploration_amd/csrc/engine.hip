@@ -254,6 +254,15 @@ __global__ void k_gather_rows(const T* __restrict__ src, T* __restrict__ dst, in
     dst[(int64_t)blockIdx.y * ld + s] = src[(int64_t)perm[blockIdx.y] * ld + s];
 }
 
+// rows perm[y] of src (leading dimension ld_src) -> rows y of dst (ld_dst), first `cols` columns
+template <typename T>
+__global__ void k_gather_rows_ld(const T* __restrict__ src, int ld_src, T* __restrict__ dst, int ld_dst, int cols,
+                                 const int32_t* __restrict__ perm) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= cols) return;
+    dst[(int64_t)blockIdx.y * ld_dst + s] = src[(int64_t)perm[blockIdx.y] * ld_src + s];
+}
+
 __global__ void k_unpermute(int B, int AO, const int32_t* __restrict__ perm, const int32_t* __restrict__ action,
                             const int32_t* __restrict__ best_v, int32_t* __restrict__ action_o, int32_t* __restrict__ best_o) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -283,6 +292,7 @@ class EngineBase {
     virtual int set_formulation(int f) = 0;
     virtual int64_t device_bytes() const = 0;
     virtual int64_t store_append(int which, const void* rows, int64_t n) = 0;
+    virtual int64_t store_append_unique(const int32_t* unique_idx, int64_t n) = 0;
     virtual int store_select(int which, const int32_t* ids, int64_t n) = 0;
     virtual int store_reset(int which) = 0;
     virtual int belief_update(const int32_t* act, const int32_t* obs, void* out) = 0;
@@ -748,6 +758,28 @@ class EngineT : public EngineBase {
         }
         store_rows_[which] = have + n;
         return have;
+    }
+
+    // distinct alpha' rows of the last backup -> alpha store, device to device (ids are consecutive from the return)
+    int64_t store_append_unique(const int32_t* unique_idx, int64_t n) override {
+        if (!have_result_) FAIL(PBVI_EINVAL, "backup_store_unique: no backup result resident");
+        if (n <= 0 || n > 65535 || unique_idx == nullptr) FAIL(PBVI_EINVAL, "backup_store_unique: bad arguments (1 <= n <= 65535)");
+        for (int64_t i = 0; i < n; ++i)
+            if (unique_idx[i] < 0 || unique_idx[i] >= res_unique_) FAIL(PBVI_EINVAL, "backup_store_unique: row index out of range");
+        HIPCHK(hipSetDevice(device_));
+        T* dst = nullptr;
+        int rc = store_reserve(0, n, &dst);
+        if (rc) return rc;
+        if ((rc = ids_.ensure((size_t)n * sizeof(int32_t), &bytes_))) return rc;
+        HIPCHK(hipMemcpyAsync(ids_.p, unique_idx, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        if (S_pad_ > S_) HIPCHK(hipMemsetAsync(dst, 0, (size_t)n * S_pad_ * sizeof(T), stream_));   // pad columns stay zero
+        hipLaunchKernelGGL(k_gather_rows_ld<T>, dim3((S_ + 255) / 256, (unsigned)n), dim3(256), 0, stream_, out_.as<T>(), S_,
+                           dst, S_pad_, S_, ids_.as<int32_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream_));            // unique_idx is the caller's host memory
+        const int64_t first = store_rows_[0];
+        store_rows_[0] = first + n;
+        return first;
     }
 
     // make room for n more rows in a store, keeping what is there; returns the destination of the new rows
@@ -1804,6 +1836,11 @@ int pbvi_backup_fetch(pbvi_engine_t* e, void* out_alpha, int32_t* out_action, in
     NEED(e);
     return e->impl->backup_fetch(out_alpha, out_action, out_best_alpha, out_keep);
 }
+int64_t pbvi_backup_store_unique(pbvi_engine_t* e, const int32_t* unique_idx, int64_t n) {
+    NEED(e);
+    return e->impl->store_append_unique(unique_idx, n);
+}
+
 int pbvi_backup_fetch_unique_keys(pbvi_engine_t* e, int32_t* out_keys) {
     NEED(e);
     return e->impl->fetch_unique_keys(out_keys);

@@ -29,7 +29,7 @@ EXPORTS = [
     'pbvi_belief_store_append', 'pbvi_beliefs_select', 'pbvi_belief_store_reset', 'pbvi_debug_poison',
     'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
     'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk', 'pbvi_engine_set_rto_f64', 'pbvi_backup_fetch_unique_keys', 'pbvi_assemble_rows',
-    'pbvi_backup_fetch_exchange',
+    'pbvi_backup_fetch_exchange', 'pbvi_backup_store_unique',
 ]
 
 
@@ -82,6 +82,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_backup_fetch': (C.c_int, [vp, vp, i32p, i32p, u8p]),
         'pbvi_backup_unique_count': (C.c_int64, [vp]),
         'pbvi_backup_fetch_unique': (C.c_int, [vp, vp, i32p]),
+        'pbvi_backup_store_unique': (C.c_int64, [vp, i32p, C.c_int64]),
         'pbvi_backup_device_results': (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         'pbvi_backup': (C.c_int, [vp, vp, C.c_int64, C.c_double, C.c_int, vp, i32p, i32p, u8p, sp]),
         'pbvi_prune_dominated': (C.c_int, [vp, u8p]),
@@ -210,15 +211,18 @@ class BackupResult:
         """Per-belief alpha' matrix [B,S] (what the reference computes before its dedup)."""
         return self.unique_alpha[self.index]
 
-    def value_function_rows(self, use_keep: bool = False):
+    def value_function_rows(self, use_keep: bool = False, with_index: bool = False):
         """``(rows, actions)`` to hand to ``ValueFunction``: one row per distinct key among the (kept)
-        beliefs, in order of first occurrence -- the order the reference's byte-dedup produces."""
+        beliefs, in order of first occurrence -- the order the reference's byte-dedup produces.
+        ``with_index``: also the positions of those rows in ``unique_alpha`` (for ``Engine.store_unique``)."""
         idx = self.index[self.keep] if use_keep else self.index
         act = self.actions[self.keep] if use_keep else self.actions
         if idx.size == 0:
-            return self.unique_alpha[:0], act[:0]
+            return (self.unique_alpha[:0], act[:0], idx[:0]) if with_index else (self.unique_alpha[:0], act[:0])
         first = np.unique(idx, return_index=True)[1]
         first.sort()
+        if with_index:
+            return self.unique_alpha[idx[first]], act[first], idx[first]
         return self.unique_alpha[idx[first]], act[first]
 
 
@@ -313,6 +317,19 @@ class Engine:
         if first < 0:
             _check(first)
         return first
+
+    def store_unique(self, unique_idx) -> int:
+        """Append rows ``unique_idx`` of the last backup's distinct alpha' rows to the alpha store, device to device
+        (``pbvi_backup_store_unique``); returns the store id of the first one."""
+        i = np.ascontiguousarray(unique_idx, dtype=np.int32)
+        first = int(self._lib.pbvi_backup_store_unique(self._h, i.ctypes.data_as(C.POINTER(C.c_int32)), i.shape[0]))
+        if first < 0:
+            _check(first)
+        return first
+
+    def store_tag(self, which: str):
+        """What ``row_ids`` expects in ``obj._dev[0]`` for a row of this engine's store."""
+        return (id(self), which, self._store_epoch[which])
 
     def select_alpha(self, ids) -> None:
         i = np.ascontiguousarray(ids, dtype=np.int32)

@@ -385,9 +385,21 @@ class ValueFunction:
         self._actions = None
 
     def extend(self, other: 'ValueFunction') -> None:
-        self._uniqueness_dict.update(other._uniqueness_dict)
-        self._vector_list = list(self._uniqueness_dict.values())
-        self._dev_ids = None
+        mine, theirs = self._uniqueness_dict, other._uniqueness_dict
+        # device store ids of the result (Engine.row_ids caches them per container): this set's rows keep their
+        # slots -- an object replaced on equal bytes names an equal row -- then the other's rows that are new
+        carried = None
+        a, b = getattr(self, '_dev_ids', None), getattr(other, '_dev_ids', None)
+        if a is None and len(mine) and all(hasattr(v, '_dev') for v in mine.values()):
+            tag = next(iter(mine.values()))._dev[0]
+            if all(v._dev[0] == tag for v in mine.values()):
+                a = (tag, np.fromiter((v._dev[1] for v in mine.values()), dtype=np.int32, count=len(mine)))
+        if a is not None and b is not None and a[0] == b[0] and len(a[1]) == len(mine) and len(b[1]) == len(theirs):
+            fresh = np.fromiter((k not in mine for k in theirs), dtype=bool, count=len(theirs))
+            carried = (a[0], np.concatenate([a[1], b[1][fresh]]))
+        mine.update(theirs)
+        self._vector_list = list(mine.values())
+        self._dev_ids = carried
         self._vector_array = None
         self._actions = None
         self._pruning_level = 1

@@ -221,7 +221,6 @@ class BeliefSet:
         mine = self._unique_by_key                           # same dedup as the bytes-keyed dictionaries, cheaper keys
         theirs = other._unique_by_key
         added = [b for k, b in theirs.items() if k not in mine]
-        replaced = len(added) != len(theirs)
         merged = dict(mine)
         merged.update(theirs)
         out = BeliefSet.__new__(BeliefSet)
@@ -232,7 +231,8 @@ class BeliefSet:
         out.is_on_gpu = self.is_on_gpu
         out._belief_list = list(merged.values())
         ids = getattr(self, '_dev_ids', None)
-        if ids is not None and not replaced and len(ids[1]) == len(mine) and len(self._belief_list) == len(mine):
+        if ids is not None and len(ids[1]) == len(mine) and len(self._belief_list) == len(mine):
+            # a slot the other set's object took over keeps its id: equal bytes, so it names an equal row
             tag = ids[0]
             if all(getattr(b, '_dev', (None,))[0] == tag for b in added):
                 out._dev_ids = (tag, np.concatenate([ids[1], np.fromiter((b._dev[1] for b in added), dtype=np.int32,
@@ -445,7 +445,16 @@ class PBVI_Solver(Solver):
             if len(beliefs) <= self.BELIEF_BLOCK:
                 eng.sync_rows('belief', beliefs, lambda b: b.values, owner=belief_set)
                 eng.run(self.gamma, belief_dominance_prune)
-                alpha_new, actions = eng.fetch().value_function_rows(use_keep=belief_dominance_prune)
+                alpha_new, actions, uidx = eng.fetch().value_function_rows(use_keep=belief_dominance_prune, with_index=True)
+                if len(uidx):
+                    # the new rows join the engine's alpha store device to device: the next call selects them by id
+                    first, tag = eng.store_unique(uidx), eng.store_tag('alpha')
+                    vectors = []
+                    for k, (row, act) in enumerate(zip(alpha_new, actions)):
+                        v = AlphaVector(row, act)
+                        v._dev = (tag, first + k)
+                        vectors.append(v)
+                    alpha_new = vectors
             else:   # beliefs are independent: larger sets go through the engine in blocks (it takes 65535 at a time)
                 parts = []
                 for i0 in range(0, len(beliefs), self.BELIEF_BLOCK):
@@ -454,7 +463,8 @@ class PBVI_Solver(Solver):
                     parts.append(eng.fetch().value_function_rows(use_keep=belief_dominance_prune))
                 alpha_new = np.concatenate([p[0] for p in parts])
                 actions = np.concatenate([p[1] for p in parts])
-            new_vf = ValueFunction(value_function.model, alpha_new, actions)
+            new_vf = (ValueFunction(value_function.model, alpha_new) if isinstance(alpha_new, list)
+                      else ValueFunction(value_function.model, alpha_new, actions))
         else:
             alpha_new, actions = self._backup_numpy(model, belief_set.belief_array, value_function.alpha_vector_array,
                                                     belief_dominance_prune)
