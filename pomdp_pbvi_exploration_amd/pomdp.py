@@ -708,10 +708,12 @@ class PBVI_Solver(Solver):
             # (belief, alpha) pairs and keeps the rest (Engine.max_value_objects)
             eng = value_function.model.engine
             beliefs = belief_set.belief_list
-            old = eng.max_value_objects(value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda x: x.values,
-                                        alpha_owner=value_function, belief_owner=belief_set)
-            new = eng.max_value_objects(new_value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda x: x.values,
-                                        alpha_owner=new_value_function, belief_owner=belief_set)
+            # smaller alpha set first: in the solve loop it is the previous value function, a subset of the other one,
+            # so the larger set then only needs (all beliefs x its additional rows)
+            pair = sorted((value_function, new_value_function), key=len)
+            vals = {id(vf): eng.max_value_objects(vf.alpha_vector_list, beliefs, lambda v: v.values, lambda x: x.values,
+                                                  alpha_owner=vf, belief_owner=belief_set) for vf in pair}
+            old, new = vals[id(value_function)], vals[id(new_value_function)]
         else:
             b = belief_set.belief_array
             old = np.max(np.matmul(b, value_function.alpha_vector_array.T), axis=1)
