@@ -54,8 +54,8 @@ def cpu_baseline(m, alpha, beliefs, sample: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--beliefs', type=int, default=1024, help='beliefs per GPU')
     ap.add_argument('--alphas', type=int, default=1024)
     ap.add_argument('--reach', type=int, default=1, choices=[1, 5], help='reachable states per (s,a)')
