@@ -213,6 +213,17 @@ int pbvi_prune_dominated(pbvi_engine_t* e, uint8_t* keep /* [V] */);
 int pbvi_value_max(pbvi_engine_t* e, double* out_value, int32_t* out_index);
 
 /*
+ * The same maxima for rows [0, n) of the BELIEF STORE (pbvi_belief_store_append / pbvi_belief_walk order) against the
+ * working alpha set, with the store itself as the GEMM operand: nothing is gathered or sorted and the zero maps and
+ * tile lists of rows scored before are kept.  compute_change (src/pomdp.py:2141-2169) scores the whole accumulated
+ * belief set after every backup; that set only grows.  out_value / out_index: [n] (either may be NULL), store order.
+ */
+int pbvi_value_max_store(pbvi_engine_t* e, int64_t n, double* out_value, int32_t* out_index);
+/* rows currently held by the stores (ids are 0 .. count-1) */
+int64_t pbvi_belief_store_count(const pbvi_engine_t* e);
+int64_t pbvi_alpha_store_count(const pbvi_engine_t* e);
+
+/*
  * Batched belief update (Bayes step) of the resident belief block: the step that produces the beliefs the
  * backup consumes.  Replaces Belief.update (src/pomdp.py:382-421) applied to B beliefs at once (the
  * reference's own batched form lives in its simulator, src/pomdp.py:3277-3310):

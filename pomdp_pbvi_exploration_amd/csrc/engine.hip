@@ -288,6 +288,8 @@ class EngineBase {
     virtual int assemble_keys(double gamma, int64_t n, const int32_t* keys, void* out_rows) = 0;
     virtual int prune_dominated(uint8_t* keep) = 0;
     virtual int value_max(double* out_value, int32_t* out_index) = 0;
+    virtual int value_max_store(int64_t n, double* out_value, int32_t* out_index) = 0;
+    virtual int64_t store_count(int which) const = 0;
     virtual int set_tie_window(double rel) = 0;
     virtual int set_formulation(int f) = 0;
     virtual int64_t device_bytes() const = 0;
@@ -331,6 +333,10 @@ class EngineT : public EngineBase {
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     DevBuf bp_, nzP_, pmag_, prd_;                          // belief-side formulation: projected beliefs, tile map, magnitudes, b.ER
     bool btl_valid_ = false;                                // btl_/btc_ describe the resident belief block
+    // belief store as a GEMM operand in place (value_max_store): zero maps and tile lists kept per store row, extended
+    // as rows are appended
+    DevBuf snz_, sbtl_, sbtc_;
+    int64_t snz_rows_ = 0, sbt_rows_ = 0;
     void* host_stage_ = nullptr;                            // pinned bounce buffer for rows going to pageable host memory
     size_t host_stage_cap_ = 0;
     DevBuf keys_tmp_, keys_act_, keys_best_, keys_rows_;    // unique-row keys out / rows from keys in (multi-GPU exchange)
@@ -362,7 +368,7 @@ class EngineT : public EngineBase {
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
-                         &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
+                         &snz_, &sbtl_, &sbtc_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (DevBuf* b : all) b->release();
         if (host_stage_) (void)hipHostFree(host_stage_);
@@ -855,6 +861,7 @@ class EngineT : public EngineBase {
     int store_reset(int which) override {
         if (which < 0 || which > 1) FAIL(PBVI_EINVAL, "store_reset: bad store");
         store_rows_[which] = 0;
+        if (which == 1) snz_rows_ = sbt_rows_ = 0;
         return PBVI_OK;
     }
 
@@ -1126,6 +1133,101 @@ class EngineT : public EngineBase {
                 if (out_index) out_index[h_perm_[(size_t)i]] = ti[(size_t)i];
             }
         return PBVI_OK;
+    }
+
+    int64_t store_count(int which) const override { return (which == 0 || which == 1) ? store_rows_[which] : -1; }
+
+    // grow a buffer to `need` bytes keeping its first `used` bytes
+    int grow_keep(DevBuf& b, size_t need, size_t used) {
+        if (need <= b.cap) return PBVI_OK;
+        DevBuf nb;
+        int rc = nb.ensure(std::max(need, b.cap * 2), &bytes_);
+        if (rc) return rc;
+        if (used > 0) HIPCHK(hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        bytes_ -= (int64_t)b.cap;
+        b.release();
+        b = nb;
+        return PBVI_OK;
+    }
+
+    // max_v b.alpha_v (exact, like value_max) for rows [0, n) of the BELIEF STORE against the working alpha set, with the
+    // store itself as the GEMM operand: no gather, no sort, and the zero maps / tile lists of rows seen before are reused.
+    // compute_change (src/pomdp.py:2141-2169) scores the whole accumulated belief set after every backup; that set only
+    // grows, and its rows already sit in the store in arrival order (a walk's successive beliefs overlap heavily, so
+    // 256-row blocks of the store have tight joint support without sorting).
+    int value_max_store(int64_t n, double* out_value, int32_t* out_index) override {
+        if (V_ <= 0) FAIL(PBVI_EINVAL, "value_max_store: no alpha set resident");
+        if (n <= 0 || n > store_rows_[1] || (!out_value && !out_index)) FAIL(PBVI_EINVAL, "value_max_store: bad arguments");
+        HIPCHK(hipSetDevice(device_));
+        int rc;
+        const int k_tiles = S_pad_ / GEMM_BK;
+        const int64_t have = store_rows_[1], have_pad = round_up(have, GEMM_BM);
+        // rows [have, have_pad) are read by the last row block: make them exist and be zero
+        if ((size_t)have_pad * S_pad_ * sizeof(T) > store_[1].cap) {
+            T* unused = nullptr;
+            if ((rc = store_reserve(1, have_pad - have, &unused))) return rc;
+        }
+        T* base = store_[1].as<T>();
+        if (have_pad > have)
+            HIPCHK(hipMemsetAsync(base + (size_t)have * S_pad_, 0, (size_t)(have_pad - have) * S_pad_ * sizeof(T), stream_));
+        // zero maps: complete blocks computed earlier stay; the block that was partial then and everything after is (re)done
+        if ((rc = grow_keep(snz_, (size_t)(have_pad / GEMM_BM) * k_tiles, (size_t)(snz_rows_ / GEMM_BM) * k_tiles))) return rc;
+        {
+            const int64_t r0 = snz_rows_ / GEMM_BM * GEMM_BM;
+            if (have_pad > r0) {
+                uint8_t* nz = snz_.as<uint8_t>() + (size_t)(r0 / GEMM_BM) * k_tiles;
+                if constexpr (kF32)
+                    HIPCHK(launch_tile_nonzero_f32((const float*)(base + (size_t)r0 * S_pad_), S_pad_, (int)(have_pad - r0), k_tiles, nz, stream_));
+                else
+                    HIPCHK(launch_tile_nonzero_f64((const double*)(base + (size_t)r0 * S_pad_), S_pad_, (int)(have_pad - r0), k_tiles, nz, stream_));
+            }
+            snz_rows_ = have;
+        }
+        if (kF32) {   // per-row tile lists for the f64 refinement
+            if ((rc = grow_keep(sbtl_, (size_t)have * k_tiles * sizeof(int32_t), (size_t)sbt_rows_ * k_tiles * sizeof(int32_t)))) return rc;
+            if ((rc = grow_keep(sbtc_, (size_t)have * sizeof(int32_t), (size_t)sbt_rows_ * sizeof(int32_t)))) return rc;
+            for (int64_t r0 = sbt_rows_; r0 < have; r0 += 32768) {
+                const int cnt = (int)std::min<int64_t>(32768, have - r0);
+                HIPCHK(launch_belief_tiles<T>(base + (size_t)r0 * S_pad_, S_pad_, cnt, S_, k_tiles,
+                                              sbtl_.as<int32_t>() + (size_t)r0 * k_tiles, sbtc_.as<int32_t>() + r0, stream_));
+            }
+            sbt_rows_ = have;
+        }
+        // run value_max_device on windows of the store: the block members point into the store for the duration
+        struct Saved {
+            DevBuf bel, nzA, btl, btc;
+            int64_t B, B_pad;
+            bool sorted, btl_valid, have_result;
+        } sv{bel_, nzA_, btl_, btc_, B_, B_pad_, sorted_, btl_valid_, have_result_};
+        auto restore = [&]() {
+            bel_ = sv.bel; nzA_ = sv.nzA; btl_ = sv.btl; btc_ = sv.btc;
+            B_ = sv.B; B_pad_ = sv.B_pad; sorted_ = sv.sorted; btl_valid_ = sv.btl_valid; have_result_ = sv.have_result;
+        };
+        const size_t huge = ~(size_t)0 >> 1;              // aliased buffers must never look too small to ensure()
+        const int64_t window = 32768;
+        rc = PBVI_OK;
+        for (int64_t r0 = 0; r0 < n && rc == PBVI_OK; r0 += window) {
+            const int64_t cnt = std::min<int64_t>(window, n - r0);
+            bel_.p = base + (size_t)r0 * S_pad_;                       bel_.cap = huge;
+            nzA_.p = snz_.as<uint8_t>() + (size_t)(r0 / GEMM_BM) * k_tiles;   nzA_.cap = huge;
+            if (kF32) {
+                btl_.p = sbtl_.as<int32_t>() + (size_t)r0 * k_tiles;   btl_.cap = huge;
+                btc_.p = sbtc_.as<int32_t>() + r0;                     btc_.cap = huge;
+            }
+            B_ = cnt;
+            B_pad_ = round_up(cnt, GEMM_BM);
+            sorted_ = false;
+            btl_valid_ = kF32;
+            rc = value_max_device();
+            if (rc == PBVI_OK) rc = out_begin();
+            if (rc == PBVI_OK && out_value) rc = out_add(out_value + r0, bs2_.p, (size_t)cnt * sizeof(double));
+            if (rc == PBVI_OK && out_index) rc = out_add(out_index + r0, bv2_.p, (size_t)cnt * sizeof(int32_t));
+            if (rc == PBVI_OK) rc = out_finish();
+        }
+        if (rc != PBVI_OK) (void)hipStreamSynchronize(stream_);
+        restore();
+        return rc;
     }
 
     // Work list of the f64 refinement (see RefineWork): room for every candidate of up to 16M (entry, alpha) pairs
@@ -1883,6 +1985,12 @@ int64_t pbvi_alpha_store_append(pbvi_engine_t* e, const void* rows, int64_t n) {
     NEED(e);
     return e->impl->store_append(0, rows, n);
 }
+int pbvi_value_max_store(pbvi_engine_t* e, int64_t n, double* out_value, int32_t* out_index) {
+    NEED(e);
+    return e->impl->value_max_store(n, out_value, out_index);
+}
+int64_t pbvi_belief_store_count(const pbvi_engine_t* e) { return (e && e->impl) ? e->impl->store_count(1) : -1; }
+int64_t pbvi_alpha_store_count(const pbvi_engine_t* e) { return (e && e->impl) ? e->impl->store_count(0) : -1; }
 int pbvi_alpha_select(pbvi_engine_t* e, const int32_t* ids, int64_t V) {
     NEED(e);
     return e->impl->store_select(0, ids, V);

@@ -30,6 +30,7 @@ EXPORTS = [
     'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
     'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk', 'pbvi_engine_set_rto_f64', 'pbvi_backup_fetch_unique_keys', 'pbvi_assemble_rows',
     'pbvi_backup_fetch_exchange', 'pbvi_backup_store_unique',
+    'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count',
 ]
 
 
@@ -87,6 +88,9 @@ def load_library(path: str = LIB_PATH):
         'pbvi_backup': (C.c_int, [vp, vp, C.c_int64, C.c_double, C.c_int, vp, i32p, i32p, u8p, sp]),
         'pbvi_prune_dominated': (C.c_int, [vp, u8p]),
         'pbvi_value_max': (C.c_int, [vp, f64p, i32p]),
+        'pbvi_value_max_store': (C.c_int, [vp, C.c_int64, f64p, i32p]),
+        'pbvi_belief_store_count': (C.c_int64, [vp]),
+        'pbvi_alpha_store_count': (C.c_int64, [vp]),
         'pbvi_alpha_store_append': (C.c_int64, [vp, vp, C.c_int64]),
         'pbvi_alpha_select': (C.c_int, [vp, i32p, C.c_int64]),
         'pbvi_alpha_store_reset': (C.c_int, [vp]),
@@ -401,9 +405,26 @@ class Engine:
     _VMAX_ENTRIES = 3
     _BLOCK = 32768          # beliefs per resident block (the engine takes at most 65535)
 
+    def max_value_store(self, n: int = -1):
+        """``(max_v b.alpha_v, argmax)`` for belief-store rows ``[0, n)`` (all rows by default) against the working
+        alpha set, computed on the store in place (``pbvi_value_max_store``)."""
+        if n < 0:
+            n = int(self._lib.pbvi_belief_store_count(self._h))
+        val = np.empty(n, dtype=np.float64)
+        idx = np.empty(n, dtype=np.int32)
+        _check(self._lib.pbvi_value_max_store(self._h, n, val.ctypes.data_as(C.POINTER(C.c_double)),
+                                              idx.ctypes.data_as(C.POINTER(C.c_int32))))
+        return val, idx
+
+    _STORE_SCAN_MIN = 2048      # beliefs from which scoring the store in place beats gathering a block
+
     def _vmax_block(self, a_ids: np.ndarray, b_ids: np.ndarray) -> np.ndarray:
         out = np.empty(len(b_ids), dtype=np.float64)
         self.select_alpha(a_ids)
+        if len(b_ids) >= self._STORE_SCAN_MIN:
+            top = int(b_ids.max()) + 1
+            if 2 * len(b_ids) >= top:          # most of the store's prefix is wanted: score it whole, pick by id
+                return self.max_value_store(top)[0][b_ids]
         for i0 in range(0, len(b_ids), self._BLOCK):
             self.select_beliefs(b_ids[i0:i0 + self._BLOCK])
             out[i0:i0 + self._BLOCK] = self.max_value_resident()[0]

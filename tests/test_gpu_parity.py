@@ -353,6 +353,50 @@ def test_row_stores_select_in_host_order():
     eng.close()
 
 
+def test_value_max_over_the_belief_store_in_place(monkeypatch):
+    """pbvi_value_max_store: compute_change's maxima with the belief store itself as the GEMM operand -- no gather, no
+    sort, zero maps and tile lists extended as rows arrive.  Equal to the gathered-block path and to the oracle, across
+    appends that leave partial 256-row blocks, for f32 (exact re-scoring) and f64 engines."""
+    m = synth.olfactory_model(H=15, W=40, R=5)
+    alpha, _ = synth.alpha_set(m, 40)
+    alpha[7] = alpha[3]                                           # an exact tie: the lower index must win
+    beliefs = synth.belief_points(m, 700, max_depth=24)
+    want = orc.max_value_per_belief(alpha.astype(np.float64), beliefs.astype(np.float64))
+    for dtype in ('f32', 'f64'):
+        eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype)
+        eng.store_rows('alpha', alpha)
+        eng.select_alpha(np.arange(len(alpha)))
+        done = 0
+        for upto in (100, 256, 300, 700):                         # partial block, exact block, straddling, several blocks
+            eng.store_rows('belief', beliefs[done:upto])
+            done = upto
+            val, idx = eng.max_value_store()
+            assert len(val) == upto
+            eng.select_beliefs(np.arange(upto))
+            v2, i2 = eng.max_value_resident()
+            assert np.array_equal(val, v2) and np.array_equal(idx, i2)
+            np.testing.assert_allclose(val, want[:upto], rtol=1e-12 if dtype == 'f64' else 1e-7)
+            assert not np.any(idx == 7)
+        v_part, _ = eng.max_value_store(513)
+        assert np.array_equal(v_part, val[:513])
+        # the resident block survives the store scan untouched
+        v3, i3 = eng.max_value_resident()
+        assert np.array_equal(v3, v2) and np.array_equal(i3, i2)
+        # Engine.max_value_objects takes the store path for large belief sets
+        monkeypatch.setattr(Engine, '_STORE_SCAN_MIN', 64)
+        ids = np.arange(700, dtype=np.int32)[::2]
+        got = eng._vmax_block(np.arange(len(alpha), dtype=np.int32), ids)
+        assert np.array_equal(got, val[ids])
+        monkeypatch.undo()
+        eng.reset_store('belief')
+        eng.store_rows('belief', beliefs[5:9])
+        v4, _ = eng.max_value_store()
+        assert np.array_equal(v4, val[5:9])
+        with pytest.raises(ValueError):
+            eng.max_value_store(5)
+        eng.close()
+
+
 def test_solver_loop_on_gpu_keeps_rows_resident():
     """FSVI on the 4x3 grid through the Python API with use_gpu=True: every backup goes through the row
     stores; the trajectory equals the host NumPy path's (same seeds)."""
