@@ -23,6 +23,18 @@ struct ModelView {
 // Score matrix as written by the GEMM: split-K partial slabs.  f32 engines: nchunks[pair] slabs
 // exist for tile pair (col>>8, row>>8) (zero-tile skipping makes the count per pair vary); f64
 // engines: one dense slab (nchunks == nullptr, fixed = 1).
+// Row of (observation o, action a, belief b) in the belief-side operand.  Observation-major, then belief, then action:
+// the rows of one observation share tiles (a rarely-seen observation's near-empty tiles are skipped) and a 256-row
+// tile holds all actions of ~256/A consecutive beliefs -- neighbours in a walk, whose supports overlap -- rather than
+// a few actions of every belief of the block.
+__host__ __device__ __forceinline__ int64_t push_row_index(int o, int a, int b, int A, int B) {
+#ifdef PBVI_PUSH_ORDER_OAB
+    return ((int64_t)o * A + a) * B + b;
+#else
+    return ((int64_t)o * B + b) * A + a;
+#endif
+}
+
 template <typename T>
 struct SlabView {
     const T* slabs;
@@ -47,7 +59,7 @@ struct SlabView {
         return s;
     }
     __device__ __forceinline__ int64_t push_row(int b, int g) const {      // g = a * O + o
-        return ((int64_t)(g % push_O) * push_A + g / push_O) * push_B + b;
+        return push_row_index(g % push_O, g / push_O, b, push_A, push_B);
     }
     // score of (belief b, group g, alpha v); V = columns per group in the alpha-side layout
     __device__ __forceinline__ T score(int b, int g, int V, int v) const {

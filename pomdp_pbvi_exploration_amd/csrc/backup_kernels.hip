@@ -1321,7 +1321,7 @@ __global__ void k_push_project(const T* __restrict__ bel, int ldb, int B, ModelV
         for (int q = 0; q < 4; ++q) {
             if (q >= no) break;                             // uniform across the block
             const T val = (T)(gamma * acc[q]);
-            const int64_t row = ((int64_t)(o0 + q) * mv.A + a) * B + b;     // observation-major (see SlabView)
+            const int64_t row = push_row_index(o0 + q, a, b, mv.A, B);           // see SlabView
             if (sp < ldp) bp[row * ldp + sp] = val;                         // pad columns get exact zeros
             mg[q] = fabs((double)val) * am;
         }
