@@ -105,11 +105,9 @@ def gather_unique(dist, group, rows, count: int, index, actions, keep, n_total: 
         send[:count] = rows[:count]
     all_rows = torch.empty((world * umax, S), dtype=rows.dtype, device=dev)
     dist.all_gather_into_tensor(all_rows, send, group=group)
-    offs = [0]
-    for c in counts_h[:-1]:
-        offs.append(offs[-1] + c)
     uniq = torch.cat([all_rows[r * umax: r * umax + counts_h[r]] for r in range(world)], dim=0)
-    gidx = all_meta[:, 1:1 + per].to(torch.int64) + torch.tensor(offs, dtype=torch.int64, device=dev)[:, None]
+    counts_d = all_meta[:, 0].to(torch.int64)                  # offsets on the device: no host-to-device copy in the step
+    gidx = all_meta[:, 1:1 + per].to(torch.int64) + (torch.cumsum(counts_d, 0) - counts_d)[:, None]
     all_act = all_meta[:, 1 + per:1 + 2 * per].reshape(-1).to(actions.dtype)
     all_keep = all_meta[:, 1 + 2 * per:].reshape(-1).to(keep.dtype)
     return uniq, gidx.reshape(-1)[:n_total], all_act[:n_total], all_keep[:n_total]
@@ -145,10 +143,8 @@ def gather_packed(dist, group, meta, per: int, key_width: int, n_total: int, ass
     k0 = 1 + 3 * per
     all_keys = torch.cat([all_meta[r, k0:k0 + counts_h[r] * key_width].view(counts_h[r], key_width) for r in range(world)], dim=0)
     uniq = assemble(all_keys.contiguous())
-    offs = [0]
-    for c in counts_h[:-1]:
-        offs.append(offs[-1] + c)
-    gidx = all_meta[:, 1:1 + per].to(torch.int64) + torch.tensor(offs, dtype=torch.int64, device=dev)[:, None]
+    counts_d = all_meta[:, 0].to(torch.int64)                  # offsets on the device: no host-to-device copy in the step
+    gidx = all_meta[:, 1:1 + per].to(torch.int64) + (torch.cumsum(counts_d, 0) - counts_d)[:, None]
     all_act = all_meta[:, 1 + per:1 + 2 * per].reshape(-1)
     all_keep = all_meta[:, 1 + 2 * per:1 + 3 * per].reshape(-1).to(torch.uint8)
     return uniq, gidx.reshape(-1)[:n_total], all_act[:n_total], all_keep[:n_total]
