@@ -224,6 +224,15 @@ int64_t pbvi_belief_store_count(const pbvi_engine_t* e);
 int64_t pbvi_alpha_store_count(const pbvi_engine_t* e);
 
 /*
+ * f32 engines re-score the candidates of every belief in fp64, so pbvi_value_max / pbvi_value_max_store return exact
+ * maxima and first-maximum indices (np.argmax semantics).  compute_change only takes max|new - old| of the values and
+ * compares it with eps * gamma / (1 - gamma) (src/pomdp.py:2167-2169, :2372): exact = 0 skips the re-scoring and
+ * returns the fp32 GEMM's maxima (relative error ~1e-7, within the 1e-6 bar of fp32 engines); indices are then the
+ * fp32 argmax.  Default 1.  No effect on f64 engines.
+ */
+int pbvi_set_value_max_exact(pbvi_engine_t* e, int exact);
+
+/*
  * Batched belief update (Bayes step) of the resident belief block: the step that produces the beliefs the
  * backup consumes.  Replaces Belief.update (src/pomdp.py:382-421) applied to B beliefs at once (the
  * reference's own batched form lives in its simulator, src/pomdp.py:3277-3310):

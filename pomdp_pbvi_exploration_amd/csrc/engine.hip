@@ -291,6 +291,7 @@ class EngineBase {
     virtual int value_max_store(int64_t n, double* out_value, int32_t* out_index) = 0;
     virtual int64_t store_count(int which) const = 0;
     virtual int set_tie_window(double rel) = 0;
+    virtual int set_value_max_exact(int exact) = 0;
     virtual int set_formulation(int f) = 0;
     virtual int64_t device_bytes() const = 0;
     virtual int64_t store_append(int which, const void* rows, int64_t n) = 0;
@@ -333,6 +334,7 @@ class EngineT : public EngineBase {
     DevBuf btl_, btc_, val_exact_;                         // per-belief non-zero tile lists; exact action values
     DevBuf bp_, nzP_, pmag_, prd_;                          // belief-side formulation: projected beliefs, tile map, magnitudes, b.ER
     bool btl_valid_ = false;                                // btl_/btc_ describe the resident belief block
+    bool vmax_exact_ = true;                                // f32 engines: re-score value_max's maxima in fp64
     // belief store as a GEMM operand in place (value_max_store): zero maps and tile lists kept per store row, extended
     // as rows are appended
     DevBuf snz_, sbtl_, sbtc_;
@@ -1320,6 +1322,14 @@ class EngineT : public EngineBase {
         formulation_ = f;
         return PBVI_OK;
     }
+    // f32 engines: value_max / value_max_store return the fp32 GEMM's maxima as they are (relative error of the order
+    // of 1e-7, bounded by the tie window) instead of re-scoring every belief's candidates in fp64.  For callers that
+    // only compare values against a tolerance (compute_change); argmax users keep the default.
+    int set_value_max_exact(int exact) override {
+        vmax_exact_ = exact != 0;
+        return PBVI_OK;
+    }
+
     int set_tie_window(double rel) override {
         tie_rel_user_ = rel;
         return PBVI_OK;
@@ -1438,9 +1448,10 @@ int EngineT<T>::value_max_device() {
     const int k_chunk = kF32 ? plan_.chunk_len * GEMM_BK : S_pad_;
     // every belief is re-scored exactly in f32 engines (flag_all): the comparison that
     // follows (new value > old best value) is strict and must not see GEMM rounding
+    const bool rescore = kF32 && vmax_exact_;
     HIPCHK(launch_argmax<T>(sv, (int)V_, 1, (int)B_, nullptr, tie_window(k_chunk), 0.0, chain_steps(), 1, bv2_.as<int32_t>(),
-                            bs2_.as<double>(), err2_.as<double>(), kF32 ? queue2_.as<int32_t>() : nullptr, qc, stream_));
-    if (kF32) {
+                            bs2_.as<double>(), err2_.as<double>(), rescore ? queue2_.as<int32_t>() : nullptr, qc, stream_));
+    if (rescore) {
         if (!btl_valid_) {   // tile lists of the resident block (the backup's k_dead builds them too)
             const int k_tiles = S_pad_ / GEMM_BK;
             if ((rc = btl_.ensure((size_t)B_ * k_tiles * sizeof(int32_t), &bytes_))) return rc;
@@ -2061,6 +2072,10 @@ int pbvi_belief_update(pbvi_engine_t* e, const int32_t* actions, const int32_t* 
 int pbvi_set_formulation(pbvi_engine_t* e, int formulation) {
     NEED(e);
     return e->impl->set_formulation(formulation);
+}
+int pbvi_set_value_max_exact(pbvi_engine_t* e, int exact) {
+    NEED(e);
+    return e->impl->set_value_max_exact(exact);
 }
 int pbvi_set_tie_window(pbvi_engine_t* e, double rel) {
     NEED(e);

@@ -30,7 +30,7 @@ EXPORTS = [
     'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
     'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk', 'pbvi_engine_set_rto_f64', 'pbvi_backup_fetch_unique_keys', 'pbvi_assemble_rows',
     'pbvi_backup_fetch_exchange', 'pbvi_backup_store_unique',
-    'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count',
+    'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact',
 ]
 
 
@@ -90,6 +90,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_value_max': (C.c_int, [vp, f64p, i32p]),
         'pbvi_value_max_store': (C.c_int, [vp, C.c_int64, f64p, i32p]),
         'pbvi_belief_store_count': (C.c_int64, [vp]),
+        'pbvi_set_value_max_exact': (C.c_int, [vp, C.c_int]),
         'pbvi_alpha_store_count': (C.c_int64, [vp]),
         'pbvi_alpha_store_append': (C.c_int64, [vp, vp, C.c_int64]),
         'pbvi_alpha_select': (C.c_int, [vp, i32p, C.c_int64]),
@@ -430,25 +431,43 @@ class Engine:
             out[i0:i0 + self._BLOCK] = self.max_value_resident()[0]
         return out
 
+    def set_value_max_exact(self, exact: bool) -> None:
+        """f32 engines: fp64 re-scoring of ``max_value_*`` results on (default) or off (``pbvi_set_value_max_exact``)."""
+        _check(self._lib.pbvi_set_value_max_exact(self._h, 1 if exact else 0))
+
     def max_value_objects(self, alpha_objects, belief_objects, alpha_values, belief_values, alpha_owner=None,
-                          belief_owner=None) -> np.ndarray:
+                          belief_owner=None, exact: bool = True) -> np.ndarray:
+        if not exact and self.dtype == 'f32':
+            self.set_value_max_exact(False)
+            try:
+                return self._max_value_objects(alpha_objects, belief_objects, alpha_values, belief_values, alpha_owner,
+                                               belief_owner, False)
+            finally:
+                self.set_value_max_exact(True)
+        return self._max_value_objects(alpha_objects, belief_objects, alpha_values, belief_values, alpha_owner,
+                                       belief_owner, True)
+
+    def _max_value_objects(self, alpha_objects, belief_objects, alpha_values, belief_values, alpha_owner, belief_owner,
+                           exact: bool) -> np.ndarray:
         """``max_v b.alpha_v`` for every belief object against the set of alpha objects, reusing earlier results.
 
         ``compute_change`` (``src/pomdp.py:2141-2169``) asks for this twice per backup on the whole accumulated
         belief set.  The maximum over a set that grew is the maximum of the old value and the maximum over the new
         rows, and a belief scored before keeps its value, so only (known beliefs x new alpha rows) and
         (new beliefs x all alpha rows) go through the GEMM.  Values are the engine's exact re-scored ones, so the
-        result equals the from-scratch one.  Entries are keyed by the set of alpha store ids."""
+        result equals the from-scratch one.  Entries are keyed by the set of alpha store ids (and by whether the values
+        are exact: ``exact=False`` -- f32 engines, ``pbvi_set_value_max_exact`` -- keeps the fp32 GEMM's maxima)."""
         a_ids = self.row_ids('alpha', alpha_objects, alpha_values, alpha_owner)
         b_ids = self.row_ids('belief', belief_objects, belief_values, belief_owner)
         epochs = (self._store_epoch['alpha'], self._store_epoch['belief'])
         if self._vmax_epochs != epochs:
             self._vmax_cache, self._vmax_epochs = [], epochs
         aset = np.unique(a_ids)                             # sorted ids: set algebra stays in NumPy
-        hit = next((e for e in self._vmax_cache if np.array_equal(e['aset'], aset)), None)
+        pool = [e for e in self._vmax_cache if e['exact'] == exact]
+        hit = next((e for e in pool if np.array_equal(e['aset'], aset)), None)
         base = hit
         if base is None:     # largest cached subset of this alpha set
-            subs = [e for e in self._vmax_cache
+            subs = [e for e in pool
                     if len(e['aset']) <= len(aset) and np.isin(e['aset'], aset, assume_unique=True).all()]
             base = max(subs, key=lambda e: len(e['aset'])) if subs else None
         n_ids = int(b_ids.max()) + 1 if len(b_ids) else 0
@@ -465,7 +484,7 @@ class Engine:
         if (~known).any():
             vals[~known] = self._vmax_block(a_ids, b_ids[~known])
         if hit is None:
-            hit = {'aset': aset, 'vals': np.full(n_ids, np.nan)}
+            hit = {'aset': aset, 'vals': np.full(n_ids, np.nan), 'exact': exact}
             self._vmax_cache.append(hit)
         elif len(hit['vals']) < n_ids:
             hit['vals'] = np.concatenate([hit['vals'], np.full(n_ids - len(hit['vals']), np.nan)])

@@ -711,8 +711,10 @@ class PBVI_Solver(Solver):
             # smaller alpha set first: in the solve loop it is the previous value function, a subset of the other one,
             # so the larger set then only needs (all beliefs x its additional rows)
             pair = sorted((value_function, new_value_function), key=len)
+            # only max|new - old| of the values is used, against eps * gamma / (1 - gamma): an f32 engine returns its
+            # GEMM's maxima as they are (exact=False); f64 engines are exact either way
             vals = {id(vf): eng.max_value_objects(vf.alpha_vector_list, beliefs, lambda v: v.values, lambda x: x.values,
-                                                  alpha_owner=vf, belief_owner=belief_set) for vf in pair}
+                                                  alpha_owner=vf, belief_owner=belief_set, exact=False) for vf in pair}
             old, new = vals[id(value_function)], vals[id(new_value_function)]
         else:
             b = belief_set.belief_array

@@ -397,6 +397,42 @@ def test_value_max_over_the_belief_store_in_place(monkeypatch):
         eng.close()
 
 
+def test_value_max_without_fp64_rescoring_stays_within_the_f32_bar():
+    """pbvi_set_value_max_exact(0) (what compute_change uses on f32 engines): the fp32 GEMM's maxima, within 1e-6
+    relative of the exact ones; exact mode is back afterwards; max_value_objects keeps exact and inexact results apart."""
+    from pomdp_pbvi_exploration_amd.mdp import AlphaVector
+    m = synth.olfactory_model(H=15, W=40, R=5)
+    alpha, _ = synth.alpha_set(m, 40)
+    beliefs = synth.belief_points(m, 300, max_depth=24)
+    want = orc.max_value_per_belief(alpha.astype(np.float64), beliefs.astype(np.float64))
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32')
+    eng.store_rows('alpha', alpha)
+    eng.store_rows('belief', beliefs)
+    eng.select_alpha(np.arange(40))
+    eng.select_beliefs(np.arange(300))
+    exact, _ = eng.max_value_resident()
+    np.testing.assert_allclose(exact, want, rtol=1e-12)
+    eng.set_value_max_exact(False)
+    fast, _ = eng.max_value_resident()
+    fast_store, _ = eng.max_value_store()
+    eng.set_value_max_exact(True)
+    np.testing.assert_allclose(fast, want, rtol=1e-6)
+    np.testing.assert_allclose(fast_store, want, rtol=1e-6)
+    assert not np.array_equal(fast, exact)                         # it really is the un-rescored value
+    again, _ = eng.max_value_resident()
+    assert np.array_equal(again, exact)
+
+    class Row:
+        def __init__(self, v):
+            self.values = v
+    A, Bl = [AlphaVector(r, 0) for r in alpha], [Row(r) for r in beliefs]
+    v_fast = eng.max_value_objects(A, Bl, lambda v: v.values, lambda x: x.values, exact=False)
+    v_exact = eng.max_value_objects(A, Bl, lambda v: v.values, lambda x: x.values)
+    np.testing.assert_allclose(v_exact, want, rtol=1e-12)
+    np.testing.assert_allclose(v_fast, want, rtol=1e-6)
+    eng.close()
+
+
 def test_solver_loop_on_gpu_keeps_rows_resident():
     """FSVI on the 4x3 grid through the Python API with use_gpu=True: every backup goes through the row
     stores; the trajectory equals the host NumPy path's (same seeds)."""

@@ -258,7 +258,8 @@ class _StubEngine:
         self._vmax_cache, self._vmax_epochs = [], None
         self.pairs_scored = 0
         # the real bookkeeping methods, bound to this object
-        for name in ('row_ids', 'max_value_objects', 'belief_tag'):
+        self.dtype = 'f64'
+        for name in ('row_ids', 'max_value_objects', '_max_value_objects', 'belief_tag'):
             setattr(self, name, getattr(Engine, name).__get__(self))
         self._VMAX_ENTRIES, self._BLOCK = Engine._VMAX_ENTRIES, Engine._BLOCK
 
