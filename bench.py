@@ -181,6 +181,18 @@ def main():
             if (args.mode == 'sparse' and args.dtype == 'f32' and m.S == 30000 and m.R == 1 and args.alphas == 1024 and B == 1024):
                 out['roofline']['traffic'] = pmc['traffic_bytes']
                 out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes)'
+                # the HBM-bound stages beside the GEMM: PMC bytes of the stage's main kernel / the stage's live time
+                # (the stage time also holds its small helper kernels, so these fractions are lower bounds)
+                other = pmc.get('other_kernels', {})
+                sec = {}
+                for stage, kern in (('ms_project', 'k_project'), ('ms_argmax', 'k_argmax'), ('ms_refine', 'k_refine')):
+                    if kern in other:
+                        ms = out['stage_ms'][stage]
+                        gbs = other[kern]['traffic_bytes'] / (ms * 1e-3) / 1e9
+                        sec[kern] = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                     'frac': gbs / PEAK_HBM_GBS, 'traffic': other[kern]['traffic_bytes'], 'ms': ms}
+                if sec:
+                    out['stage_roofline'] = sec
         except (OSError, KeyError, ValueError):
             pass
         if args.mode == 'dense':   # the projection GEMMs dominate: report them as the roofline kernel

@@ -10,6 +10,7 @@ FETCH_SIZE under-reports 16-byte-per-lane streams 2x on gfx950; Infinity-Cache h
 """
 import csv
 import glob
+import re
 import json
 import os
 import sys
@@ -81,6 +82,9 @@ def main():
                            'workload': 'olfactory-30000 reachable-sparse R=1 V=1024 B=1024 f32',
                            'launches_averaged': n, 'FETCH_SIZE_KB': fv, 'WRITE_SIZE_KB': wv,
                            'traffic_bytes': tot * 1024,
+                           'other_kernels': {re.sub(r'^void ', '', nm).split('(')[0].split('<')[0].replace('pbvi::', ''):
+                                             {'launches': nn, 'traffic_bytes': tt * 1024}
+                                             for tt, nm, nn, _, _ in sorted(table, reverse=True)[1:8] if 'pbvi::' in nm},
                            'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bytes = '
                                      '(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md section HBM'}, fh, indent=1)
         lines.append('')
