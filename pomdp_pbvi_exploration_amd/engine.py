@@ -184,10 +184,39 @@ class HostArena:
     are mapped once per GiB, the address space does not change between GPU calls."""
 
     BLOCK_BYTES = 1 << 30
+    _POPULATE_CHUNK = 64 << 20
+    _MADV_POPULATE_WRITE = 23           # Linux >= 5.14: fault the pages in (writable) without changing their contents
 
     def __init__(self):
         self._block = None
         self._off = 0
+
+    @classmethod
+    def _populate(cls, block: np.ndarray) -> None:
+        """Fault a fresh block's pages in from a helper thread.  Untouched, every 4 KiB page of a result costs a
+        page fault (and a zeroing) at the moment the engine's copy lands in it -- 0.1 us per KiB measured, 2.4 ms for
+        the 24 MB of beliefs one FSVI expansion returns; the helper pays that on another core, ahead of use, and
+        ``madvise`` leaves whatever was already written alone."""
+        import threading
+        try:
+            libc = C.CDLL(None, use_errno=True)
+            madvise = libc.madvise
+        except (OSError, AttributeError):
+            return
+        madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        madvise.restype = C.c_int
+        page = 4096
+        lo = (block.ctypes.data + page - 1) // page * page
+        hi = (block.ctypes.data + block.shape[0]) // page * page
+
+        def work(keep_alive=block):
+            a = lo
+            while a < hi:
+                n = min(cls._POPULATE_CHUNK, hi - a)
+                if madvise(a, n, cls._MADV_POPULATE_WRITE) != 0:
+                    return                                   # older kernel / not permitted: pages fault in on first use
+                a += n
+        threading.Thread(target=work, name='pbvi-arena-populate', daemon=True).start()
 
     def empty(self, shape, dtype) -> np.ndarray:
         dtype = np.dtype(dtype)
@@ -197,6 +226,7 @@ class HostArena:
         off = (self._off + 63) // 64 * 64
         if self._block is None or off + n > self._block.shape[0]:
             self._block = np.empty(self.BLOCK_BYTES, dtype=np.uint8)
+            self._populate(self._block)
             off = 0
         self._off = off + n
         return self._block[off:off + n].view(dtype).reshape(shape)
