@@ -284,6 +284,12 @@ int pbvi_mdp_value_iteration(int device, int32_t S, int32_t A, int32_t R, const 
  */
 int64_t pbvi_belief_walk(pbvi_engine_t* e, const double* b0, int64_t n, const int32_t* actions, const int32_t* observations,
                          const uint8_t* restart, double* out_beliefs);
+/*
+ * Dedup keys of the n beliefs of the last pbvi_belief_walk: out_keys[i] = wrapping sum of the 64-bit patterns of the
+ * fp64 row i -- the integer the host's belief containers hash on in place of the row's bytes (BeliefSet.union,
+ * src/pomdp.py:585-606, keys its dictionaries on values.tobytes()) -- so the host does not pass over the rows again.
+ */
+int pbvi_belief_walk_keys(pbvi_engine_t* e, int64_t n, uint64_t* out_keys);
 /* Optional fp64 copy of RTO ([S][A][O][R], as at creation) for pbvi_belief_walk on an f32 engine, so the fp64 belief
  * values it returns do not depend on the engine's arithmetic type (f64 engines read their own table). */
 int pbvi_engine_set_rto_f64(pbvi_engine_t* e, const double* rto);

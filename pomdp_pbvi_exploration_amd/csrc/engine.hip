@@ -263,6 +263,19 @@ __global__ void k_gather_rows_ld(const T* __restrict__ src, int ld_src, T* __res
     dst[(int64_t)blockIdx.y * ld_dst + s] = src[(int64_t)perm[blockIdx.y] * ld_src + s];
 }
 
+// key[r] = wrapping sum of the 64-bit patterns of row r (the hash the host's belief containers key on: equal bytes give
+// equal sums; mdp.py::_RowKey)
+__global__ void k_row_bit_sums(const double* __restrict__ rows, int S, unsigned long long* __restrict__ key) {
+    __shared__ unsigned long long red[4];
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(rows + (int64_t)blockIdx.x * S);
+    unsigned long long acc = 0;
+    for (int s = threadIdx.x; s < S; s += 256) acc += p[s];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) key[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 __global__ void k_unpermute(int B, int AO, const int32_t* __restrict__ perm, const int32_t* __restrict__ action,
                             const int32_t* __restrict__ best_v, int32_t* __restrict__ action_o, int32_t* __restrict__ best_o) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -305,6 +318,7 @@ class EngineBase {
     virtual int64_t belief_walk(const double* b0, int64_t n, const int32_t* act, const int32_t* obs, const uint8_t* restart,
                                 double* out) = 0;
     virtual int64_t beliefs_count() const = 0;
+    virtual int walk_keys(int64_t n, uint64_t* out_keys) = 0;
 };
 
 template <typename T>
@@ -339,6 +353,7 @@ class EngineT : public EngineBase {
     // as rows are appended
     DevBuf snz_, sbtl_, sbtc_;
     int64_t snz_rows_ = 0, sbt_rows_ = 0;
+    int64_t walk_rows_ = 0;                                 // rows the last belief_walk left in walk64_
     void* host_stage_ = nullptr;                            // pinned bounce buffer for rows going to pageable host memory
     size_t host_stage_cap_ = 0;
     DevBuf keys_tmp_, keys_act_, keys_best_, keys_rows_;    // unique-row keys out / rows from keys in (multi-GPU exchange)
@@ -868,7 +883,22 @@ class EngineT : public EngineBase {
         if ((rc = out_finish())) return rc;
         const int64_t first = store_rows_[1];
         store_rows_[1] = first + n;
+        walk_rows_ = n;
         return first;
+    }
+
+    // bit-pattern sums of the fp64 rows of the last walk (rows 1..n of walk64_), for the host's dedup keys
+    int walk_keys(int64_t n, uint64_t* out_keys) override {
+        if (n <= 0 || n != walk_rows_ || !out_keys) FAIL(PBVI_EINVAL, "belief_walk_keys: n must be the length of the last walk");
+        HIPCHK(hipSetDevice(device_));
+        int rc = keys_tmp_.ensure((size_t)n * sizeof(uint64_t), &bytes_);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_row_bit_sums, dim3((unsigned)n), dim3(256), 0, stream_, walk64_.as<double>() + S_, S_,
+                           keys_tmp_.as<unsigned long long>());
+        HIPCHK(hipGetLastError());
+        if ((rc = out_begin())) return rc;
+        if ((rc = out_add(out_keys, keys_tmp_.p, (size_t)n * sizeof(uint64_t)))) return rc;
+        return out_finish();
     }
 
     int store_reset(int which) override {
@@ -2039,6 +2069,10 @@ int pbvi_beliefs_advance(pbvi_engine_t* e, const int32_t* actions, const int32_t
     return e->impl->beliefs_advance(actions, observations, keep, out_B);
 }
 
+int pbvi_belief_walk_keys(pbvi_engine_t* e, int64_t n, uint64_t* out_keys) {
+    NEED(e);
+    return e->impl->walk_keys(n, out_keys);
+}
 int64_t pbvi_belief_walk(pbvi_engine_t* e, const double* b0, int64_t n, const int32_t* actions, const int32_t* observations,
                          const uint8_t* restart, double* out_beliefs) {
     NEED(e);

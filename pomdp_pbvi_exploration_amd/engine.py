@@ -31,6 +31,7 @@ EXPORTS = [
     'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk', 'pbvi_engine_set_rto_f64', 'pbvi_backup_fetch_unique_keys', 'pbvi_assemble_rows',
     'pbvi_backup_fetch_exchange', 'pbvi_backup_store_unique',
     'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact',
+    'pbvi_belief_walk_keys',
 ]
 
 
@@ -90,6 +91,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_value_max': (C.c_int, [vp, f64p, i32p]),
         'pbvi_value_max_store': (C.c_int, [vp, C.c_int64, f64p, i32p]),
         'pbvi_belief_store_count': (C.c_int64, [vp]),
+        'pbvi_belief_walk_keys': (C.c_int, [vp, C.c_int64, C.POINTER(C.c_uint64)]),
         'pbvi_set_value_max_exact': (C.c_int, [vp, C.c_int]),
         'pbvi_alpha_store_count': (C.c_int64, [vp]),
         'pbvi_alpha_store_append': (C.c_int64, [vp, vp, C.c_int64]),
@@ -691,6 +693,13 @@ class Engine:
         if first < 0:
             _check(first)
         return out, first
+
+    def belief_walk_keys(self, n: int) -> np.ndarray:
+        """``[n]`` uint64: bit-pattern sums of the fp64 rows of the last ``belief_walk`` (what ``_RowKey`` computes on
+        the host), from the device."""
+        keys = np.empty(n, dtype=np.uint64)
+        _check(self._lib.pbvi_belief_walk_keys(self._h, n, keys.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return keys
 
     def belief_tag(self):
         """Tag that marks an object as resident in this engine's belief store (see ``row_ids``)."""

@@ -291,6 +291,13 @@ class _RowKey(int):
         self.row = row
         return self
 
+    @classmethod
+    def from_sum(cls, bit_sum: int, row) -> '_RowKey':
+        """Key of ``row`` whose bit-pattern sum is already known (the engine computes it for rows it produced)."""
+        self = int.__new__(cls, bit_sum)
+        self.row = row
+        return self
+
     __hash__ = int.__hash__
 
     def __eq__(self, other) -> bool:

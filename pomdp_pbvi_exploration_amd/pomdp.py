@@ -624,6 +624,7 @@ class PBVI_Solver(Solver):
             return BeliefSet(model, [b0])
         eng = model.engine
         values, first = eng.belief_walk(b0.values, acts, obs, restart)
+        sums = eng.belief_walk_keys(len(acts)).tolist() if hasattr(eng, 'belief_walk_keys') else None
         tag = eng.belief_tag()
         seq = [b0]
         for i in range(len(acts)):
@@ -631,6 +632,8 @@ class PBVI_Solver(Solver):
             nb.model = b0.model
             nb._values = values[i]
             nb._dev = (tag, first + i)
+            if sums is not None:                       # the dedup key's hash comes from the device: no host pass over the row
+                nb._key = _RowKey.from_sum(sums[i], values[i])
             seq.append(nb)
         return BeliefSet(model, seq)
 

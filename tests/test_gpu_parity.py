@@ -772,6 +772,11 @@ def test_belief_walk_matches_host_updates(dtype):
     want = np.array(want)
     eng = Engine.for_model(model, dtype=dtype)
     got, first = eng.belief_walk(b0.values, acts, obs, restart)
+    from pomdp_pbvi_exploration_amd.mdp import _RowKey
+    keys = eng.belief_walk_keys(len(acts))                       # the hash of the host's dedup key, from the device
+    assert [int(k) for k in keys] == [int(_RowKey(r)) for r in got]
+    with pytest.raises(ValueError):
+        eng.belief_walk_keys(len(acts) + 1)
     tol = 1e-13 if dtype == 'f64' else 1e-6
     np.testing.assert_allclose(got, want, rtol=tol, atol=tol * 1e-3)
     assert np.allclose(got.sum(axis=1), 1.0, atol=1e-12)
