@@ -323,6 +323,50 @@ def test_max_value_cache_scores_only_new_pairs():
     assert query(12, 6) == 12 * 6
 
 
+def test_store_ids_travel_with_the_containers():
+    """ValueFunction.extend and BeliefSet.union carry the device-store ids of their rows (Engine.row_ids caches them per
+    container): a slot taken over on equal bytes keeps its id, new rows bring theirs, and what row_ids would find by
+    walking the objects is what the carried array says -- so a solve never walks 10^4 objects per call."""
+    from pomdp_pbvi_exploration_amd.mdp import AlphaVector
+    model, _ = load_POMDP_file(os.path.join(EXAMPLES, '4x3.95-no_loop_2_grid.POMDP'))
+    rng = np.random.default_rng(11)
+    S = model.state_count
+    eng = _StubEngine(model)
+    old = ValueFunction(model, rng.normal(size=(6, S)), [0, 1, 2, 3, 0, 1])
+    ids_old = eng.row_ids('alpha', old.alpha_vector_list, lambda v: v.values, owner=old)
+    assert list(ids_old) == [0, 1, 2, 3, 4, 5] and old._dev_ids[1] is ids_old
+    # a backup's result: two new rows and one that repeats an old row's bytes, every vector tagged with its store id
+    rows = np.vstack([rng.normal(size=(2, S)), old.alpha_vector_array[3:4]])
+    first = eng.store_rows('alpha', rows)
+    tag = (id(eng), 'alpha', eng._store_epoch['alpha'])
+    vecs = []
+    for k, r in enumerate(rows):
+        v = AlphaVector(r, 2)
+        v._dev = (tag, first + k)
+        vecs.append(v)
+    new = ValueFunction(model, vecs)
+    new.extend(old)
+    assert len(new) == 8 and new._dev_ids is not None
+    walked = [v._dev[1] for v in new.alpha_vector_list]          # the objects' own tags (old object took the repeated slot)
+    assert [eng.rows['alpha'][i].tobytes() for i in new._dev_ids[1]] == [v.values.tobytes() for v in new.alpha_vector_list]
+    assert sorted(walked) == sorted(set(walked)) and len(set(new._dev_ids[1].tolist())) == 8
+    assert eng.row_ids('alpha', new.alpha_vector_list, lambda v: v.values, owner=new) is new._dev_ids[1]
+    new.append(AlphaVector(rng.normal(size=S), 0))               # any other change drops the cache
+    assert new._dev_ids is None
+
+    bel = rng.random((5, S))
+    bel /= bel.sum(axis=1, keepdims=True)
+    mine = BeliefSet(model, [Belief(model, r) for r in bel[:3]])
+    eng.row_ids('belief', mine.belief_list, lambda b: b.values, owner=mine)
+    theirs = BeliefSet(model, [Belief(model, bel[1].copy()), Belief(model, bel[3]), Belief(model, bel[4])])   # first one repeats
+    eng.row_ids('belief', theirs.belief_list, lambda b: b.values, owner=theirs)
+    both = mine.union(theirs)
+    assert len(both) == 5 and both._dev_ids is not None
+    assert [eng.rows['belief'][i].tobytes() for i in both._dev_ids[1]] == [b.values.tobytes() for b in both.belief_list]
+    untagged = BeliefSet(model, [Belief(model, rng.dirichlet(np.ones(S)))])
+    assert getattr(mine.union(untagged), '_dev_ids', None) is None     # a belief without a store row: walk on demand
+
+
 def test_device_walk_draws_the_same_trajectory_as_the_host_walk():
     """PBVI_Solver._walk_device simulates the (a, o) trajectory first and updates the beliefs in one batched call; it
     must consume the random streams exactly like the step-by-step host walk (same beliefs, same order)."""
