@@ -353,7 +353,8 @@ class EngineT : public EngineBase {
     // as rows are appended
     DevBuf snz_, sbtl_, sbtc_;
     int64_t snz_rows_ = 0, sbt_rows_ = 0;
-    int64_t walk_rows_ = 0;                                 // rows the last belief_walk left in walk64_
+    int64_t walk_rows_ = 0;
+    hipEvent_t walk_ev_[8] = {};                            // belief_walk: chain -> copy -> host hand-offs, per quarter                                 // rows the last belief_walk left in walk64_
     void* host_stage_ = nullptr;                            // pinned bounce buffer for rows going to pageable host memory
     size_t host_stage_cap_ = 0;
     DevBuf keys_tmp_, keys_act_, keys_best_, keys_rows_;    // unique-row keys out / rows from keys in (multi-GPU exchange)
@@ -387,6 +388,8 @@ class EngineT : public EngineBase {
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &snz_, &sbtl_, &sbtc_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
+        for (auto& e : walk_ev_)
+            if (e) (void)hipEventDestroy(e);
         for (DevBuf* b : all) b->release();
         if (host_stage_) (void)hipHostFree(host_stage_);
         for (auto& e : ev_)
@@ -872,15 +875,51 @@ class EngineT : public EngineBase {
         double* rows = walk64_.as<double>();
         HIPCHK(hipMemcpyAsync(rows, b0, (size_t)S_ * sizeof(double), hipMemcpyHostToDevice, stream_));
         const ModelView<T> mv = view();
+        // The fp64 rows go back to the host while the chain is still running: in quarters, each copied by the side
+        // stream into the pinned buffer as soon as its last step is done, and moved on to the caller's memory by this
+        // thread while the device works on the next quarter (the 24 MB of a 99-step walk at S = 30000 took 1.4 ms
+        // after a 1.2 ms chain; now most of it hides behind the chain).
+        const bool to_host = !is_device_pointer(out);
+        constexpr int kChunks = 4;
+        int64_t chunk_end[kChunks];
+        int n_chunks = 0;
+        if (to_host && n >= 2 * kChunks) {
+            if ((rc = out_begin())) return rc;                                   // (nothing of an earlier call is staged)
+            if ((rc = stage_reserve((size_t)n * S_ * sizeof(double)))) return rc;
+            for (auto& e : walk_ev_)
+                if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            n_chunks = kChunks;
+            for (int c = 0; c < kChunks; ++c) chunk_end[c] = n * (c + 1) / kChunks;
+        }
+        int c_next = 0;
         for (int64_t i = 0; i < n; ++i) {
             const double* base = (restart && restart[i]) ? rows : rows + (size_t)i * S_;       // row i = b_i (row 0 = b0)
             HIPCHK(launch_walk_step<T>(base, mv, rto64_.as<double>(), in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), act[i], obs[i],
                                        bu_unnorm_.as<double>(), bu_mass_.as<double>(), rows + (size_t)(i + 1) * S_,
                                        dst + (size_t)i * S_pad_, stream_));
+            if (c_next < n_chunks && i + 1 == chunk_end[c_next]) {
+                const int64_t r0 = c_next ? chunk_end[c_next - 1] : 0;
+                HIPCHK(hipEventRecord(walk_ev_[2 * c_next], stream_));
+                HIPCHK(hipStreamWaitEvent(stream2_, walk_ev_[2 * c_next], 0));
+                HIPCHK(hipMemcpyAsync((char*)host_stage_ + (size_t)r0 * S_ * sizeof(double), rows + (size_t)(r0 + 1) * S_,
+                                      (size_t)(i + 1 - r0) * S_ * sizeof(double), hipMemcpyDeviceToHost, stream2_));
+                HIPCHK(hipEventRecord(walk_ev_[2 * c_next + 1], stream2_));
+                ++c_next;
+            }
         }
-        if ((rc = out_begin())) return rc;
-        if ((rc = out_add(out, rows + S_, (size_t)n * S_ * sizeof(double)))) return rc;
-        if ((rc = out_finish())) return rc;
+        if (n_chunks > 0) {
+            for (int c = 0; c < n_chunks; ++c) {
+                const int64_t r0 = c ? chunk_end[c - 1] : 0;
+                HIPCHK(hipEventSynchronize(walk_ev_[2 * c + 1]));
+                std::memcpy((char*)out + (size_t)r0 * S_ * sizeof(double), (const char*)host_stage_ + (size_t)r0 * S_ * sizeof(double),
+                            (size_t)(chunk_end[c] - r0) * S_ * sizeof(double));
+            }
+            HIPCHK(hipStreamSynchronize(stream_));
+        } else {
+            if ((rc = out_begin())) return rc;
+            if ((rc = out_add(out, rows + S_, (size_t)n * S_ * sizeof(double)))) return rc;
+            if ((rc = out_finish())) return rc;
+        }
         const int64_t first = store_rows_[1];
         store_rows_[1] = first + n;
         walk_rows_ = n;
@@ -1054,6 +1093,24 @@ class EngineT : public EngineBase {
         return PBVI_OK;
     }
     int out_finish() { return out_flush(); }
+    // pinned buffer of at least `bytes` with nothing staged in it
+    int stage_reserve(size_t bytes) {
+        int rc = out_flush();
+        if (rc) return rc;
+        if (bytes > host_stage_cap_) {
+            if (host_stage_) (void)hipHostFree(host_stage_);
+            host_stage_ = nullptr;
+            host_stage_cap_ = 0;
+            const size_t want = std::max<size_t>(bytes * 2, (size_t)64 << 20);
+            if (hipHostMalloc(&host_stage_, want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                host_stage_ = nullptr;
+                FAIL(PBVI_ENOMEM, "pinned staging allocation failed");
+            }
+            host_stage_cap_ = want;
+        }
+        return PBVI_OK;
+    }
 
     // (a*, v*[a*,:]) of every unique row of the last backup: [U][1+O] int32, host or device destination
     int fetch_unique_keys(int32_t* out_keys) override {
