@@ -276,7 +276,9 @@ class _RowKey(int):
     a megabyte per row: the key IS an integer -- the wrapping sum of the row's bit patterns, one single-threaded pass,
     equal bytes give equal sums -- so dictionaries hash it at C speed, and equality compares the bytes, which only
     happens when two keys carry the same sum, i.e. practically only for equal rows.  Used by the belief containers;
-    the alpha-vector container keeps ``bytes`` keys (measured: no gain there)."""
+    the alpha-vector container keeps ``bytes`` keys: the sum is permutation-invariant and a solve's alpha-vectors are
+    largely shifted copies of one another (wrap-around grid), so their sums collide -- 400 byte comparisons per
+    ``extend`` when tried."""
 
     def __new__(cls, row):
         if isinstance(row, int):                            # copy / pickle rebuild: the row comes back through __dict__
