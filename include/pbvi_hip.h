@@ -219,6 +219,15 @@ int pbvi_value_max(pbvi_engine_t* e, double* out_value, int32_t* out_index);
  * belief set after every backup; that set only grows.  out_value / out_index: [n] (either may be NULL), store order.
  */
 int pbvi_value_max_store(pbvi_engine_t* e, int64_t n, double* out_value, int32_t* out_index);
+/*
+ * max_v b.alpha_v of the beliefs of the last pbvi_backup_run against the alpha set it ran on, out_value [B] in the
+ * caller's order: what compute_change (src/pomdp.py:2165) asks for next about exactly these beliefs and that set.
+ * In the belief-side formulation the beliefs ride along as extra rows of the score GEMM (they fit its row padding), so
+ * the values cost one row-max kernel.  fp32 engines: the GEMM's maxima (as with pbvi_set_value_max_exact(0)); f64
+ * engines: the same sums pbvi_value_max returns.  PBVI_EUNSUPPORTED (-4) after an alpha-side backup
+ * (pbvi_stats_t.formulation == 1).
+ */
+int pbvi_backup_fetch_value_max(pbvi_engine_t* e, double* out_value);
 /* rows currently held by the stores (ids are 0 .. count-1) */
 int64_t pbvi_belief_store_count(const pbvi_engine_t* e);
 int64_t pbvi_alpha_store_count(const pbvi_engine_t* e);

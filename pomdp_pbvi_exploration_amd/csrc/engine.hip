@@ -276,6 +276,26 @@ __global__ void k_row_bit_sums(const double* __restrict__ rows, int S, unsigned 
     if (threadIdx.x == 0) key[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// max_v score[row0 + b][v] for the B extra rows of the belief-side GEMM (the beliefs themselves multiplied by the alpha
+// set: b . alpha_v), one wave per row; out[perm ? perm[b] : b]
+template <typename T>
+__global__ void k_extra_rowmax(SlabView<T> sv, int64_t row0, int B, int V, const int32_t* __restrict__ perm,
+                               double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    T m = -std::numeric_limits<T>::infinity();
+    for (int v = lane; v < V; v += 64) {
+        const T sc = sv.at(row0 + b, v);
+        m = sc > m ? sc : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if (lane == 0) out[perm ? perm[b] : b] = (double)m;
+}
+
 __global__ void k_unpermute(int B, int AO, const int32_t* __restrict__ perm, const int32_t* __restrict__ action,
                             const int32_t* __restrict__ best_v, int32_t* __restrict__ action_o, int32_t* __restrict__ best_o) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -319,6 +339,7 @@ class EngineBase {
                                 double* out) = 0;
     virtual int64_t beliefs_count() const = 0;
     virtual int walk_keys(int64_t n, uint64_t* out_keys) = 0;
+    virtual int backup_value_max(double* out_value) = 0;
 };
 
 template <typename T>
@@ -354,6 +375,8 @@ class EngineT : public EngineBase {
     DevBuf snz_, sbtl_, sbtc_;
     int64_t snz_rows_ = 0, sbt_rows_ = 0;
     int64_t walk_rows_ = 0;
+    DevBuf vmax_bk_;                                        // max_v b.alpha_v of the last backup's beliefs (belief-side GEMM's extra rows)
+    bool have_bk_vmax_ = false;
     hipEvent_t walk_ev_[8] = {};                            // belief_walk: chain -> copy -> host hand-offs, per quarter                                 // rows the last belief_walk left in walk64_
     void* host_stage_ = nullptr;                            // pinned bounce buffer for rows going to pageable host memory
     size_t host_stage_cap_ = 0;
@@ -386,7 +409,7 @@ class EngineT : public EngineBase {
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
-                         &snz_, &sbtl_, &sbtc_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
+                         &snz_, &sbtl_, &sbtc_, &vmax_bk_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
         for (auto& e : walk_ev_)
             if (e) (void)hipEventDestroy(e);
@@ -924,6 +947,18 @@ class EngineT : public EngineBase {
         store_rows_[1] = first + n;
         walk_rows_ = n;
         return first;
+    }
+
+    // max_v b.alpha_v of the last backup's beliefs against its alpha set, caller order (belief-side formulation only)
+    int backup_value_max(double* out_value) override {
+        if (!have_result_ || !have_bk_vmax_)
+            FAIL(PBVI_EUNSUPPORTED, "backup_fetch_value_max: the last backup did not run in the belief-side formulation");
+        if (!out_value) FAIL(PBVI_EINVAL, "backup_fetch_value_max: NULL destination");
+        HIPCHK(hipSetDevice(device_));
+        int rc;
+        if ((rc = out_begin())) return rc;
+        if ((rc = out_add(out_value, vmax_bk_.p, (size_t)res_B_ * sizeof(double)))) return rc;
+        return out_finish();
     }
 
     // bit-pattern sums of the fp64 rows of the last walk (rows 1..n of walk64_), for the host's dedup keys
@@ -1633,13 +1668,18 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     if (use_push) {
         // K1 (belief side): every belief through every (a, o); K2: [B*A*O] x [V]
         if ((rc = build_inverse_lists())) return rc;
-        const int64_t M = (int64_t)AO * B_, M_pad = round_up(M, GEMM_BM);
+        // B extra rows behind the projected ones: the beliefs themselves, so the same GEMM also yields b . alpha_v --
+        // compute_change's max_v b.alpha_v of these beliefs against this alpha set (pbvi_backup_fetch_value_max)
+        // rides in the M padding (1800 + 100 rows of 2048 in a solve loop).
+        const int64_t M = (int64_t)AO * B_, Mx = M + B_, M_pad = round_up(Mx, GEMM_BM);
         if ((rc = bp_.ensure((size_t)M_pad * S_pad_ * sizeof(T), &bytes_))) return rc;
+        if ((rc = vmax_bk_.ensure((size_t)B_ * sizeof(double), &bytes_))) return rc;
         if ((rc = pmag_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
         if ((rc = nzP_.ensure((size_t)(M_pad / GEMM_BM) * k_tiles, &bytes_))) return rc;
         HIPCHK(hipMemsetAsync(pmag_.p, 0, (size_t)pairs * sizeof(double), stream_));
-        if (M_pad > M)
-            HIPCHK(hipMemsetAsync(bp_.as<T>() + (size_t)M * S_pad_, 0, (size_t)(M_pad - M) * S_pad_ * sizeof(T), stream_));
+        HIPCHK(hipMemcpyAsync(bp_.as<T>() + (size_t)M * S_pad_, bel_.p, (size_t)B_ * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+        if (M_pad > Mx)
+            HIPCHK(hipMemsetAsync(bp_.as<T>() + (size_t)Mx * S_pad_, 0, (size_t)(M_pad - Mx) * S_pad_ * sizeof(T), stream_));
         HIPCHK(launch_push_project<T>(bel_.as<T>(), S_pad_, (int)B_, mv, in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), gamma,
                                       alpha_.as<T>() + (size_t)V_ * S_pad_, bp_.as<T>(), S_pad_, pmag_.as<double>(), stream_));
         if constexpr (kF32)
@@ -1647,7 +1687,10 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         else
             HIPCHK(launch_tile_nonzero_f64((const double*)bp_.p, S_pad_, (int)M_pad, k_tiles, nzP_.as<uint8_t>(), stream_));
         HIPCHK(hipEventRecord(ev_[1], stream_));
-        if ((rc = score_gemm(alpha_.as<T>(), V_, nullptr, 1, (int)V_, &sv, bp_.as<T>(), M, nzP_.as<uint8_t>()))) return rc;
+        if ((rc = score_gemm(alpha_.as<T>(), V_, nullptr, 1, (int)V_, &sv, bp_.as<T>(), Mx, nzP_.as<uint8_t>()))) return rc;
+        hipLaunchKernelGGL(k_extra_rowmax<T>, dim3((unsigned)((B_ + 3) / 4)), dim3(256), 0, stream_, sv, M, (int)B_, (int)V_,
+                           sorted_ ? perm_.as<int32_t>() : nullptr, vmax_bk_.as<double>());
+        HIPCHK(hipGetLastError());
         sv.push = 1;
         sv.push_B = (int)B_;
         sv.push_A = A_;
@@ -1763,6 +1806,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     HIPCHK(hipEventRecord(ev_[7], stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     have_result_ = true;
+    have_bk_vmax_ = use_push;
     res_B_ = B_;
     const int h_ucount = h_cnt[3];
     res_unique_ = h_ucount;
@@ -2126,6 +2170,10 @@ int pbvi_beliefs_advance(pbvi_engine_t* e, const int32_t* actions, const int32_t
     return e->impl->beliefs_advance(actions, observations, keep, out_B);
 }
 
+int pbvi_backup_fetch_value_max(pbvi_engine_t* e, double* out_value) {
+    NEED(e);
+    return e->impl->backup_value_max(out_value);
+}
 int pbvi_belief_walk_keys(pbvi_engine_t* e, int64_t n, uint64_t* out_keys) {
     NEED(e);
     return e->impl->walk_keys(n, out_keys);

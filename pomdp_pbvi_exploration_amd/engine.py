@@ -31,7 +31,7 @@ EXPORTS = [
     'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk', 'pbvi_engine_set_rto_f64', 'pbvi_backup_fetch_unique_keys', 'pbvi_assemble_rows',
     'pbvi_backup_fetch_exchange', 'pbvi_backup_store_unique',
     'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact',
-    'pbvi_belief_walk_keys',
+    'pbvi_belief_walk_keys', 'pbvi_backup_fetch_value_max',
 ]
 
 
@@ -91,6 +91,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_value_max': (C.c_int, [vp, f64p, i32p]),
         'pbvi_value_max_store': (C.c_int, [vp, C.c_int64, f64p, i32p]),
         'pbvi_belief_store_count': (C.c_int64, [vp]),
+        'pbvi_backup_fetch_value_max': (C.c_int, [vp, f64p]),
         'pbvi_belief_walk_keys': (C.c_int, [vp, C.c_int64, C.POINTER(C.c_uint64)]),
         'pbvi_set_value_max_exact': (C.c_int, [vp, C.c_int]),
         'pbvi_alpha_store_count': (C.c_int64, [vp]),
@@ -462,6 +463,38 @@ class Engine:
             self.select_beliefs(b_ids[i0:i0 + self._BLOCK])
             out[i0:i0 + self._BLOCK] = self.max_value_resident()[0]
         return out
+
+    def seed_max_values(self, alpha_objects, belief_objects, alpha_values, belief_values, alpha_owner=None,
+                        belief_owner=None) -> bool:
+        """After a backup in the belief-side formulation: take ``max_v b.alpha_v`` of its beliefs against its alpha set
+        from the engine (``pbvi_backup_fetch_value_max`` -- the beliefs rode along in the score GEMM) and put it where
+        ``max_value_objects`` will look, so ``compute_change`` does not run that GEMM again.  Returns False when the
+        last backup has no such values (alpha-side formulation)."""
+        vals = np.empty(self.B, dtype=np.float64)
+        rc = self._lib.pbvi_backup_fetch_value_max(self._h, vals.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc == -4:
+            return False
+        _check(rc)
+        a_ids = self.row_ids('alpha', alpha_objects, alpha_values, alpha_owner)
+        b_ids = self.row_ids('belief', belief_objects, belief_values, belief_owner)
+        if len(b_ids) != len(vals):
+            return False
+        epochs = (self._store_epoch['alpha'], self._store_epoch['belief'])
+        if self._vmax_epochs != epochs:
+            self._vmax_cache, self._vmax_epochs = [], epochs
+        exact = self.dtype != 'f32'             # fp32 engines: the GEMM's maxima, the exact=False pool of max_value_objects
+        aset = np.unique(a_ids)
+        hit = next((e for e in self._vmax_cache if e['exact'] == exact and np.array_equal(e['aset'], aset)), None)
+        n_ids = int(b_ids.max()) + 1
+        if hit is None:
+            hit = {'aset': aset, 'vals': np.full(n_ids, np.nan), 'exact': exact}
+            self._vmax_cache.append(hit)
+            del self._vmax_cache[:-self._VMAX_ENTRIES]
+        elif len(hit['vals']) < n_ids:
+            hit['vals'] = np.concatenate([hit['vals'], np.full(n_ids - len(hit['vals']), np.nan)])
+        unknown = np.isnan(hit['vals'][b_ids])
+        hit['vals'][b_ids[unknown]] = vals[unknown]        # a value scored before stays (it is the same sum)
+        return True
 
     def set_value_max_exact(self, exact: bool) -> None:
         """f32 engines: fp64 re-scoring of ``max_value_*`` results on (default) or off (``pbvi_set_value_max_exact``)."""

@@ -444,7 +444,12 @@ class PBVI_Solver(Solver):
             beliefs = belief_set.belief_list
             if len(beliefs) <= self.BELIEF_BLOCK:
                 eng.sync_rows('belief', beliefs, lambda b: b.values, owner=belief_set)
-                eng.run(self.gamma, belief_dominance_prune)
+                stats = eng.run(self.gamma, belief_dominance_prune)
+                if stats['formulation'] == 2:
+                    # belief-side GEMM: it also multiplied the beliefs themselves by the alpha set; compute_change asks for
+                    # exactly those maxima next (these beliefs, the value function that was just backed up)
+                    eng.seed_max_values(value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda b: b.values,
+                                        alpha_owner=value_function, belief_owner=belief_set)
                 alpha_new, actions, uidx = eng.fetch().value_function_rows(use_keep=belief_dominance_prune, with_index=True)
                 if len(uidx):
                     # the new rows join the engine's alpha store device to device: the next call selects them by id

@@ -433,6 +433,41 @@ def test_value_max_without_fp64_rescoring_stays_within_the_f32_bar():
     eng.close()
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+@pytest.mark.parametrize('B', [40, 300])
+def test_backup_in_the_belief_side_formulation_also_yields_the_value_maxima(dtype, B):
+    """pbvi_backup_fetch_value_max: in the belief-side formulation the beliefs ride along as extra rows of the score
+    GEMM, so the backup also knows max_v b.alpha_v of its beliefs (compute_change's next question).  f64 engines: the
+    value pbvi_value_max returns; f32 engines: the GEMM's maxima (1e-6); caller order also when the block is sorted;
+    an alpha-side backup has no such values."""
+    import ctypes as C
+    m = synth.olfactory_model(H=15, W=40, R=5)
+    alpha, _ = synth.alpha_set(m, 200)
+    beliefs = synth.belief_points(m, B, max_depth=24)
+    want = orc.max_value_per_belief(alpha.astype(np.float64), beliefs.astype(np.float64))
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype)
+    eng.set_alpha(alpha)
+    eng.set_beliefs(beliefs)
+    out = np.empty(B, dtype=np.float64)
+    ptr = out.ctypes.data_as(C.POINTER(C.c_double))
+    eng.set_formulation('belief')
+    st = eng.run(m.gamma)
+    assert st['formulation'] == 2
+    assert eng._lib.pbvi_backup_fetch_value_max(eng._h, ptr) == 0
+    np.testing.assert_allclose(out, want, rtol=1e-12 if dtype == 'f64' else 1e-6)
+    res_push = eng.fetch()
+    exact, _ = eng.max_value_resident()
+    if dtype == 'f64':
+        assert np.array_equal(out, exact)
+    eng.set_formulation('alpha')
+    st = eng.run(m.gamma)
+    assert st['formulation'] == 1
+    assert eng._lib.pbvi_backup_fetch_value_max(eng._h, ptr) == -4
+    res_pull = eng.fetch()                                          # the extra rows changed nothing of the backup itself
+    assert np.array_equal(res_push.best_alpha_ind, res_pull.best_alpha_ind) and np.array_equal(res_push.actions, res_pull.actions)
+    eng.close()
+
+
 def test_solver_loop_on_gpu_keeps_rows_resident():
     """FSVI on the 4x3 grid through the Python API with use_gpu=True: every backup goes through the row
     stores; the trajectory equals the host NumPy path's (same seeds)."""
