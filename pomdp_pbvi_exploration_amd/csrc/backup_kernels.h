@@ -194,6 +194,14 @@ hipError_t launch_belief_update(const T* bel, int ldb, int B, ModelView<T> mv, c
 
 // one step of the belief walk: out64 [S] / out_store [S_pad] = normalised update of `base` (fp64 [S]) with (a, o);
 // unnorm [S], partial [ceil(S_pad/256)] fp64 scratch; rto64: fp64 copy of RTO in mv's layout, or nullptr = use mv.rto
+// one kernel per step: pushes belief i and writes belief i (normalising the previous raw result on the fly); see the kernel
+template <typename T>
+hipError_t launch_walk_fused(const double* plain_base, const double* prev_unnorm, const double* prev_partial, double* prev_out64,
+                             T* prev_out_store, ModelView<T> mv, const double* rto64, const int32_t* in_ptr, const int32_t* in_src,
+                             int a, int o, double* unnorm, double* partial, hipStream_t st);
+template <typename T>
+hipError_t launch_walk_finish(const double* unnorm, const double* partial, ModelView<T> mv, double* out64, T* out_store,
+                              hipStream_t st);
 template <typename T>
 hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* rto64, const int32_t* in_ptr,
                             const int32_t* in_src, int a, int o, double* unnorm, double* partial, double* out64,

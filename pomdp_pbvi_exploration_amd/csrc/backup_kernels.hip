@@ -1408,16 +1408,24 @@ __global__ void k_walk_push(const double* __restrict__ base, const TT* __restric
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// Sum of n block partials, computed identically by every block that calls it (fixed tree: lane-strided loads, wave
+// shuffles, then the four wave sums in order), so all blocks of a step divide by the same mass.
+__device__ __forceinline__ double partials_sum(const double* __restrict__ partial, int n, double* red /* [4] shared */) {
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) m += partial[i];
+    for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    return tot;
+}
+
 template <typename T>
 __global__ void k_walk_norm(const double* __restrict__ unnorm, const double* __restrict__ partial, int n_partial, int S,
                             int S_pad, double* __restrict__ out64, T* __restrict__ out_store) {
-    __shared__ double mass_sh;
-    if (threadIdx.x == 0) {
-        double m = 0.0;
-        for (int i = 0; i < n_partial; ++i) m += partial[i];   // same order in every block
-        mass_sh = m;
-    }
-    __syncthreads();
+    __shared__ double red_m[4];
+    const double mass_sh = partials_sum(partial, n_partial, red_m);
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s < S) {
         const double v = unnorm[s] / mass_sh;
@@ -1426,6 +1434,72 @@ __global__ void k_walk_norm(const double* __restrict__ unnorm, const double* __r
     } else if (s < S_pad) {
         out_store[s] = T(0);
     }
+}
+
+// One kernel per step of a chain: step i pushes belief i through (a, o) AND writes belief i itself, normalising the
+// previous step's raw result on the fly (every block re-adds the previous step's block partials in the same order, so
+// all blocks divide by the same mass; a gathered value prev_unnorm[s] / mass is the very double k_walk_norm would have
+// stored).  Halves the dependent launches of a walk, which is what its time consists of (~6 us each).
+//   plain_base : belief to push when it is already normalised (b0: first step and restarts), else nullptr
+//   prev_*     : previous step's raw row / partial sums / destinations of its normalised row (all nullptr at step 0)
+template <typename TT, typename T>
+__global__ void k_walk_fused(const double* __restrict__ plain_base, const double* __restrict__ prev_unnorm,
+                             const double* __restrict__ prev_partial, int n_partial, double* __restrict__ prev_out64,
+                             T* __restrict__ prev_out_store, const TT* __restrict__ rto_all, int S, int S_pad, int O, int R,
+                             const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src, int a, int o,
+                             double* __restrict__ unnorm, double* __restrict__ partial) {
+#pragma clang fp contract(off)
+    __shared__ double red[4];
+    const double mass = prev_unnorm != nullptr ? partials_sum(prev_partial, n_partial, red) : 1.0;
+    const int sp = blockIdx.x * 256 + threadIdx.x;
+    if (prev_out64 != nullptr) {                         // the previous belief, normalised (k_walk_norm's statement)
+        if (sp < S) {
+            const double v = prev_unnorm[sp] / mass;
+            prev_out64[sp] = v;
+            prev_out_store[sp] = (T)v;
+        } else if (sp < S_pad) {
+            prev_out_store[sp] = T(0);
+        }
+    }
+    double u = 0.0;
+    if (sp < S) {
+        const int32_t* ptr = in_ptr + (int64_t)a * (S + 1);
+        const int32_t* src = in_src + (int64_t)a * S * R;
+        const TT* rto = rto_all + (int64_t)(a * O + o) * R * S_pad;
+        for (int j = ptr[sp]; j < ptr[sp + 1]; ++j) {
+            const int e = src[j];
+            const int s = e / R, r = e - s * R;
+            const double bs = plain_base != nullptr ? plain_base[s] : prev_unnorm[s] / mass;
+            const double w = (double)rto[(int64_t)r * S_pad + s] * bs;
+            u = u + w;
+        }
+        unnorm[sp] = u;
+    }
+    const double tot = block_sum(u, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+template <typename T>
+hipError_t launch_walk_fused(const double* plain_base, const double* prev_unnorm, const double* prev_partial, double* prev_out64,
+                             T* prev_out_store, ModelView<T> mv, const double* rto64, const int32_t* in_ptr, const int32_t* in_src,
+                             int a, int o, double* unnorm, double* partial, hipStream_t st) {
+    const int blocks = (mv.S_pad + 255) / 256;
+    if (rto64 != nullptr)
+        hipLaunchKernelGGL((k_walk_fused<double, T>), dim3(blocks), dim3(256), 0, st, plain_base, prev_unnorm, prev_partial, blocks,
+                           prev_out64, prev_out_store, rto64, mv.S, mv.S_pad, mv.O, mv.R, in_ptr, in_src, a, o, unnorm, partial);
+    else
+        hipLaunchKernelGGL((k_walk_fused<T, T>), dim3(blocks), dim3(256), 0, st, plain_base, prev_unnorm, prev_partial, blocks,
+                           prev_out64, prev_out_store, mv.rto, mv.S, mv.S_pad, mv.O, mv.R, in_ptr, in_src, a, o, unnorm, partial);
+    return hipGetLastError();
+}
+
+// the last belief of a chain: only the normalisation is left
+template <typename T>
+hipError_t launch_walk_finish(const double* unnorm, const double* partial, ModelView<T> mv, double* out64, T* out_store,
+                              hipStream_t st) {
+    const int blocks = (mv.S_pad + 255) / 256;
+    hipLaunchKernelGGL(k_walk_norm<T>, dim3(blocks), dim3(256), 0, st, unnorm, partial, blocks, mv.S, mv.S_pad, out64, out_store);
+    return hipGetLastError();
 }
 
 template <typename T>
@@ -1480,6 +1554,10 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
                                        hipStream_t);                                                                   \
     template hipError_t launch_walk_step<T>(const double*, ModelView<T>, const double*, const int32_t*, const int32_t*, \
                                             int, int, double*, double*, double*, T*, hipStream_t);                     \
+    template hipError_t launch_walk_fused<T>(const double*, const double*, const double*, double*, T*, ModelView<T>,      \
+                                             const double*, const int32_t*, const int32_t*, int, int, double*, double*,   \
+                                             hipStream_t);                                                               \
+    template hipError_t launch_walk_finish<T>(const double*, const double*, ModelView<T>, double*, T*, hipStream_t);     \
     template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
 PBVI_INST(float)
 PBVI_INST(double)

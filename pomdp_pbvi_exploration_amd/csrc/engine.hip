@@ -891,8 +891,8 @@ class EngineT : public EngineBase {
         if (rc) return rc;
         const int blocks = (S_pad_ + 255) / 256;
         if ((rc = walk64_.ensure((size_t)(n + 1) * S_ * sizeof(double), &bytes_))) return rc;      // row 0 = b0
-        if ((rc = bu_unnorm_.ensure((size_t)S_ * sizeof(double), &bytes_))) return rc;
-        if ((rc = bu_mass_.ensure((size_t)blocks * sizeof(double), &bytes_))) return rc;
+        if ((rc = bu_unnorm_.ensure((size_t)2 * S_ * sizeof(double), &bytes_))) return rc;          // ping-pong: raw row of step i
+        if ((rc = bu_mass_.ensure((size_t)2 * blocks * sizeof(double), &bytes_))) return rc;      // and its block partials
         T* dst = nullptr;
         if ((rc = store_reserve(1, n, &dst))) return rc;
         double* rows = walk64_.as<double>();
@@ -914,19 +914,48 @@ class EngineT : public EngineBase {
             n_chunks = kChunks;
             for (int c = 0; c < kChunks; ++c) chunk_end[c] = n * (c + 1) / kChunks;
         }
+        // step i: one kernel pushes belief i (b0 at the start and after a restart, else the previous step's raw row
+        // normalised on the fly) and writes belief i (rows64 row i, store row i - 1); the last belief is finished by a
+        // normalisation of its own.  A quarter of the rows is complete once the kernel after its last step is queued.
+        static const bool two_kernels = getenv("PBVI_WALK_TWO_KERNELS") != nullptr;      // debug / A-B only: the unfused chain
+        auto queue_copy = [&](int c) -> int {
+            const int64_t r0 = c ? chunk_end[c - 1] : 0, r1 = chunk_end[c];
+            HIPCHK(hipEventRecord(walk_ev_[2 * c], stream_));
+            HIPCHK(hipStreamWaitEvent(stream2_, walk_ev_[2 * c], 0));
+            HIPCHK(hipMemcpyAsync((char*)host_stage_ + (size_t)r0 * S_ * sizeof(double), rows + (size_t)(r0 + 1) * S_,
+                                  (size_t)(r1 - r0) * S_ * sizeof(double), hipMemcpyDeviceToHost, stream2_));
+            HIPCHK(hipEventRecord(walk_ev_[2 * c + 1], stream2_));
+            return PBVI_OK;
+        };
         int c_next = 0;
+        double* un[2] = {bu_unnorm_.as<double>(), bu_unnorm_.as<double>() + S_};
+        double* pa[2] = {bu_mass_.as<double>(), bu_mass_.as<double>() + blocks};
         for (int64_t i = 0; i < n; ++i) {
-            const double* base = (restart && restart[i]) ? rows : rows + (size_t)i * S_;       // row i = b_i (row 0 = b0)
-            HIPCHK(launch_walk_step<T>(base, mv, rto64_.as<double>(), in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), act[i], obs[i],
-                                       bu_unnorm_.as<double>(), bu_mass_.as<double>(), rows + (size_t)(i + 1) * S_,
-                                       dst + (size_t)i * S_pad_, stream_));
-            if (c_next < n_chunks && i + 1 == chunk_end[c_next]) {
-                const int64_t r0 = c_next ? chunk_end[c_next - 1] : 0;
-                HIPCHK(hipEventRecord(walk_ev_[2 * c_next], stream_));
-                HIPCHK(hipStreamWaitEvent(stream2_, walk_ev_[2 * c_next], 0));
-                HIPCHK(hipMemcpyAsync((char*)host_stage_ + (size_t)r0 * S_ * sizeof(double), rows + (size_t)(r0 + 1) * S_,
-                                      (size_t)(i + 1 - r0) * S_ * sizeof(double), hipMemcpyDeviceToHost, stream2_));
-                HIPCHK(hipEventRecord(walk_ev_[2 * c_next + 1], stream2_));
+            if (two_kernels) {
+                const double* base = (restart && restart[i]) ? rows : rows + (size_t)i * S_;       // row i = b_i (row 0 = b0)
+                HIPCHK(launch_walk_step<T>(base, mv, rto64_.as<double>(), in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), act[i], obs[i],
+                                           un[0], pa[0], rows + (size_t)(i + 1) * S_, dst + (size_t)i * S_pad_, stream_));
+                if (c_next < n_chunks && i + 1 == chunk_end[c_next]) {
+                    if ((rc = queue_copy(c_next))) return rc;
+                    ++c_next;
+                }
+                continue;
+            }
+            const bool from_b0 = i == 0 || (restart && restart[i]);
+            const double* prev_un = i > 0 ? un[(i - 1) & 1] : nullptr;
+            HIPCHK(launch_walk_fused<T>(from_b0 ? rows : nullptr, prev_un, i > 0 ? pa[(i - 1) & 1] : nullptr,
+                                        i > 0 ? rows + (size_t)i * S_ : nullptr, i > 0 ? dst + (size_t)(i - 1) * S_pad_ : nullptr, mv,
+                                        rto64_.as<double>(), in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), act[i], obs[i], un[i & 1],
+                                        pa[i & 1], stream_));
+            if (c_next < n_chunks && i == chunk_end[c_next]) {         // beliefs 1 .. i are written
+                if ((rc = queue_copy(c_next))) return rc;
+                ++c_next;
+            }
+        }
+        if (!two_kernels) {
+            HIPCHK(launch_walk_finish<T>(un[(n - 1) & 1], pa[(n - 1) & 1], mv, rows + (size_t)n * S_, dst + (size_t)(n - 1) * S_pad_, stream_));
+            while (c_next < n_chunks) {
+                if ((rc = queue_copy(c_next))) return rc;
                 ++c_next;
             }
         }
