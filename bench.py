@@ -1,15 +1,27 @@
-"""Headline benchmark: alpha-vector backups / second at |S|=30000, |B|=1024 per GPU.
+"""Headline benchmark: alpha-vector backups / second at |S|=30000, |B|=1024 per GPU (SURVEY.md 8d).
 
     python bench.py --gpus N --steps K --warmup W          (N=1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1)
 
-A step is ONE point-based backup (``pbvi_backup_run``: Gamma projection, score GEMM, argmax +
-fp64 tie refinement, action selection, alpha' assembly) of the resident belief block
-against the resident alpha set -- inputs are in HBM when the timed region starts, results
-stay in HBM.  With N>1 the beliefs are sharded (1024 per GPU, weak scaling) and each step
-ends with the RCCL all-gather of the new alpha rows.  Workload: the synthetic olfactory
-model of SURVEY.md 8d (BASELINE config "reachable-sparse", R=1 as in every large model of
-the reference).  Prints ONE JSON line on rank 0.
+A step is ONE point-based backup of SURVEY 8d's metric: ``pbvi_backup_run`` (Gamma projection, score GEMM, argmax +
+fp64 tie refinement, action selection, dedup, alpha' assembly) of the resident belief block against the resident
+alpha set, THEN its results -- the U distinct alpha' rows, the per-belief index into them and the actions -- copied
+into page-locked host buffers (``pbvi_backup_fetch_compact``), synchronised.  That is what the reference's own
+``backup_times`` contain: ``ValueFunction.__init__``'s ``tobytes()`` forces the device-to-host copy
+(src/mdp.py:667-669).  Inputs are in HBM when the timed region starts.  ``value`` = beliefs / MEDIAN step time
+(median of the timed calls); the mean over the whole timed region and the device-resident figure (results
+left in HBM) are reported beside it.
+
+With N>1 the beliefs are sharded and each step is the product path of ``dist.sharded_engine_step``: local backup, ONE
+all-gather of integers (per-belief index / action / keep + the keys of the distinct rows), global dedup, and every
+replica appends the globally distinct rows to its alpha store.  ``--scaling weak`` (default) keeps ``--beliefs`` per
+GPU; ``--scaling strong --beliefs-total 8192`` is BASELINE config 5 literally.
+
+Workload: the synthetic olfactory model of SURVEY.md 8d, reachable-sparse R=1 (BASELINE config "reachable-sparse CSR
+SpMM backup", as every large model of the reference).  The other BASELINE configurations that fit one GPU run in the
+same process and are reported under ``secondary``, each with its own roofline: ``c3_dense`` (dense projection as
+|A||O| MFMA GEMMs over densified T.O, every tile multiplied), ``c4_f64`` (the reference's precision), ``c4_r5``
+(stochastic moves, 5 reachable states).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -28,6 +40,7 @@ if REPO not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F64_MFMA_TFLOPS = 78.6       # MI355X_MICROARCH.md: v_mfma_f64_16x16x4_f64, dense
 PEAK_HBM_GBS = 8000.0
+STAGES = ('ms_total', 'ms_project', 'ms_score', 'ms_argmax', 'ms_refine', 'ms_action', 'ms_assemble')
 
 
 def cpu_baseline(m, alpha, beliefs, sample: int):
@@ -51,12 +64,98 @@ def cpu_baseline(m, alpha, beliefs, sample: int):
                       f'{cores} schedulable cores, OpenBLAS threads {blas_threads}'}
 
 
+class HostResults:
+    """Page-locked destination of one step's results (pbvi_host_alloc): U rows (room for B), index, actions."""
+
+    def __init__(self, eng, B: int):
+        from pomdp_pbvi_exploration_amd.engine import PinnedBuffer
+        item = 4 if eng.dtype == 'f32' else 8
+        self.buf = PinnedBuffer(B * eng.S * item + 2 * B * 4 + 4096)
+        self.rows = self.buf.carve((B, eng.S), eng.np_dtype)
+        self.index = self.buf.carve((B,), np.int32)
+        self.actions = self.buf.carve((B,), np.int32)
+
+    def close(self):
+        self.rows = self.index = self.actions = None
+        self.buf.close()
+
+
+def gemm_roofline(stats, dtype: str, mode: str):
+    """Roofline of the dominant kernel from the engine's per-call stats (HIP events on the engine's stream)."""
+    if mode == 'dense':     # the projection GEMMs dominate
+        ms = float(np.mean([s['ms_project_gemm'] for s in stats]))
+        pf, pfe = stats[0]['project_flops'], stats[0]['project_flops_executed']
+        ach = pfe / (ms * 1e-3) / 1e12
+        return {'bound': 'mfma', 'kernel': 'k_gemm_nt_f32_mfma (dense projection alpha x D_ao^T, batched over (a,o))',
+                'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                'traffic': None, 'flops_per_launch': pfe, 'ms_per_launch': ms, 'dense_flops_per_launch': pf}
+    ms = float(np.mean([s['ms_score'] for s in stats]))
+    flops, dense = stats[0]['score_flops_executed'], stats[0]['score_flops']
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == 'f32' else PEAK_F64_MFMA_TFLOPS
+    ach = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': ('k_gemm_nt_f32_streamk' if dtype == 'f32' else 'k_gemm_nt_f64_mfma') +
+                                       ' (belief x Gamma score GEMM, non-zero tiles)',
+            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+            'flops_per_launch': flops, 'ms_per_launch': ms, 'dense_flops_per_launch': dense,
+            'dense_equivalent_tflops': dense / (ms * 1e-3) / 1e12,
+            'tiles_run_over_dense': stats[0]['score_tiles_run'] / max(1, stats[0]['score_tiles_dense'])}
+
+
+def timed_steps(step, steps: int, warmup: int, fence):
+    """``warmup`` untimed steps, then ``steps`` timed ones between two fences.  Returns (per-step seconds, whole-region
+    seconds, list of what step() returned)."""
+    for _ in range(warmup):
+        step()
+    fence()
+    per, outs = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t = time.perf_counter()
+        outs.append(step())
+        per.append(time.perf_counter() - t)
+    fence()
+    return np.asarray(per), time.perf_counter() - t0, outs
+
+
+def measure_config(name, m, alpha, beliefs, dtype, mode, steps, warmup, fence, true_dense=False):
+    """One single-GPU configuration measured like the headline one (run + results to pinned host, median)."""
+    from pomdp_pbvi_exploration_amd.engine import Engine, debug_gemm_dense
+    prev = debug_gemm_dense(True) if true_dense else None
+    try:
+        eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype, mode=mode)
+        eng.set_alpha(alpha)
+        eng.set_beliefs(beliefs)
+        B = beliefs.shape[0]
+        host = HostResults(eng, B)
+
+        def step():
+            st = eng.run(m.gamma)
+            eng.fetch_compact_into(host.rows, host.index, host.actions)
+            return st
+
+        per, _, stats = timed_steps(step, steps, warmup, fence)
+        med = float(np.median(per))
+        out = {'workload': name, 'dtype': dtype, 'value': B / med, 'unit': 'backups/s', 'ms_per_step': med * 1e3,
+               'steps': steps, 'warmup': warmup, 'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': int(alpha.shape[0]), 'B': B,
+               'roofline': gemm_roofline(stats, dtype, mode),
+               'stage_ms': {k: float(np.mean([s[k] for s in stats])) for k in STAGES},
+               'unique_rows': int(stats[-1]['n_unique'])}
+        host.close()
+        eng.close()
+        return out
+    finally:
+        if prev is not None:
+            debug_gemm_dense(prev)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--beliefs', type=int, default=1024, help='beliefs per GPU')
+    ap.add_argument('--beliefs', type=int, default=1024, help='beliefs per GPU (weak scaling)')
+    ap.add_argument('--scaling', type=str, default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--beliefs-total', type=int, default=8192, help='beliefs over all GPUs (--scaling strong: BASELINE config 5)')
     ap.add_argument('--alphas', type=int, default=1024)
     ap.add_argument('--reach', type=int, default=1, choices=[1, 5], help='reachable states per (s,a)')
     ap.add_argument('--cpu-sample', type=int, default=1024, help='beliefs in the CPU baseline sample (0 = skip)')
@@ -67,6 +166,8 @@ def main():
     ap.add_argument('--mode', type=str, default='sparse', choices=['sparse', 'dense'],
                     help="projection: reachable-sparse ELL SpMM (BASELINE config 3, the reference's path) or dense "
                          "|A||O| MFMA GEMMs over densified T.O (config 2; 65 GB of matrices at S=30000)")
+    ap.add_argument('--secondary', type=str, default='auto', choices=['auto', 'none'],
+                    help="'auto': on one GPU with the default workload also measure c3_dense, c4_f64, c4_r5")
     args = ap.parse_args()
 
     import torch
@@ -78,6 +179,7 @@ def main():
             raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N')
     torch.cuda.set_device(local_rank)
     distributed = world > 1 or os.environ.get('PBVI_FORCE_DIST') == '1'   # the latter: rehearse the RCCL path on one GPU
+    dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -85,13 +187,22 @@ def main():
 
     from pomdp_pbvi_exploration_amd import synth
     from pomdp_pbvi_exploration_amd.engine import Engine
-    from pomdp_pbvi_exploration_amd.dist import EngineShard, gather_packed, gather_unique
+    from pomdp_pbvi_exploration_amd.dist import EngineShard, gather_unique, shard_bounds, sharded_engine_step
 
     H, W = (int(x) for x in args.grid.split('x'))
     m = synth.olfactory_model(H=H, W=W, R=args.reach)
     alpha, _ = synth.alpha_set(m, args.alphas)
-    B = args.beliefs
-    beliefs = synth.belief_points(m, B, start=rank * B)            # this rank's block of the global set
+    if args.scaling == 'strong':
+        n_total = args.beliefs_total
+        lo, hi, per = shard_bounds(n_total, world, rank)
+        if per % 64:
+            raise SystemExit('--beliefs-total / --gpus must be a multiple of 64 (the synthetic walks restart every 64 beliefs)')
+        B = hi - lo
+        beliefs = synth.belief_points(m, B, start=lo)
+    else:
+        B = args.beliefs
+        n_total = B * world
+        beliefs = synth.belief_points(m, B, start=rank * B)        # this rank's block of the global set
 
     eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=args.dtype, device=local_rank,
                  mode=args.mode)
@@ -99,88 +210,89 @@ def main():
     eng.set_alpha(alpha)
     eng.set_beliefs(beliefs)
     shard = EngineShard(eng, m.gamma)
-
-    exchange_rows = os.environ.get('PBVI_EXCHANGE') == 'rows'       # A-B only
-
-    def step():
-        if distributed:
-            # local backup, then ONE all-gather of integers: per-belief index / action / keep and the keys
-            # (a*, v*[a*, :]) of this rank's distinct alpha' rows; every rank rebuilds all rows from the keys against
-            # its replica of the alpha set (dist.gather_packed).  PBVI_EXCHANGE=rows moves the rows themselves instead.
-            if exchange_rows:
-                rows, count, idx, acts, keep, st = shard.run_resident_unique()
-                gather_unique(dist, None, rows, count, idx, acts, keep, B * world)
-            else:
-                meta, per, kw, st = shard.run_resident_packed()
-                gather_packed(dist, None, meta, per, kw, B * world, shard.assemble)
-            return st
-        return eng.run(m.gamma)
+    host = HostResults(eng, B)
+    exchange_rows = os.environ.get('PBVI_EXCHANGE') == 'rows'       # A-B only: move alpha' rows instead of keys
 
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    stats = [step() for _ in range(args.steps)]
-    fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def step():
+        if distributed:
+            if exchange_rows:
+                rows, count, idx, acts, keep, st = shard.run_resident_unique()
+                gather_unique(dist, None, rows, count, idx, acts, keep, n_total)
+                return st
+            # local backup -> one all-gather of integers -> global dedup -> every replica appends the distinct rows
+            eng.reset_store('alpha')                                # same store contents every step
+            return sharded_engine_step(shard, dist, None, n_total)[5]
+        st = eng.run(m.gamma)
+        eng.fetch_compact_into(host.rows, host.index, host.actions)   # U rows + index + actions -> pinned host, synchronised
+        return st
 
-    # PCIe-inclusive variant (host beliefs in, host alpha' out) -- reported beside, never as `value`
+    per_step, elapsed, stats = timed_steps(step, args.steps, args.warmup, fence)
+    if distributed:
+        t = torch.tensor(np.concatenate([[elapsed], per_step]), dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # slowest rank, step by step and over the region
+        elapsed, per_step = float(t[0].item()), t[1:].cpu().numpy()
+
+    # device-resident variant: the same backups with the results left in HBM
+    resident_ms = None
     host_ms = None
     if not distributed:
+        _, el2, _ = timed_steps(lambda: eng.run(m.gamma), args.steps, 2, fence)
+        resident_ms = el2 / args.steps * 1e3
+        # PCIe-inclusive variant: pageable host beliefs in, the expanded [B][S] alpha' matrix out to pageable memory
         t1 = time.perf_counter()
         for _ in range(3):
             eng.set_beliefs(beliefs)
             eng.run(m.gamma)
             eng.fetch()
+            eng.fetch_full()
         host_ms = (time.perf_counter() - t1) / 3 * 1e3
 
     if rank == 0:
         K = args.steps
-        ms_step = elapsed / K * 1e3
-        ms_score = float(np.mean([s['ms_score'] for s in stats]))
-        flops_dense = stats[0]['score_flops']                   # 2*B*S*A*O*V
-        flops = stats[0]['score_flops_executed']                # same, restricted to structurally non-zero tiles
-        achieved = flops / (ms_score * 1e-3) / 1e12
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_F64_MFMA_TFLOPS
-        gemm_name = ('k_gemm_nt_f32_streamk' if args.dtype == 'f32' else 'k_gemm_nt_f64_mfma')
+        med = float(np.median(per_step))
+        sparse = args.mode == 'sparse'
         out = {
-            'metric': 'alpha-vector backups/sec', 'value': B * world * K / elapsed, 'unit': 'backups/s',
-            'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'olfactory-{m.S} {"reachable-sparse" if args.mode == "sparse" else "dense-projection"} R={m.R} backup (S={m.S}, A={m.A}, O={m.O}), '
-                                   f'V={args.alphas} alpha-vectors, B={B} beliefs per GPU',
-                       'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': args.alphas, 'B_per_gpu': B,
-                       'parallelism': (f'belief-sharded x{world}, 1 all-gather of ' + ('alpha rows' if exchange_rows else 'row keys (rows rebuilt per rank)')) if distributed else 'single GPU'},
-            'roofline': {'bound': 'mfma', 'kernel': f'{gemm_name} (belief x Gamma score GEMM, non-zero tiles)',
-                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': None,
-                         'flops_per_launch': flops, 'ms_per_launch': ms_score,
-                         'dense_flops_per_launch': flops_dense,
-                         'dense_equivalent_tflops': flops_dense / (ms_score * 1e-3) / 1e12,
-                         'tiles_run_over_dense': stats[0]['score_tiles_run'] / max(1, stats[0]['score_tiles_dense'])},
-            'stage_ms': {k: float(np.mean([s[k] for s in stats])) for k in
-                         ('ms_total', 'ms_project', 'ms_score', 'ms_argmax', 'ms_refine', 'ms_action', 'ms_assemble')},
-            'unique_rows': int(stats[-1]['n_unique']), 'refined_pairs': int(stats[-1]['n_refined']), 'dead_pairs': int(stats[-1]['n_dead']),
-            'refined_actions': int(stats[-1]['n_refined_actions']), 'pairs': int(stats[-1]['n_pairs']), 'split_k': int(stats[-1]['split_k']),
+            'metric': 'alpha-vector backups/sec', 'value': n_total / med, 'unit': 'backups/s',
+            'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': med * 1e3, 'higher_is_better': True,
+            'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'olfactory-{m.S} {"reachable-sparse" if sparse else "dense-projection"} R={m.R} backup '
+                                   f'(S={m.S}, A={m.A}, O={m.O}), V={args.alphas} alpha-vectors, '
+                                   + (f'B={B} beliefs per GPU' if args.scaling == 'weak' else f'B={n_total} beliefs over {world} GPU(s)'),
+                       'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': args.alphas, 'B_per_gpu': B, 'B_total': n_total,
+                       'step': ('local backup + all-gather of ' + ('alpha rows' if exchange_rows else 'row keys')
+                                + ' + global dedup + append of the distinct rows to every replica\'s alpha store') if distributed
+                               else 'pbvi_backup_run + pbvi_backup_fetch_compact (U distinct rows, index, actions) into pinned host memory, synchronised',
+                       'parallelism': f'belief-sharded x{world}' if distributed else 'single GPU'},
+            'value_statistic': f'beliefs / median of the {K} timed steps (SURVEY 8d)',
+            'value_mean_over_region': n_total * K / elapsed, 'ms_per_step_mean': elapsed / K * 1e3,
+            'ms_per_step_min': float(per_step.min()) * 1e3, 'ms_per_step_max': float(per_step.max()) * 1e3,
+            'roofline': gemm_roofline(stats, args.dtype, args.mode) if stats and stats[0] else None,
+            'stage_ms': {k: float(np.mean([s[k] for s in stats])) for k in STAGES} if stats and stats[0] else None,
         }
+        if stats and stats[-1]:
+            st = stats[-1]
+            out.update({'unique_rows': int(st['n_unique']), 'refined_pairs': int(st['n_refined']), 'dead_pairs': int(st['n_dead']),
+                        'refined_actions': int(st['n_refined_actions']), 'pairs': int(st['n_pairs']), 'split_k': int(st['split_k'])})
+        if resident_ms is not None:
+            out['value_device_resident'] = B / (resident_ms * 1e-3)
+            out['ms_per_step_device_resident'] = resident_ms
         # HBM-side bytes per launch of the roofline kernel come from a separate rocprofv3 --pmc run
         # (FETCH_SIZE / WRITE_SIZE cannot be read inside this process); reported only for the exact
         # workload they were measured on.
         try:
-            with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')) as fh:
+            pmc_path = next(p for p in (os.path.join(REPO, 'profiles', f) for f in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'))
+                            if os.path.exists(p))
+            with open(pmc_path) as fh:
                 pmc = json.load(fh)
-            if (args.mode == 'sparse' and args.dtype == 'f32' and m.S == 30000 and m.R == 1 and args.alphas == 1024 and B == 1024):
+            if (sparse and args.dtype == 'f32' and m.S == 30000 and m.R == 1 and args.alphas == 1024 and B == 1024
+                    and out['roofline'] is not None):
                 out['roofline']['traffic'] = pmc['traffic_bytes']
-                out['roofline']['traffic_source'] = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes)'
+                out['roofline']['traffic_source'] = f'{os.path.relpath(pmc_path, REPO)} (rocprofv3 --pmc, separate passes)'
                 # the HBM-bound stages beside the GEMM: PMC bytes of the stage's main kernel / the stage's live time
                 # (the stage time also holds its small helper kernels, so these fractions are lower bounds)
                 other = pmc.get('other_kernels', {})
@@ -193,19 +305,36 @@ def main():
                                      'frac': gbs / PEAK_HBM_GBS, 'traffic': other[kern]['traffic_bytes'], 'ms': ms}
                 if sec:
                     out['stage_roofline'] = sec
-        except (OSError, KeyError, ValueError):
+        except (StopIteration, OSError, KeyError, ValueError):
             pass
-        if args.mode == 'dense':   # the projection GEMMs dominate: report them as the roofline kernel
-            ms_proj = float(np.mean([s['ms_project'] for s in stats]))
-            pf, pfe = stats[0]['project_flops'], stats[0]['project_flops_executed']
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'k_gemm_nt_f32_mfma (dense projection, batched over (a,o))',
-                               'achieved': pfe / (ms_proj * 1e-3) / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': pfe / (ms_proj * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-                               'flops_per_launch': pfe, 'ms_per_launch': ms_proj, 'dense_flops_per_launch': pf,
-                               'note': 'ms_project also holds the memset / scale-copy passes around the GEMM'}
         if host_ms is not None:
-            out['pcie_inclusive'] = {'ms_per_step': host_ms, 'value': B / (host_ms * 1e-3), 'unit': 'backups/s'}
-        if world == 1 and args.cpu_sample > 0:
+            out['pcie_inclusive'] = {'ms_per_step': host_ms, 'value': B / (host_ms * 1e-3), 'unit': 'backups/s',
+                                     'what': 'pageable beliefs uploaded + run + unique rows and the expanded [B][S] alpha\' matrix fetched to pageable memory'}
+    host.close()
+    eng.close()
+
+    # The other BASELINE configurations that fit one GPU, in the same process (single-GPU default run only)
+    default_workload = (world == 1 and not distributed and args.mode == 'sparse' and args.dtype == 'f32' and args.reach == 1
+                        and args.grid == '75x400' and args.alphas == 1024 and B == 1024)
+    if rank == 0 and args.secondary == 'auto' and default_workload:
+        sec = {}
+        try:
+            sec['c4_f64'] = measure_config('olfactory-30000 reachable-sparse R=1, fp64 engine (the reference\'s precision)',
+                                           m, alpha, beliefs, 'f64', 'sparse', 10, 3, fence)
+            m5 = synth.olfactory_model(H=H, W=W, R=5)
+            alpha5, _ = synth.alpha_set(m5, args.alphas)
+            beliefs5 = synth.belief_points(m5, B)
+            sec['c4_r5'] = measure_config('olfactory-30000 reachable-sparse R=5 (stochastic moves)', m5, alpha5, beliefs5,
+                                          'f32', 'sparse', 20, 5, fence)
+            del m5, alpha5, beliefs5
+            sec['c3_dense'] = measure_config('olfactory-30000 dense projection (|A||O| MFMA GEMMs over densified T.O, every '
+                                             'tile of both GEMMs multiplied), fp32', m, alpha, beliefs, 'f32', 'dense', 3, 1,
+                                             fence, true_dense=True)
+        except (MemoryError, RuntimeError) as e:          # a smaller card: report what was measured
+            sec['error'] = f'{type(e).__name__}: {e}'
+        out['secondary'] = sec
+    if rank == 0:
+        if world == 1 and not distributed and args.cpu_sample > 0:
             out['cpu_baseline'] = cpu_baseline(m, alpha, beliefs, min(args.cpu_sample, B))
         print(json.dumps(out), flush=True)
     if distributed:

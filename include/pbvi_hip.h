@@ -17,7 +17,10 @@
  *     PBVI_F32 -> float, PBVI_F64 -> double.  Indices are int32 (the binding narrows
  *     NumPy int64 after a range check).
  *   - Return value: 0 on success, negative pbvi_status otherwise; the message is
- *     available from pbvi_last_error() (thread-local).  The library never aborts.
+ *     available from pbvi_last_error() (thread-local).  The library itself never calls abort() or
+ *     exit(); a GPU memory fault, however, is raised by the HSA runtime as a process abort that no
+ *     library can intercept -- the engine validates every index array it is handed (ids, keys, actions,
+ *     observations) on the host before a kernel can use it for exactly that reason.
  *   - Host pointers are owned by the caller and only read/written during the call.
  *     Device memory is owned by the handle.  A handle is not thread-safe.
  *   - Every call is synchronous: results are in the output buffers on return.
@@ -25,6 +28,7 @@
 #ifndef PBVI_HIP_H
 #define PBVI_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -79,6 +83,8 @@ typedef struct pbvi_stats {
     int32_t formulation;    /* which operand was projected: 1 = alpha-vectors (Gamma), 2 = beliefs (pbvi_set_formulation) */
     int64_t n_refine_candidates; /* f32 engines: near-tie candidates listed over all refined triples (a triple that moves
                                     to the GEMM path -- every alpha row re-scored -- stops listing) */
+    double ms_project_gemm;  /* dense mode: the batched projection GEMM kernel alone (ms_project also holds the
+                                clears and the scale/copy pass around it); 0 in sparse mode */
 } pbvi_stats_t;
 
 /* Library / device queries. */
@@ -162,6 +168,21 @@ int64_t pbvi_backup_unique_count(const pbvi_engine_t* e);
 int pbvi_backup_fetch_unique(pbvi_engine_t* e, void* out_rows, int32_t* out_index);
 
 /*
+ * Everything ValueFunction.__init__ needs of a backup (src/mdp.py:660-669 -- the `tobytes()` there is what makes
+ * the reference's own backup timing include the device-to-host copy), in ONE staged transfer and one
+ * synchronisation: out_rows [U][S] T, out_index [B], out_action [B], out_best_alpha [B][A][O], out_keep [B]; any
+ * of them may be NULL.  Destinations in page-locked host memory (pbvi_host_alloc) are written by DMA directly;
+ * pageable ones go through the engine's pinned bounce buffer.  This is the call SURVEY 8d's metric is timed on.
+ */
+int pbvi_backup_fetch_compact(pbvi_engine_t* e, void* out_rows, int32_t* out_index, int32_t* out_action,
+                              int32_t* out_best_alpha, uint8_t* out_keep);
+
+/* Page-locked host memory for result buffers (hipHostMalloc / hipHostFree); NULL on failure.  The reference's
+ * counterpart is CuPy's pinned-memory pool behind `cp.asnumpy` (src/mdp.py:806-831, ValueFunction.to_cpu). */
+void* pbvi_host_alloc(size_t bytes);
+void pbvi_host_free(void* p);
+
+/*
  * The new alpha-vectors join the value function (ValueFunction.extend, src/mdp.py:763-779; append=True in
  * PBVI_Solver.backup, src/pomdp.py:1521-1522): append n of the last backup's distinct rows -- unique_idx[i] in
  * [0, U), in that order -- to the engine's alpha store, device to device.  Returns the store id of the first
@@ -182,7 +203,14 @@ int pbvi_backup_fetch_unique_keys(pbvi_engine_t* e, int32_t* out_keys);
 /* Everything a rank contributes to the exchange in one int32 buffer of 1 + 3B + B(1+O) entries (host or device):
  *   [0] U | index [B] | actions [B] | keep [B] | keys of the U distinct rows, padded with zeros to [B][1+O]. */
 int pbvi_backup_fetch_exchange(pbvi_engine_t* e, int32_t* out);
+/* Same with per-sized sections, per >= B (= ceil(B_total / ranks) of a sharded run): 1 + 3 per + per (1+O) entries,
+ * zeros behind the B valid ones, so every rank of a ragged split sends a message of the same length. */
+int pbvi_backup_fetch_exchange_padded(pbvi_engine_t* e, int64_t per, int32_t* out);
 int pbvi_assemble_rows(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows);
+/* pbvi_assemble_rows whose rows also join the alpha store (ValueFunction.extend on every replica of a sharded
+ * backup, src/pomdp.py:1521-1522 / src/mdp.py:763-779): returns the store id of the first of the n appended rows,
+ * or a negative error code.  out_rows (host or device, [n][S] T) may be NULL. */
+int64_t pbvi_assemble_rows_store(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows);
 
 /*
  * Device addresses of the last run's results, for the multi-GPU layer to hand to
@@ -320,6 +348,11 @@ int pbvi_set_tie_window(pbvi_engine_t* e, double rel);
  * allocation is filled with 0xFF bytes (NaN floats, -1 indices), so a read of memory the engine never
  * wrote fails the parity tests instead of hiding behind zero-filled pages.  Returns the previous state. */
 int pbvi_debug_poison(int enable);
+
+/* Benchmark / debug: list every K tile of every GEMM tile pair, zero or not -- the "dense backup" configuration of
+ * BASELINE.json is measured this way (results are unchanged: skipped tiles only ever add +0).  Also enabled by
+ * PBVI_GEMM_DENSE=1 in the environment.  Process-wide; returns the previous state. */
+int pbvi_debug_gemm_dense(int enable);
 
 /* Bytes of device memory currently held by the handle. */
 int64_t pbvi_device_bytes(const pbvi_engine_t* e);

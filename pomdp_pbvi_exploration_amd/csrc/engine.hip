@@ -112,6 +112,15 @@ static bool is_device_pointer(const void* ptr) {
     }
     return attr.type == hipMemoryTypeDevice;
 }
+// true iff ptr is page-locked host memory the DMA engines can write directly (hipHostMalloc / pbvi_host_alloc)
+static bool is_pinned_host_pointer(const void* ptr) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
 
 // keys of the unique rows of the last backup: key[u] = (a*, v*[a*, 0..O-1]) of the u-th distinct (a*, v*) pair
 __global__ void k_gather_keys(int U, int A, int O, const int32_t* __restrict__ uniq, const int32_t* __restrict__ action,
@@ -125,16 +134,25 @@ __global__ void k_gather_keys(int U, int A, int O, const int32_t* __restrict__ u
 
 // everything a rank contributes to the exchange, in one int32 buffer:
 //   [0] U | [1, 1+B) index | [1+B, 1+2B) action | [1+2B, 1+3B) keep | [1+3B, 1+3B+B*(1+O)) keys of the U distinct rows (rest 0)
-__global__ void k_pack_exchange(int B, int U, int A, int O, const int32_t* __restrict__ inv, const int32_t* __restrict__ action,
+// `per` >= B is the common block size of a sharded run (ceil(B_total / ranks)): the message has per-sized sections so
+// that every rank sends the same number of integers; entries of beliefs >= B are 0.
+__global__ void k_pack_exchange(int B, int per, int U, int A, int O, const int32_t* __restrict__ inv, const int32_t* __restrict__ action,
                                 const uint8_t* __restrict__ keep, const int32_t* __restrict__ uniq,
                                 const int32_t* __restrict__ best_v, int32_t* __restrict__ out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c == 0) out[0] = U;
-    if (c >= B) return;
+    if (c >= per) return;
+    int32_t* k = out + 1 + 3 * (int64_t)per + (int64_t)c * (1 + O);
+    if (c >= B) {
+        out[1 + c] = 0;
+        out[1 + per + c] = 0;
+        out[1 + 2 * per + c] = 0;
+        for (int o = 0; o <= O; ++o) k[o] = 0;
+        return;
+    }
     out[1 + c] = inv[c];
-    out[1 + B + c] = action[c];
-    out[1 + 2 * B + c] = keep[c];
-    int32_t* k = out + 1 + 3 * (int64_t)B + (int64_t)c * (1 + O);
+    out[1 + per + c] = action[c];
+    out[1 + 2 * per + c] = keep[c];
     if (c < U) {
         const int b = uniq[c], a = action[b];
         k[0] = a;
@@ -316,9 +334,11 @@ class EngineBase {
     virtual int device_results(void** d_alpha, int32_t** d_action, uint8_t** d_keep) = 0;
     virtual int64_t unique_count() const = 0;
     virtual int fetch_unique(void* out_rows, int32_t* out_index) = 0;
+    virtual int fetch_compact(void* out_rows, int32_t* out_index, int32_t* out_action, int32_t* out_best, uint8_t* out_keep) = 0;
     virtual int fetch_unique_keys(int32_t* out_keys) = 0;
-    virtual int fetch_exchange(int32_t* out) = 0;
+    virtual int fetch_exchange(int32_t* out, int64_t per) = 0;
     virtual int assemble_keys(double gamma, int64_t n, const int32_t* keys, void* out_rows) = 0;
+    virtual int64_t assemble_keys_store(double gamma, int64_t n, const int32_t* keys, void* out_rows) = 0;
     virtual int prune_dominated(uint8_t* keep) = 0;
     virtual int value_max(double* out_value, int32_t* out_index) = 0;
     virtual int value_max_store(int64_t n, double* out_value, int32_t* out_index) = 0;
@@ -399,6 +419,7 @@ class EngineT : public EngineBase {
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_lists_ = nullptr;
     GemmPlan plan_ = {};
     hipEvent_t ev_[9] = {};
+    hipEvent_t ev_pg_[2] = {};                       // around the dense projection's GEMM kernel
     bool have_result_ = false, res_sorted_ = false;
     int64_t res_B_ = 0;
 
@@ -416,6 +437,8 @@ class EngineT : public EngineBase {
         for (DevBuf* b : all) b->release();
         if (host_stage_) (void)hipHostFree(host_stage_);
         for (auto& e : ev_)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_pg_)
             if (e) (void)hipEventDestroy(e);
         if (ev_fork_) (void)hipEventDestroy(ev_fork_);
         if (ev_join_) (void)hipEventDestroy(ev_join_);
@@ -465,6 +488,7 @@ class EngineT : public EngineBase {
                 HIPCHK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
         }
         for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
+        for (auto& e : ev_pg_) HIPCHK(hipEventCreate(&e));
         HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_lists_, hipEventDisableTiming));
@@ -1104,6 +1128,22 @@ class EngineT : public EngineBase {
         return out_finish();
     }
 
+    // everything a caller of backup() needs, in one staged transfer and one synchronisation: the U distinct rows, the
+    // per-belief index into them, actions, best_alpha_ind and the keep mask (any destination may be NULL)
+    int fetch_compact(void* out_rows, int32_t* out_index, int32_t* out_action, int32_t* out_best, uint8_t* out_keep) override {
+        if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch_compact: no backup result resident");
+        HIPCHK(hipSetDevice(device_));
+        const size_t B = (size_t)res_B_;
+        int rc;
+        if ((rc = out_begin())) return rc;
+        if (out_rows && (rc = out_add(out_rows, out_.p, (size_t)res_unique_ * S_ * sizeof(T)))) return rc;
+        if (out_index && (rc = out_add(out_index, inv_.p, B * sizeof(int32_t)))) return rc;
+        if (out_action && (rc = out_add(out_action, res_action_, B * sizeof(int32_t)))) return rc;
+        if (out_best && (rc = out_add(out_best, res_best_, B * A_ * O_ * sizeof(int32_t)))) return rc;
+        if (out_keep && (rc = out_add(out_keep, keep_.p, B))) return rc;
+        return out_finish();
+    }
+
     // ---- device -> host results ------------------------------------------------------------------------------------ //
     // Results bound for ordinary (pageable) host memory go through one long-lived pinned buffer and a CPU memcpy:
     // the DMA never targets memory the driver has to register first.  Device destinations are copied directly.
@@ -1131,6 +1171,10 @@ class EngineT : public EngineBase {
         if (bytes == 0) return PBVI_OK;
         if (is_device_pointer(dst)) {
             HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToDevice, stream_));
+            return PBVI_OK;
+        }
+        if (is_pinned_host_pointer(dst)) {                   // caller's page-locked buffer: DMA straight into it
+            HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, stream_));
             return PBVI_OK;
         }
         const size_t need = (out_used_ + 255) / 256 * 256 + bytes;
@@ -1193,11 +1237,12 @@ class EngineT : public EngineBase {
     }
 
     // one buffer with everything this rank contributes to the multi-GPU exchange (layout: k_pack_exchange)
-    int fetch_exchange(int32_t* out) override {
+    int fetch_exchange(int32_t* out, int64_t per) override {
         if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch_exchange: no backup result resident");
         if (!out) FAIL(PBVI_EINVAL, "backup_fetch_exchange: NULL destination");
+        if (per < res_B_ || per > 0x7fffffff) FAIL(PBVI_EINVAL, "backup_fetch_exchange: per must be >= the number of beliefs of the last backup");
         HIPCHK(hipSetDevice(device_));
-        const size_t n = 1 + 3 * (size_t)res_B_ + (size_t)res_B_ * (1 + O_);
+        const size_t n = 1 + 3 * (size_t)per + (size_t)per * (1 + O_);
         int32_t* dst = out;
         const bool direct = is_device_pointer(out);
         if (!direct) {
@@ -1205,7 +1250,7 @@ class EngineT : public EngineBase {
             if (rc) return rc;
             dst = keys_tmp_.as<int32_t>();
         }
-        hipLaunchKernelGGL(k_pack_exchange, dim3((unsigned)((res_B_ + 255) / 256)), dim3(256), 0, stream_, (int)res_B_,
+        hipLaunchKernelGGL(k_pack_exchange, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream_, (int)res_B_, (int)per,
                            (int)res_unique_, A_, O_, inv_.as<int32_t>(), res_action_, keep_.as<uint8_t>(), uniq_.as<int32_t>(),
                            res_best_, dst);
         HIPCHK(hipGetLastError());
@@ -1239,6 +1284,49 @@ class EngineT : public EngineBase {
         HIPCHK(hipStreamSynchronize(stream_));
         if (h_bad) FAIL(PBVI_EINVAL, "assemble_keys: action or alpha index out of range");
         return PBVI_OK;
+    }
+
+    // Same, and the rows also join the alpha store (ids consecutive from the return value): the sharded backup's
+    // "every replica appends the same rows" step, device to device.  out_rows may be NULL.
+    int64_t assemble_keys_store(double gamma, int64_t n, const int32_t* keys, void* out_rows) override {
+        if (V_ <= 0) FAIL(PBVI_EINVAL, "assemble_rows_store: no alpha set resident");
+        if (n <= 0 || n > 65535 || !keys) FAIL(PBVI_EINVAL, "assemble_rows_store: bad arguments (1 <= n <= 65535)");
+        HIPCHK(hipSetDevice(device_));
+        int rc;
+        if ((rc = keys_tmp_.ensure((size_t)n * (1 + O_) * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = keys_act_.ensure((size_t)(n + 1) * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = keys_best_.ensure((size_t)n * A_ * O_ * sizeof(int32_t), &bytes_))) return rc;
+        T* dst = nullptr;
+        if ((rc = store_reserve(0, n, &dst))) return rc;
+        int* bad = keys_act_.as<int>() + n;
+        HIPCHK(hipMemcpyAsync(keys_tmp_.p, keys, (size_t)n * (1 + O_) * sizeof(int32_t), hipMemcpyDefault, stream_));
+        HIPCHK(hipMemsetAsync(bad, 0, sizeof(int), stream_));
+        hipLaunchKernelGGL(k_scatter_keys, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream_, (int)n, A_, O_, (int)V_,
+                           keys_tmp_.as<int32_t>(), keys_act_.as<int32_t>(), keys_best_.as<int32_t>(), bad);
+        HIPCHK(hipGetLastError());
+        if (S_pad_ > S_) HIPCHK(hipMemsetAsync(dst, 0, (size_t)n * S_pad_ * sizeof(T), stream_));   // pad columns stay zero
+        HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, view(), gamma, keys_act_.as<int32_t>(), keys_best_.as<int32_t>(), nullptr,
+                                  nullptr, (int)n, dst, S_pad_, stream_));
+        int h_bad = 0;
+        HIPCHK(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        if (out_rows) {
+            if (is_device_pointer(out_rows) || is_pinned_host_pointer(out_rows)) {
+                HIPCHK(hipMemcpy2DAsync(out_rows, (size_t)S_ * sizeof(T), dst, (size_t)S_pad_ * sizeof(T), (size_t)S_ * sizeof(T),
+                                        (size_t)n, hipMemcpyDefault, stream_));
+            } else {   // pageable destination: compact on the device, then through the pinned bounce buffer
+                if ((rc = keys_rows_.ensure((size_t)n * S_ * sizeof(T), &bytes_))) return rc;
+                HIPCHK(hipMemcpy2DAsync(keys_rows_.p, (size_t)S_ * sizeof(T), dst, (size_t)S_pad_ * sizeof(T), (size_t)S_ * sizeof(T),
+                                        (size_t)n, hipMemcpyDeviceToDevice, stream_));
+                if ((rc = out_begin())) return rc;
+                if ((rc = out_add(out_rows, keys_rows_.p, (size_t)n * S_ * sizeof(T)))) return rc;
+                if ((rc = out_finish())) return rc;
+            }
+        }
+        HIPCHK(hipStreamSynchronize(stream_));
+        if (h_bad) FAIL(PBVI_EINVAL, "assemble_rows_store: action or alpha index out of range");
+        const int64_t first = store_rows_[0];
+        store_rows_[0] = first + n;
+        return first;
     }
 
     int device_results(void** d_alpha, int32_t** d_action, uint8_t** d_keep) override {
@@ -1565,7 +1653,7 @@ int EngineT<T>::project_dense(double gamma) {
         HIPCHK(launch_gemm_nt_f32((const float*)alpha_.p, S_pad_, (const float*)dense_.p, S_pad_, prod_.as<float>(), pl,
                                   nzAlpha_.as<uint8_t>(), nzD_.as<uint8_t>(), 0, 0, S_, klistD_.as<int>(),
                                   kcountD_.as<int>(), nchunksD_.as<int>(), stream_, AO, rows_pad_s_ * (int64_t)S_pad_,
-                                  batch_stride));
+                                  batch_stride, nullptr, nullptr, nullptr, ev_pg_[0], ev_pg_[1]));
     } else {
         ld_prod = S_;
         batch_stride = Vt * S_;
@@ -1866,6 +1954,11 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         st->formulation = last_formulation_;
         st->n_dead = kF32 ? h[5] : 0;                        // counted by k_dead
         if (mode_ == PBVI_DENSE) {
+            if (kF32) {
+                float t = 0.f;
+                (void)hipEventElapsedTime(&t, ev_pg_[0], ev_pg_[1]);
+                st->ms_project_gemm = (double)t;
+            }
             st->project_flops = 2LL * AO * V_ * (int64_t)S_ * S_;
             st->project_flops_executed = st->project_flops;
             if (kF32) {
@@ -2131,7 +2224,15 @@ int pbvi_backup_fetch_unique_keys(pbvi_engine_t* e, int32_t* out_keys) {
 }
 int pbvi_backup_fetch_exchange(pbvi_engine_t* e, int32_t* out) {
     NEED(e);
-    return e->impl->fetch_exchange(out);
+    return e->impl->fetch_exchange(out, e->impl->beliefs_count());
+}
+int pbvi_backup_fetch_exchange_padded(pbvi_engine_t* e, int64_t per, int32_t* out) {
+    NEED(e);
+    return e->impl->fetch_exchange(out, per);
+}
+int64_t pbvi_assemble_rows_store(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows) {
+    NEED(e);
+    return e->impl->assemble_keys_store(gamma, n, keys, out_rows);
 }
 int pbvi_assemble_rows(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows) {
     NEED(e);
@@ -2146,6 +2247,25 @@ int pbvi_backup_fetch_unique(pbvi_engine_t* e, void* out_rows, int32_t* out_inde
     NEED(e);
     return e->impl->fetch_unique(out_rows, out_index);
 }
+int pbvi_backup_fetch_compact(pbvi_engine_t* e, void* out_rows, int32_t* out_index, int32_t* out_action,
+                              int32_t* out_best_alpha, uint8_t* out_keep) {
+    NEED(e);
+    return e->impl->fetch_compact(out_rows, out_index, out_action, out_best_alpha, out_keep);
+}
+void* pbvi_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        pbvi::set_error("pbvi_host_alloc: hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
+        return nullptr;
+    }
+    return p;
+}
+void pbvi_host_free(void* p) {
+    if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+}
+int pbvi_debug_gemm_dense(int enable) { return pbvi::set_gemm_force_dense(enable); }
 int pbvi_backup(pbvi_engine_t* e, const void* beliefs, int64_t B, double gamma, int flags, void* out_alpha,
                 int32_t* out_action, int32_t* out_best_alpha, uint8_t* out_keep, pbvi_stats_t* stats) {
     NEED(e);

@@ -383,6 +383,19 @@ __global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* _
     }
 }
 
+// Every K tile of every pair listed, zero or not (PBVI_GEMM_DENSE in the environment, or pbvi_debug_gemm_dense):
+// what BASELINE's "dense backup" configuration is measured with.  Results are unchanged (zero tiles add +0).
+static int g_force_dense = -1;
+int gemm_force_dense() {
+    if (g_force_dense < 0) g_force_dense = getenv("PBVI_GEMM_DENSE") ? (atoi(getenv("PBVI_GEMM_DENSE")) != 0) : 0;
+    return g_force_dense;
+}
+int set_gemm_force_dense(int enable) {
+    const int prev = gemm_force_dense();
+    g_force_dense = enable ? 1 : 0;
+    return prev;
+}
+
 int choose_chunk_len(int tiles_mn, int k_tiles) {
     if (const char* env = getenv("PBVI_GEMM_CHUNK")) {
         const int v = atoi(env);
@@ -430,12 +443,13 @@ static hipError_t set_lds_attr() {
 hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, const GemmPlan& pl,
                               const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
                               int* kcount, int* nchunks, hipStream_t stream, int batch, int64_t batch_stride_b,
-                              int64_t batch_stride_c, int* streamk_ws, hipStream_t list_stream, hipEvent_t list_event) {
+                              int64_t batch_stride_c, int* streamk_ws, hipStream_t list_stream, hipEvent_t list_event,
+                              hipEvent_t ev_before, hipEvent_t ev_after) {
     hipError_t e = set_lds_attr();
     if (e != hipSuccess) return e;
     if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
     const int pairs = pl.tiles_m * pl.tiles_n;
-    static const int force_dense = getenv("PBVI_GEMM_DENSE") ? atoi(getenv("PBVI_GEMM_DENSE")) : 0;   // debug / A-B only
+    const int force_dense = gemm_force_dense();          // benchmark / debug: list every tile (a true-dense GEMM)
     // The tile lists and the stream-K plan depend on the zero maps only, not on the operands' values: with a
     // list_stream they are built beside whatever `stream` is still doing (the Gamma projection) and the GEMM waits.
     hipStream_t ls = (list_stream != nullptr && list_event != nullptr) ? list_stream : stream;
@@ -470,10 +484,13 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
     const int64_t groups = ((int64_t)pl.tiles_n * pl.max_chunks + 7) / 8 * 8;
     const int64_t total = groups * pl.tiles_m;
     if (total <= 0 || total > 0x7fffffff) return hipErrorInvalidValue;
+    if (ev_before != nullptr && (e = hipEventRecord(ev_before, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_gemm_nt_f32_mfma, dim3((unsigned)total, batch), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B,
                        ldb, C, pl.ldc, pl.slab_stride, pl.tiles_m, pl.tiles_n, pl.k_tiles, pl.chunk_len, pl.max_chunks,
                        klist, kcount, batch_stride_b, batch_stride_c);
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (ev_after != nullptr && (e = hipEventRecord(ev_after, stream)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad, bool single_chunk) {

@@ -242,7 +242,7 @@ static hipError_t launch_gemm_nt_f64_t(const double* A, int lda, int M, const TB
     const int tiles_m = (M + D_BM - 1) / D_BM, tiles_n = (N + D_BN - 1) / D_BN;
     const int64_t pairs = (int64_t)tiles_m * tiles_n;
     if (pairs > 0x7fffffff) return hipErrorInvalidValue;
-    static const int force_dense = getenv("PBVI_GEMM_DENSE") ? atoi(getenv("PBVI_GEMM_DENSE")) : 0;   // debug / A-B only
+    const int force_dense = gemm_force_dense();          // benchmark / debug: every tile listed
     hipLaunchKernelGGL(k_build_klists_f64, dim3((unsigned)pairs), dim3(256), 0, stream, force_dense ? nullptr : nzA,
                        force_dense ? nullptr : nzB, G, v_group, N, tiles_m, kt32, klist, kcount);
     hipError_t e = hipGetLastError();

@@ -31,6 +31,8 @@ struct GemmPlan {
     bool streamk;      // persistent stream-K scheduler (score GEMMs); else one block per (pair, chunk)
     int nblocks;       // stream-K grid = CUs of the device
 };
+int set_gemm_force_dense(int enable);   // returns the previous setting (see gemm.hip)
+int gemm_force_dense();
 size_t streamk_workspace_ints(const GemmPlan& pl);   // ints of device workspace the stream-K plan needs
 // single_chunk: one K chunk per pair, i.e. slab 0 is the finished product (no split-K).
 GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad, bool single_chunk = false);
@@ -41,7 +43,8 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
                               const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
                               int* kcount, int* nchunks, hipStream_t stream, int batch = 1,
                               int64_t batch_stride_b = 0, int64_t batch_stride_c = 0, int* streamk_ws = nullptr,
-                              hipStream_t list_stream = nullptr, hipEvent_t list_event = nullptr);
+                              hipStream_t list_stream = nullptr, hipEvent_t list_event = nullptr,
+                              hipEvent_t ev_before = nullptr, hipEvent_t ev_after = nullptr);   // around the GEMM kernel (non-stream-K)
 // list_stream + list_event: build the tile lists / stream-K plan on that stream (they need the zero maps only) and
 // make `stream` wait for them before the GEMM kernel.
 // streamk_ws layout: prefix[pairs+1], start_pair[nblocks], first_block[pairs], plan[2] = {steps per block, total steps}

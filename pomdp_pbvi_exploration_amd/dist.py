@@ -1,16 +1,41 @@
 """Belief-sharded backup across the GPUs of one node.
 
-One process per GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI on the
-GPU box, ``gloo`` in the CPU tests).  Every rank holds the whole model and alpha set;
-the B beliefs are split into contiguous blocks of ceil(B/G) rows; after the local
-backup ONE all-gather moves the new alpha rows ``[B/G, S]`` (+ actions, keep mask) so
-every rank ends with the full ``[B, S]`` result in belief order and the replicas stay
-identical.  No other collective is on the data path.  The reference has no
-counterpart (single GPU, ``cupy.cuda.runtime.setDevice``).
+One process per GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI on the GPU box, ``gloo`` in the CPU
+tests).  Every rank holds the whole model and alpha set; the B beliefs are split into contiguous blocks of
+``per = ceil(B/G)`` rows; after the local backup ONE all-gather makes every rank hold the whole result, the ranks
+deduplicate it globally and every replica appends the same rows to its alpha store, so the replicas stay identical
+from one backup to the next.  No other collective is on the data path.  The reference has no counterpart (single
+GPU, ``cupy.cuda.runtime.setDevice``, ``Experiments/Olfactory Navigation/run_test.py:12``).
+
+Two exchanges:
+
+* **keys** (engine path, default): the alpha' row of a belief is a function of its key ``(a*, v*[a*, :])`` and of the
+  replicated alpha set and model only, so a rank contributes integers -- per-belief index / action / keep and the
+  keys of its distinct rows, one message of ``1 + 3 per + per (1+O)`` int32 (``pbvi_backup_fetch_exchange_padded``) --
+  and every rank rebuilds the globally distinct rows against its own replica (``pbvi_assemble_rows_store``: straight
+  into the alpha store, device to device).
+* **rows** (host NumPy path, and ``PBVI_EXCHANGE=rows`` for A/B): padded row blocks.
+
+Every message is padded to the common block size, so ragged splits (B % G != 0) and empty shards (B < G) send
+equally long messages; a rank without beliefs contributes a zero-count message instead of skipping the collective.
+
+``sharded_backup`` is what ``PBVI_Solver.backup`` calls when a process group with more than one rank is up
+(``active()``): same arguments, same return value as the single-process backup.
 """
 from __future__ import annotations
 
+import os
+import sys
+
 import numpy as np
+
+
+def active(group=None) -> bool:
+    """True when this process is one rank of a multi-rank ``torch.distributed`` job (and ``PBVI_NO_SHARD`` is unset)."""
+    if 'torch' not in sys.modules or os.environ.get('PBVI_NO_SHARD'):
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
 def shard_bounds(n: int, world: int, rank: int):
@@ -21,12 +46,27 @@ def shard_bounds(n: int, world: int, rank: int):
     return lo, hi, per
 
 
-class ShardedBackup:
-    """Runs a backup sharded over the ranks of ``group`` and all-gathers the results.
+def _valid_mask(n_total: int, world: int, per: int) -> np.ndarray:
+    """[world * per] bool: which slots of the per-padded concatenation are real beliefs."""
+    m = np.zeros(world * per, dtype=bool)
+    for r in range(world):
+        lo, hi, _ = shard_bounds(n_total, world, r)
+        m[r * per: r * per + (hi - lo)] = True
+    return m
 
-    ``local_backup(beliefs_local) -> (alpha_new[b,S], actions[b], keep[b])`` is the
-    per-rank work: on the GPU box it is the HIP engine writing straight into torch
-    CUDA tensors (``EngineShard``); the CPU tests pass the host NumPy path.
+
+def _carrier_device(dist, group):
+    """Where collective operands must live: CUDA for nccl (= RCCL), host for gloo."""
+    import torch
+    backend = str(dist.get_backend(group)).lower()
+    return torch.device('cuda', torch.cuda.current_device()) if 'nccl' in backend else torch.device('cpu')
+
+
+class ShardedBackup:
+    """Row exchange: runs a backup sharded over the ranks of ``group`` and all-gathers per-belief rows.
+
+    ``local_backup(beliefs_local) -> (alpha_new[b,S], actions[b], keep[b])`` is the per-rank work: the host NumPy
+    statements in the CPU path, the HIP engine writing into torch CUDA tensors (``EngineShard``) for ``PBVI_EXCHANGE=rows``.
     """
 
     def __init__(self, group=None):
@@ -37,11 +77,12 @@ class ShardedBackup:
         self.rank = dist.get_rank(group)
 
     def gather_rows(self, local_rows, local_actions, local_keep, n_total: int):
-        """All-gather per-rank blocks (padded to ceil(B/G) rows) and trim to ``n_total``."""
+        """All-gather per-rank blocks (padded to ceil(B/G) rows) and trim the padding of every block."""
         import torch
         lo, hi, per = shard_bounds(n_total, self.world, self.rank)
         S = local_rows.shape[1]
         dev = local_rows.device
+        assert local_rows.shape[0] == hi - lo, f'rank {self.rank} holds {local_rows.shape[0]} rows, its shard has {hi - lo}'
 
         def padded(t, shape):
             if t.shape[0] == per:
@@ -59,7 +100,10 @@ class ShardedBackup:
         self.dist.all_gather_into_tensor(all_rows, rows, group=self.group)
         self.dist.all_gather_into_tensor(all_acts, acts, group=self.group)
         self.dist.all_gather_into_tensor(all_keep, keep, group=self.group)
-        return all_rows[:n_total], all_acts[:n_total], all_keep[:n_total]
+        if self.world * per == n_total:
+            return all_rows, all_acts, all_keep
+        valid = torch.from_numpy(_valid_mask(n_total, self.world, per)).to(dev)
+        return all_rows[valid], all_acts[valid], all_keep[valid]
 
     def run(self, local_backup, beliefs_all: np.ndarray):
         """Shard ``beliefs_all`` [B,S] by rank, run the local backup, all-gather."""
@@ -74,31 +118,42 @@ class ShardedBackup:
         return self.gather_rows(rows, acts, keep, n)
 
 
-def gather_unique(dist, group, rows, count: int, index, actions, keep, n_total: int):
-    """All-gather of deduplicated per-rank results.  Each rank contributes ``count`` unique alpha' rows
-    (``rows[:count]``), its per-belief ``index`` into them, ``actions`` and ``keep``; blocks are padded to
-    the largest count; two ``all_gather_into_tensor`` calls in all (the per-belief integers and the row counts
-    travel together, then the rows).  Returns the concatenated
-    unique rows ``[sum U_r, S]``, the global index ``[B]`` (offset per rank), actions and keep in belief
-    order."""
+def _check_common_per(per: int, n_total: int, world: int):
+    want = -(-n_total // world)
+    if per != want:
+        raise ValueError(f'exchange block size {per} is not ceil({n_total}/{world}) = {want}: every rank must pad its '
+                         f'message to the common block size')
+
+
+def gather_unique(dist, group, rows, count: int, index, actions, keep, n_total: int, per: int = None):
+    """Row exchange of deduplicated per-rank results (``PBVI_EXCHANGE=rows``).  Each rank contributes ``count`` unique
+    alpha' rows (``rows[:count]``), its per-belief ``index`` into them, ``actions`` and ``keep`` (its own shard's
+    length; padded here to the common ``per = ceil(n_total / world)``); blocks of rows are padded to the largest
+    count; two ``all_gather_into_tensor`` calls in all.  Returns the concatenated unique rows ``[sum U_r, S]``, the
+    global index ``[n_total]`` (offset per rank), actions and keep in belief order."""
     import torch
     world = dist.get_world_size(group)
     dev = rows.device
     S = rows.shape[1]
-    per = index.shape[0]
+    if per is None:
+        per = -(-n_total // world)
+    _check_common_per(per, n_total, world)
+    b_loc = index.shape[0]
+    if b_loc > per:
+        raise ValueError(f'this rank holds {b_loc} beliefs, more than the block size {per}')
     # exchange 1: everything that is one int per belief, plus this rank's row count, in one message
-    meta = torch.empty(1 + 3 * per, dtype=torch.int32, device=dev)
+    meta = torch.zeros(1 + 3 * per, dtype=torch.int32, device=dev)
     meta[0] = count
-    meta[1:1 + per] = index
-    meta[1 + per:1 + 2 * per] = actions
-    meta[1 + 2 * per:] = keep
+    meta[1:1 + b_loc] = index
+    meta[1 + per:1 + per + b_loc] = actions
+    meta[1 + 2 * per:1 + 2 * per + b_loc] = keep
     flat = torch.empty(world * (1 + 3 * per), dtype=torch.int32, device=dev)     # gloo wants a flat output
     dist.all_gather_into_tensor(flat, meta, group=group)
     all_meta = flat.view(world, 1 + 3 * per)
     counts_h = all_meta[:, 0].tolist()
     # exchange 2: the unique rows, padded to the largest count so one all-gather suffices
     umax = max(max(counts_h), 1)
-    if count == umax:
+    if count == umax and rows.shape[0] >= umax:
         send = rows[:umax].contiguous()
     else:
         send = torch.zeros((umax, S), dtype=rows.dtype, device=dev)
@@ -107,66 +162,101 @@ def gather_unique(dist, group, rows, count: int, index, actions, keep, n_total: 
     dist.all_gather_into_tensor(all_rows, send, group=group)
     uniq = torch.cat([all_rows[r * umax: r * umax + counts_h[r]] for r in range(world)], dim=0)
     counts_d = all_meta[:, 0].to(torch.int64)                  # offsets on the device: no host-to-device copy in the step
-    gidx = all_meta[:, 1:1 + per].to(torch.int64) + (torch.cumsum(counts_d, 0) - counts_d)[:, None]
+    gidx = (all_meta[:, 1:1 + per].to(torch.int64) + (torch.cumsum(counts_d, 0) - counts_d)[:, None]).reshape(-1)
     all_act = all_meta[:, 1 + per:1 + 2 * per].reshape(-1).to(actions.dtype)
     all_keep = all_meta[:, 1 + 2 * per:].reshape(-1).to(keep.dtype)
-    return uniq, gidx.reshape(-1)[:n_total], all_act[:n_total], all_keep[:n_total]
+    if world * per != n_total:
+        valid = torch.from_numpy(_valid_mask(n_total, world, per)).to(dev)
+        gidx, all_act, all_keep = gidx[valid], all_act[valid], all_keep[valid]
+    return uniq, gidx, all_act, all_keep
 
 
-def pack_exchange(keys, count: int, index, actions, keep):
-    """The per-rank message of ``gather_packed`` from separate tensors (the engine writes it in one kernel,
-    ``pbvi_backup_fetch_exchange``): ``[U | index[B] | actions[B] | keep[B] | keys[B][1+O] (first U valid)]`` int32."""
+def pack_exchange(keys, count: int, index, actions, keep, per: int = None):
+    """The per-rank message of the key exchange from separate tensors (the engine writes it in one kernel,
+    ``pbvi_backup_fetch_exchange_padded``): ``[U | index[per] | actions[per] | keep[per] | keys[per][1+O] (first U
+    valid)]`` int32, zeros behind this rank's beliefs."""
     import torch
-    per = index.shape[0]
-    body = torch.zeros((per, keys.shape[1]), dtype=torch.int32, device=index.device)
-    body[:count] = keys[:count]
-    head = torch.tensor([count], dtype=torch.int32, device=index.device)
-    return torch.cat([head, index.to(torch.int32), actions.to(torch.int32), keep.to(torch.int32), body.reshape(-1)])
+    b_loc = index.shape[0]
+    per = b_loc if per is None else per
+    kw = keys.shape[1]
+    meta = torch.zeros(1 + 3 * per + per * kw, dtype=torch.int32, device=index.device)
+    meta[0] = count
+    meta[1:1 + b_loc] = index.to(torch.int32)
+    meta[1 + per:1 + per + b_loc] = actions.to(torch.int32)
+    meta[1 + 2 * per:1 + 2 * per + b_loc] = keep.to(torch.int32)
+    k0 = 1 + 3 * per
+    meta[k0:k0 + count * kw] = keys[:count].reshape(-1).to(torch.int32)
+    return meta
+
+
+def merge_exchange(all_meta: np.ndarray, per: int, key_width: int, n_total: int):
+    """Host side of the key exchange.  ``all_meta [world, 1 + 3 per + per kw]`` int32 (every rank's message) ->
+    ``(keys [n, kw], index [n_total], actions [n_total], keep [n_total])``: the globally distinct keys in order of
+    first occurrence over ranks, and per belief (global belief order) the position of its key in that list."""
+    world = all_meta.shape[0]
+    counts = all_meta[:, 0].astype(np.int64)
+    if np.any(counts < 0) or np.any(counts > per):
+        raise ValueError('corrupt exchange message: unique-row count out of range')
+    k0 = 1 + 3 * per
+    keys = np.concatenate([all_meta[r, k0:k0 + counts[r] * key_width].reshape(counts[r], key_width) for r in range(world)])
+    offs = np.cumsum(counts) - counts
+    idx = (all_meta[:, 1:1 + per].astype(np.int64) + offs[:, None]).reshape(-1)
+    act = all_meta[:, 1 + per:1 + 2 * per].reshape(-1)
+    keep = all_meta[:, 1 + 2 * per:1 + 3 * per].reshape(-1)
+    if world * per != n_total:
+        valid = _valid_mask(n_total, world, per)
+        idx, act, keep = idx[valid], act[valid], keep[valid]
+    if keys.shape[0] == 0:
+        return keys, idx, act.astype(np.int64), keep.astype(bool)
+    # equal keys on different ranks are the same row (replicated alpha set): keep the first, in concatenation order
+    _, first, inv = np.unique(keys, axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind='stable')
+    pos = np.empty_like(order)
+    pos[order] = np.arange(len(order))
+    return keys[first[order]], pos[inv.reshape(-1)][idx], act.astype(np.int64), keep.astype(bool)
+
+
+def exchange_keys(dist, group, meta, per: int, key_width: int, n_total: int):
+    """ONE ``all_gather_into_tensor`` of the per-rank int32 messages (``meta``: a torch tensor on the backend's
+    carrier device), then the host-side merge.  Returns ``merge_exchange``'s tuple."""
+    import torch
+    world = dist.get_world_size(group)
+    _check_common_per(per, n_total, world)
+    n_meta = 1 + 3 * per + per * key_width
+    if meta.shape[0] != n_meta:
+        raise ValueError(f'exchange message has {meta.shape[0]} entries, block size {per} needs {n_meta}')
+    flat = torch.empty(world * n_meta, dtype=torch.int32, device=meta.device)
+    dist.all_gather_into_tensor(flat, meta, group=group)
+    return merge_exchange(flat.view(world, n_meta).cpu().numpy(), per, key_width, n_total)
 
 
 def gather_packed(dist, group, meta, per: int, key_width: int, n_total: int, assemble):
-    """The exchange without rows.  A rank's alpha' rows are functions of their keys ``(a*, v*[a*, :])`` and of the
-    replicated alpha set and model, so ONE ``all_gather_into_tensor`` of integers suffices: per rank the packed
-    message of ``pack_exchange``.  Every rank then rebuilds all rows with
-    ``assemble(all_keys [sum U_r, 1+O]) -> [sum U_r, S]`` (``pbvi_assemble_rows``: byte-identical to the rows the
-    producing rank holds).  At C4 that is 28 KB per rank on the wire instead of 8 MB.
-    Returns ``(unique rows [sum U_r, S], global index [n_total], actions [n_total], keep [n_total])``."""
-    import torch
-    world = dist.get_world_size(group)
-    dev = meta.device
-    n_meta = meta.shape[0]
-    assert n_meta == 1 + 3 * per + per * key_width
-    flat = torch.empty(world * n_meta, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(flat, meta, group=group)
-    all_meta = flat.view(world, n_meta)
-    counts_h = all_meta[:, 0].tolist()
-    k0 = 1 + 3 * per
-    all_keys = torch.cat([all_meta[r, k0:k0 + counts_h[r] * key_width].view(counts_h[r], key_width) for r in range(world)], dim=0)
-    uniq = assemble(all_keys.contiguous())
-    counts_d = all_meta[:, 0].to(torch.int64)                  # offsets on the device: no host-to-device copy in the step
-    gidx = all_meta[:, 1:1 + per].to(torch.int64) + (torch.cumsum(counts_d, 0) - counts_d)[:, None]
-    all_act = all_meta[:, 1 + per:1 + 2 * per].reshape(-1)
-    all_keep = all_meta[:, 1 + 2 * per:1 + 3 * per].reshape(-1).to(torch.uint8)
-    return uniq, gidx.reshape(-1)[:n_total], all_act[:n_total], all_keep[:n_total]
+    """Key exchange + rows: ``assemble(keys [n, 1+O] int32 ndarray) -> rows [n, S]`` rebuilds the globally distinct
+    rows (``pbvi_assemble_rows`` / ``_store``: byte-identical to the rows the producing rank holds).  At C4 that is
+    28 KB per rank on the wire instead of 8 MB.  Returns ``(rows, index [n_total], actions, keep)``."""
+    keys, idx, act, keep = exchange_keys(dist, group, meta, per, key_width, n_total)
+    return assemble(keys), idx, act, keep
 
 
-def gather_keys(dist, group, keys, count: int, index, actions, keep, n_total: int, assemble):
+def gather_keys(dist, group, keys, count: int, index, actions, keep, n_total: int, assemble, per: int = None):
     """``gather_packed`` for callers that hold the pieces separately."""
-    return gather_packed(dist, group, pack_exchange(keys, count, index, actions, keep), index.shape[0], keys.shape[1],
+    world = dist.get_world_size(group)
+    per = -(-n_total // world) if per is None else per
+    return gather_packed(dist, group, pack_exchange(keys, count, index, actions, keep, per), per, keys.shape[1],
                          n_total, assemble)
 
 
 class EngineShard:
-    """Per-rank adapter: HIP engine results copied device-to-device into torch CUDA
-    tensors that RCCL can send (torch is only the carrier of device memory here)."""
+    """Per-rank adapter between the HIP engine and the collective: the engine writes its results into buffers the
+    backend can send (torch is only the carrier: CUDA tensors for RCCL, host tensors for gloo)."""
 
-    def __init__(self, engine, gamma: float, belief_dominance_prune: bool = False):
+    def __init__(self, engine, gamma: float, belief_dominance_prune: bool = False, carrier=None):
         import torch
         self.torch = torch
         self.engine = engine
         self.gamma = gamma
         self.prune = belief_dominance_prune
-        self.device = torch.device('cuda', engine.device)
+        self.device = carrier if carrier is not None else torch.device('cuda', engine.device)
         self._bufs = None
         self._keys = None
 
@@ -195,30 +285,121 @@ class EngineShard:
         self.engine.fetch_unique_into(rows.data_ptr(), idx.data_ptr())
         return rows, self.engine.unique_count, idx, acts, keep, stats
 
-    def run_resident_packed(self):
-        """For ``gather_packed``: the engine packs count, index, actions, keep and the keys of its distinct rows into one
-        device int32 buffer (``pbvi_backup_fetch_exchange``); no alpha' row leaves the engine.  Returns
-        ``(meta, B, 1+O, stats)``."""
+    def message(self, per: int):
+        """The int32 carrier tensor of one exchange message for block size ``per``."""
         t = self.torch
-        stats = self.engine.run(self.gamma, self.prune)
-        B, kw = self.engine.B, 1 + self.engine.O
-        n = 1 + 3 * B + B * kw
+        n = self.engine.exchange_size(per)
         if self._keys is None or self._keys.shape[0] != n:
-            self._keys = t.empty(n, dtype=t.int32, device=self.device)
-        self.engine.fetch_exchange_into(self._keys.data_ptr())
-        return self._keys, B, kw, stats
+            self._keys = t.zeros(n, dtype=t.int32, device=self.device)
+        return self._keys
+
+    def run_resident_packed(self, per: int = None):
+        """For the key exchange: run, then the engine packs count, index, actions, keep and the keys of its distinct rows
+        into one int32 buffer (``pbvi_backup_fetch_exchange_padded``); no alpha' row leaves the engine.  Returns
+        ``(meta, per, 1+O, stats)``."""
+        stats = self.engine.run(self.gamma, self.prune)
+        per = self.engine.B if per is None else per
+        meta = self.message(per)
+        self.engine.fetch_exchange_into(meta.data_ptr(), per)
+        return meta, per, 1 + self.engine.O, stats
+
+    def empty_message(self, per: int):
+        """What a rank without beliefs sends: a zero-count message of the common length."""
+        meta = self.message(per)
+        meta.zero_()
+        return meta, per, 1 + self.engine.O
 
     def assemble(self, keys):
-        """Rows for a device tensor of keys (device in, device out)."""
+        """Rows for keys (ndarray or tensor) against the resident alpha set, as a tensor on the carrier device."""
         t = self.torch
-        dt = t.float32 if self.engine.dtype == 'f32' else t.float64
-        out = t.empty((keys.shape[0], self.engine.S), dtype=dt, device=self.device)
-        # `keys` was produced on torch's stream; the engine reads it on its own (non-blocking) stream
-        t.cuda.current_stream(self.device).synchronize()
-        self.engine.assemble_rows_into(keys.data_ptr(), keys.shape[0], self.gamma, out.data_ptr())
-        return out
+        if t.is_tensor(keys):
+            keys = keys.cpu().numpy()
+        rows = self.engine.assemble_rows(np.ascontiguousarray(keys, dtype=np.int32), self.gamma)
+        return t.from_numpy(rows).to(self.device)
 
     def __call__(self, beliefs_local: np.ndarray):
         self.engine.set_beliefs(beliefs_local)
         rows, acts, keep, _ = self.run_resident()
         return rows, acts, keep
+
+
+def sharded_engine_step(shard: EngineShard, dist, group, n_total: int, store: bool = True):
+    """One sharded backup of the belief blocks RESIDENT on the ranks' engines (``bench.py --gpus N``): local backup,
+    key exchange, global dedup, and every replica appends the globally distinct rows to its alpha store
+    (``pbvi_assemble_rows_store``).  Returns ``(first store id, n distinct rows, index [n_total], actions, keep, stats)``."""
+    world = dist.get_world_size(group)
+    per = -(-n_total // world)
+    eng = shard.engine
+    if eng.B > 0:
+        meta, per, kw, stats = shard.run_resident_packed(per)
+    else:
+        meta, per, kw = shard.empty_message(per)
+        stats = {}
+    keys, idx, act, keep = exchange_keys(dist, group, meta, per, kw, n_total)
+    first = -1
+    if store and len(keys):
+        _, first = eng.assemble_rows_store(keys, shard.gamma, want_rows=False)
+    return first, len(keys), idx, act, keep, stats
+
+
+def _first_occurrence(idx: np.ndarray):
+    """Distinct values of ``idx`` in order of first occurrence, and where each first occurs."""
+    if idx.size == 0:
+        return idx[:0], idx[:0]
+    first = np.unique(idx, return_index=True)[1]
+    first.sort()
+    return idx[first], first
+
+
+def sharded_backup(solver, model, belief_set, value_function, belief_dominance_prune: bool, group=None):
+    """``PBVI_Solver.backup`` (``src/pomdp.py:1447-1519``, before the ``append`` union) with the beliefs sharded over
+    the ranks of ``group``.  Every rank calls it with identical arguments (replicated model, belief set and value
+    function) and gets the identical ``ValueFunction`` back: the single-process result."""
+    import torch
+    import torch.distributed as dist
+    from .mdp import AlphaVector, ValueFunction
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    beliefs = belief_set.belief_list
+    n_total = len(beliefs)
+    lo, hi, per = shard_bounds(n_total, world, rank)
+    carrier = _carrier_device(dist, group)
+
+    if not value_function.is_on_gpu:
+        # host mirror: the reference's NumPy statements on this rank's block, per-belief rows exchanged
+        S = model.state_count
+        if hi > lo:
+            rows, acts, keep = solver._backup_numpy(model, belief_set.belief_array[lo:hi], value_function.alpha_vector_array,
+                                                    belief_dominance_prune, return_mask=True)
+        else:
+            rows, acts, keep = np.zeros((0, S)), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=bool)
+        sb = ShardedBackup(group)
+        t_rows, t_acts, t_keep = sb.gather_rows(torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float64)).to(carrier),
+                                                torch.from_numpy(np.ascontiguousarray(acts, dtype=np.int64)).to(carrier),
+                                                torch.from_numpy(np.ascontiguousarray(keep, dtype=np.uint8)).to(carrier), n_total)
+        k = t_keep.cpu().numpy().astype(bool)
+        return ValueFunction(model, t_rows.cpu().numpy()[k], t_acts.cpu().numpy()[k])
+
+    eng = value_function.model.engine
+    eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values, owner=value_function)
+    shard = EngineShard(eng, solver.gamma, belief_dominance_prune, carrier=carrier)
+    if hi > lo:
+        if hi - lo > 65535:
+            raise NotImplementedError('sharded backup: at most 65535 beliefs per rank and call')
+        eng.sync_rows('belief', beliefs[lo:hi], lambda b: b.values)
+        meta, per, kw, _ = shard.run_resident_packed(per)
+    else:
+        meta, per, kw = shard.empty_message(per)
+    keys, idx, act, keep = exchange_keys(dist, group, meta, per, kw, n_total)
+    if belief_dominance_prune:
+        idx, act = idx[keep], act[keep]
+    used, first_pos = _first_occurrence(idx)              # the order the reference's byte-dedup produces
+    if used.size == 0:
+        return ValueFunction(value_function.model, [])
+    rows, first = eng.assemble_rows_store(keys[used], solver.gamma)
+    tag = eng.store_tag('alpha')
+    vectors = []
+    for k, (row, a) in enumerate(zip(rows, act[first_pos])):
+        v = AlphaVector(row, int(a))
+        v._dev = (tag, first + k)
+        vectors.append(v)
+    return ValueFunction(value_function.model, vectors)

@@ -32,6 +32,8 @@ EXPORTS = [
     'pbvi_backup_fetch_exchange', 'pbvi_backup_store_unique',
     'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact',
     'pbvi_belief_walk_keys', 'pbvi_backup_fetch_value_max',
+    'pbvi_backup_fetch_compact', 'pbvi_host_alloc', 'pbvi_host_free', 'pbvi_debug_gemm_dense',
+    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store',
 ]
 
 
@@ -47,7 +49,8 @@ class PbviStats(C.Structure):
                 ('n_unique', C.c_int64),
                 ('score_flops', C.c_int64), ('score_flops_executed', C.c_int64), ('score_tiles_dense', C.c_int64),
                 ('score_tiles_run', C.c_int64), ('project_flops', C.c_int64), ('project_flops_executed', C.c_int64),
-                ('split_k', C.c_int32), ('formulation', C.c_int32), ('n_refine_candidates', C.c_int64)]
+                ('split_k', C.c_int32), ('formulation', C.c_int32), ('n_refine_candidates', C.c_int64),
+                ('ms_project_gemm', C.c_double)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -84,6 +87,10 @@ def load_library(path: str = LIB_PATH):
         'pbvi_backup_fetch': (C.c_int, [vp, vp, i32p, i32p, u8p]),
         'pbvi_backup_unique_count': (C.c_int64, [vp]),
         'pbvi_backup_fetch_unique': (C.c_int, [vp, vp, i32p]),
+        'pbvi_backup_fetch_compact': (C.c_int, [vp, vp, i32p, i32p, i32p, u8p]),
+        'pbvi_host_alloc': (vp, [C.c_size_t]),
+        'pbvi_host_free': (None, [vp]),
+        'pbvi_debug_gemm_dense': (C.c_int, [C.c_int]),
         'pbvi_backup_store_unique': (C.c_int64, [vp, i32p, C.c_int64]),
         'pbvi_backup_device_results': (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         'pbvi_backup': (C.c_int, [vp, vp, C.c_int64, C.c_double, C.c_int, vp, i32p, i32p, u8p, sp]),
@@ -114,6 +121,8 @@ def load_library(path: str = LIB_PATH):
         'pbvi_backup_fetch_unique_keys': (C.c_int, [vp, vp]),
         'pbvi_assemble_rows': (C.c_int, [vp, C.c_double, C.c_int64, vp, vp]),
         'pbvi_backup_fetch_exchange': (C.c_int, [vp, vp]),
+        'pbvi_backup_fetch_exchange_padded': (C.c_int, [vp, C.c_int64, vp]),
+        'pbvi_assemble_rows_store': (C.c_int64, [vp, C.c_double, C.c_int64, vp, vp]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }
@@ -130,8 +139,50 @@ def debug_poison(enable: bool) -> bool:
     return bool(load_library().pbvi_debug_poison(1 if enable else 0))
 
 
+def debug_gemm_dense(enable: bool) -> bool:
+    """List every GEMM tile, zero or not (``pbvi_debug_gemm_dense``: BASELINE's "dense backup" measurement);
+    returns the previous setting."""
+    return bool(load_library().pbvi_debug_gemm_dense(1 if enable else 0))
+
+
 def device_count() -> int:
     return int(load_library().pbvi_device_count())
+
+
+class PinnedBuffer:
+    """Page-locked host memory from ``pbvi_host_alloc`` viewed as NumPy arrays: results fetched into it are written
+    by the GPU's DMA engine directly (no bounce buffer, no CPU copy)."""
+
+    def __init__(self, nbytes: int):
+        self._lib = load_library()
+        self.nbytes = int(nbytes)
+        self._p = self._lib.pbvi_host_alloc(self.nbytes)
+        if not self._p:
+            raise MemoryError((self._lib.pbvi_last_error() or b'').decode(errors='replace'))
+        self._raw = (C.c_uint8 * self.nbytes).from_address(self._p)
+        self._off = 0
+
+    def carve(self, shape, dtype) -> np.ndarray:
+        """Next 256-byte-aligned slice of the buffer as an array of ``shape`` / ``dtype``."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        off = (self._off + 255) // 256 * 256
+        if off + n > self.nbytes:
+            raise MemoryError('PinnedBuffer exhausted')
+        self._off = off + n
+        return np.frombuffer(self._raw, dtype=dtype, count=int(np.prod(shape)), offset=off).reshape(shape)
+
+    def close(self) -> None:
+        if getattr(self, '_p', None):
+            self._raw = None
+            self._lib.pbvi_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def mdp_value_iteration(reach_states: np.ndarray, reach_prob: np.ndarray, exp_reward: np.ndarray, v0: np.ndarray,
@@ -186,13 +237,18 @@ class HostArena:
     expansion) that was 15 stalled backups in 300 and a third of the walks.  With the results living in blocks that
     are mapped once per GiB, the address space does not change between GPU calls."""
 
-    BLOCK_BYTES = 1 << 30
+    BLOCK_BYTES = 1 << 30               # largest block
+    _MIN_BLOCK = 1 << 20
+    _POPULATE_MIN = 32 << 20            # smaller blocks are not worth a helper thread
     _POPULATE_CHUNK = 64 << 20
     _MADV_POPULATE_WRITE = 23           # Linux >= 5.14: fault the pages in (writable) without changing their contents
 
-    def __init__(self):
+    def __init__(self, first_block_bytes: int = 0):
+        """Blocks grow geometrically from ``first_block_bytes`` (a hint: ~100 result rows of the model) up to 1 GiB, so
+        a tiger-sized engine holds a MiB, not a GiB, and a row that outlives its engine pins a small block."""
         self._block = None
         self._off = 0
+        self._next = max(self._MIN_BLOCK, min(self.BLOCK_BYTES, 1 << max(0, int(first_block_bytes) - 1).bit_length()))
 
     @classmethod
     def _populate(cls, block: np.ndarray) -> None:
@@ -228,8 +284,14 @@ class HostArena:
             return np.empty(shape, dtype=dtype)              # rare and huge: not worth a block
         off = (self._off + 63) // 64 * 64
         if self._block is None or off + n > self._block.shape[0]:
-            self._block = np.empty(self.BLOCK_BYTES, dtype=np.uint8)
-            self._populate(self._block)
+            size = self._next
+            while size < 4 * n:
+                size *= 2
+            size = min(size, self.BLOCK_BYTES)
+            self._next = min(size * 2, self.BLOCK_BYTES)
+            self._block = np.empty(size, dtype=np.uint8)
+            if size >= self._POPULATE_MIN:
+                self._populate(self._block)
             off = 0
         self._off = off + n
         return self._block[off:off + n].view(dtype).reshape(shape)
@@ -267,6 +329,8 @@ class BackupResult:
 class Engine:
     """One model on one GPU: resident tables, alpha set and belief block."""
 
+    _serials = iter(range(1, 1 << 62))      # process-wide: a residency tag must never match a dead engine's (ids are reused)
+
     def __init__(self, S: int, A: int, O: int, R: int, reach_states: np.ndarray, rto: np.ndarray,
                  exp_rewards: np.ndarray, dtype: str = 'f32', mode: str = 'sparse', device: int = 0):
         lib = load_library()
@@ -291,12 +355,13 @@ class Engine:
                                       PBVI_F32 if dtype == 'f32' else PBVI_F64,
                                       PBVI_SPARSE if mode == 'sparse' else PBVI_DENSE))
         self._lib = lib
+        self.serial = next(Engine._serials)
         self._alpha_token = None
         self._store_epoch = {'alpha': 0, 'belief': 0}
         self._resident = {'alpha': None, 'belief': None}     # store ids of the working alpha set / belief block
         self.B = 0
         self._vmax_cache, self._vmax_epochs = [], None
-        self._arena = HostArena()
+        self._arena = HostArena(first_block_bytes=128 * self.S * 8)
         if dtype == 'f32' and np.asarray(rto).dtype == np.float64:
             # the belief walk returns fp64 belief values to the host containers: keep them independent of the
             # engine's arithmetic type by giving it the fp64 table too (a few MB)
@@ -371,7 +436,7 @@ class Engine:
 
     def store_tag(self, which: str):
         """What ``row_ids`` expects in ``obj._dev[0]`` for a row of this engine's store."""
-        return (id(self), which, self._store_epoch[which])
+        return (self.serial, which, self._store_epoch[which])
 
     # The working alpha set / belief block is a gathered copy of store rows (1.2 GB for 10^4 alpha rows): selecting
     # the ids that are already resident is skipped.  `_resident[which]` is dropped by everything else that rewrites
@@ -406,7 +471,7 @@ class Engine:
         store epoch.  ``owner`` (the ValueFunction / BeliefSet holding the list) caches the id array so the
         per-object walk happens once per container, not once per call; containers drop ``_dev_ids`` when they
         change."""
-        tag = (id(self), which, self._store_epoch[which])
+        tag = (self.serial, which, self._store_epoch[which])
         if owner is not None:
             c = getattr(owner, '_dev_ids', None)
             if c is not None and c[0] == tag and len(c[1]) == len(objects):
@@ -462,6 +527,22 @@ class Engine:
         for i0 in range(0, len(b_ids), self._BLOCK):
             self.select_beliefs(b_ids[i0:i0 + self._BLOCK])
             out[i0:i0 + self._BLOCK] = self.max_value_resident()[0]
+        return out
+
+    def best_alpha_of_store_rows(self, b_ids: np.ndarray) -> np.ndarray:
+        """``argmax_v b.alpha_v`` (first maximum, exact) of belief-store rows ``b_ids`` against the working alpha set: the
+        usefulness scan of the solve loop's |V| limiter (``src/pomdp.py:2350-2353``).  Most of the store's prefix wanted
+        (the solve loop: all of it): scored in place; else in gathered blocks."""
+        b_ids = np.asarray(b_ids, dtype=np.int32)
+        if len(b_ids) == 0:
+            return np.zeros(0, dtype=np.int64)
+        top = int(b_ids.max()) + 1
+        if 2 * len(b_ids) >= top:
+            return self.max_value_store(top)[1][b_ids].astype(np.int64)
+        out = np.empty(len(b_ids), dtype=np.int64)
+        for i0 in range(0, len(b_ids), self._BLOCK):
+            self.select_beliefs(b_ids[i0:i0 + self._BLOCK])
+            out[i0:i0 + self._BLOCK] = self.max_value_resident()[1]
         return out
 
     def seed_max_values(self, alpha_objects, belief_objects, alpha_values, belief_values, alpha_owner=None,
@@ -583,12 +664,31 @@ class Engine:
         act = np.empty(B, dtype=np.int32)
         best = np.empty((B, self.A, self.O), dtype=np.int32)
         keep = np.empty(B, dtype=np.uint8)
-        _check(self._lib.pbvi_backup_fetch_unique(self._h, _ptr(rows), index.ctypes.data_as(C.POINTER(C.c_int32))))
-        _check(self._lib.pbvi_backup_fetch(self._h, None, act.ctypes.data_as(C.POINTER(C.c_int32)),
-                                           best.ctypes.data_as(C.POINTER(C.c_int32)),
-                                           keep.ctypes.data_as(C.POINTER(C.c_uint8))))
+        i32p = C.POINTER(C.c_int32)
+        _check(self._lib.pbvi_backup_fetch_compact(self._h, _ptr(rows), index.ctypes.data_as(i32p), act.ctypes.data_as(i32p),
+                                                   best.ctypes.data_as(i32p), keep.ctypes.data_as(C.POINTER(C.c_uint8))))
         return BackupResult(rows, index.astype(np.int64), act.astype(np.int64), best.astype(np.int64),
                             keep.astype(bool), {})
+
+    def fetch_compact_into(self, rows: np.ndarray, index: np.ndarray, actions: np.ndarray, best=None, keep=None) -> int:
+        """Results of the last run into caller-owned arrays (``pbvi_backup_fetch_compact``; pinned arrays -- see
+        ``PinnedBuffer`` -- are written by DMA directly): the U distinct rows into ``rows[:U]``, ``index`` [B] int32,
+        ``actions`` [B] int32, optionally ``best`` [B,A,O] int32 and ``keep`` [B] uint8.  One synchronisation; returns U."""
+        U = int(self._lib.pbvi_backup_unique_count(self._h))
+        if U < 0:
+            raise ValueError('no backup result resident')
+        if rows.shape[0] < U or rows.shape[1] != self.S or rows.dtype != self.np_dtype or not rows.flags.c_contiguous:
+            raise ValueError(f'rows must be a C-contiguous [>= {U}, {self.S}] {self.dtype} array')
+        for name, a, shape, dt in (('index', index, (self.B,), np.int32), ('actions', actions, (self.B,), np.int32),
+                                   ('best', best, (self.B, self.A, self.O), np.int32), ('keep', keep, (self.B,), np.uint8)):
+            if a is not None and (a.shape != shape or a.dtype != dt or not a.flags.c_contiguous):
+                raise ValueError(f'{name} must be a C-contiguous {shape} {np.dtype(dt).name} array')
+        i32p = C.POINTER(C.c_int32)
+        _check(self._lib.pbvi_backup_fetch_compact(
+            self._h, _ptr(rows), index.ctypes.data_as(i32p), actions.ctypes.data_as(i32p),
+            best.ctypes.data_as(i32p) if best is not None else None,
+            keep.ctypes.data_as(C.POINTER(C.c_uint8)) if keep is not None else None))
+        return U
 
     def fetch_full(self) -> np.ndarray:
         """Per-belief alpha' matrix [B,S] expanded on the device (``pbvi_backup_fetch``'s out_alpha)."""
@@ -616,9 +716,37 @@ class Engine:
     def fetch_unique_keys_into(self, keys_ptr: int) -> None:
         _check(self._lib.pbvi_backup_fetch_unique_keys(self._h, C.c_void_p(keys_ptr)))
 
-    def fetch_exchange_into(self, ptr: int) -> None:
-        """``[U | index[B] | actions[B] | keep[B] | keys[B][1+O]]`` int32 at a raw (host or device) address."""
-        _check(self._lib.pbvi_backup_fetch_exchange(self._h, C.c_void_p(ptr)))
+    def fetch_exchange_into(self, ptr: int, per: int = None) -> None:
+        """``[U | index[per] | actions[per] | keep[per] | keys[per][1+O]]`` int32 at a raw (host or device) address;
+        ``per`` (default B) >= B is the common block size of a sharded run."""
+        if per is None:
+            _check(self._lib.pbvi_backup_fetch_exchange(self._h, C.c_void_p(ptr)))
+        else:
+            _check(self._lib.pbvi_backup_fetch_exchange_padded(self._h, int(per), C.c_void_p(ptr)))
+
+    def exchange_size(self, per: int) -> int:
+        """int32 entries of one rank's exchange message for block size ``per``."""
+        return 1 + 3 * per + per * (1 + self.O)
+
+    def assemble_rows_store(self, keys: np.ndarray, gamma: float, want_rows: bool = True):
+        """alpha' rows for ``keys [n, 1+O]`` against the resident alpha set, appended to the alpha store device to
+        device (``pbvi_assemble_rows_store``).  Returns ``(rows [n,S] or None, first store id)``."""
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        if k.ndim != 2 or k.shape[1] != 1 + self.O or k.shape[0] == 0:
+            raise ValueError(f'keys must be [n >= 1, {1 + self.O}]')
+        out = self._arena.empty((k.shape[0], self.S), self.np_dtype) if want_rows else None
+        first = int(self._lib.pbvi_assemble_rows_store(self._h, float(gamma), k.shape[0], _ptr(k),
+                                                       _ptr(out) if out is not None else None))
+        if first < 0:
+            _check(first)
+        return out, first
+
+    def assemble_rows_store_from(self, keys_ptr: int, n: int, gamma: float) -> int:
+        """Same for keys at a raw (host or device) address; rows stay on the device.  Returns the first store id."""
+        first = int(self._lib.pbvi_assemble_rows_store(self._h, float(gamma), int(n), C.c_void_p(keys_ptr), None))
+        if first < 0:
+            _check(first)
+        return first
 
     def assemble_rows(self, keys: np.ndarray, gamma: float) -> np.ndarray:
         """alpha' rows ``[n, S]`` for ``keys [n, 1+O]`` against the resident alpha set (``pbvi_assemble_rows``)."""
@@ -736,7 +864,7 @@ class Engine:
 
     def belief_tag(self):
         """Tag that marks an object as resident in this engine's belief store (see ``row_ids``)."""
-        return (id(self), 'belief', self._store_epoch['belief'])
+        return (self.serial, 'belief', self._store_epoch['belief'])
 
     def advance_beliefs(self, actions, observations, keep=None) -> int:
         """Simulator step on the resident block (``src/pomdp.py:3305-3329``): Bayes-update every belief with its

@@ -241,10 +241,18 @@ class Model:
             return pickle.load(fh)
 
     # -- residency ------------------------------------------------------- #
-    def to_gpu(self, dtype: str = 'f64', device: int = 0) -> 'Model':
-        """GPU twin bound to a HIP engine of the given arithmetic type."""
+    def to_gpu(self, dtype: str = 'f64', device: int = None) -> 'Model':
+        """GPU twin bound to a HIP engine of the given arithmetic type.  ``device`` defaults to ``LOCAL_RANK`` (one
+        process per GPU under ``torch.distributed.run``; the reference's drivers pick the card with
+        ``cupy.cuda.runtime.setDevice``, ``Experiments/Olfactory Navigation/run_test.py:12``), else 0."""
         if self.is_on_gpu:
             return self
+        if device is None:
+            import os
+            device = int(os.environ.get('LOCAL_RANK', 0))
+            if device > 0:
+                from .engine import device_count
+                device %= max(device_count(), 1)        # more ranks than cards (a rehearsal on a smaller box): share them
         if self._alt_model is None or self._alt_model._engine_dtype != dtype:
             from .engine import Engine          # raises if the HIP library is missing
             twin = object.__new__(self.__class__)

@@ -26,6 +26,7 @@ from .mdp import Solver as MDP_Solver
 from .mdp import RewardSet, _RowKey                          # noqa: F401
 from .mdp import SimulationHistory as MDP_SimulationHistory
 from .mdp import Simulation as MDP_Simulation
+from . import dist as _dist
 
 gpu_support = True
 
@@ -434,8 +435,14 @@ class PBVI_Solver(Solver):
     def backup(self, model: Model, belief_set: BeliefSet, value_function: ValueFunction,
                append: bool = False, belief_dominance_prune: bool = True) -> ValueFunction:
         """One point-based backup (``src/pomdp.py:1447-1524``): B beliefs x V
-        alpha-vectors -> at most B new alpha-vectors (+ union with the old set)."""
-        if value_function.is_on_gpu:
+        alpha-vectors -> at most B new alpha-vectors (+ union with the old set).
+
+        As one rank of a multi-rank ``torch.distributed`` job (one process per GPU) the beliefs are sharded over the
+        ranks, one all-gather makes every rank hold the whole result and every replica appends the same rows
+        (``dist.sharded_backup``); the return value is the single-process one on every rank."""
+        if _dist.active() and len(belief_set) > 0:
+            new_vf = _dist.sharded_backup(self, model, belief_set, value_function, belief_dominance_prune)
+        elif value_function.is_on_gpu:
             # Residency: every AlphaVector / Belief row is uploaded once into the engine's device stores; the
             # working sets are selected by id in list order (tie-breaks follow the host order), the device
             # runs the backup, and only the distinct new rows come back.
@@ -478,8 +485,10 @@ class PBVI_Solver(Solver):
             new_vf.extend(value_function)
         return new_vf
 
-    def _backup_numpy(self, model, b, alpha, belief_dominance_prune):
-        """Host path: the reference's array statements (``src/pomdp.py:1485-1515``)."""
+    def _backup_numpy(self, model, b, alpha, belief_dominance_prune, return_mask: bool = False):
+        """Host path: the reference's array statements (``src/pomdp.py:1485-1515``).  ``return_mask``: every belief's
+        row and action plus the belief-dominance mask, instead of the filtered rows (the sharded backup exchanges
+        per-belief results)."""
         V = alpha.shape[0]
         alpha_r = alpha[np.arange(V)[:, None, None, None], model.reachable_states[None, :, :, :]]
         gamma_aovs = self.gamma * np.einsum('saor,vsar->aovs', model.reachable_transitional_observation_table, alpha_r)
@@ -489,10 +498,14 @@ class PBVI_Solver(Solver):
         alpha_a = model.expected_rewards_table.T + np.sum(per_o, axis=2)
         acts = np.argmax(np.einsum('bas,bs->ba', alpha_a, b), axis=1)
         rows = np.take_along_axis(alpha_a, acts[:, None, None], axis=1)[:, 0, :]
+        better = np.ones(len(acts), dtype=bool)
         if belief_dominance_prune:
             new_val = np.sum(b * rows, axis=1)
             old_val = np.max(np.matmul(b, alpha.T), axis=1)
             better = new_val > old_val
+        if return_mask:
+            return rows, acts, better
+        if belief_dominance_prune:
             rows, acts = rows[better], acts[better]
         return rows, acts
 
@@ -730,6 +743,34 @@ class PBVI_Solver(Solver):
             new = np.max(np.matmul(b, new_value_function.alpha_vector_array.T), axis=1)
         return float(np.max(np.abs(new - old)))
 
+    def _limit_value_function(self, model, value_function: ValueFunction, belief_set: BeliefSet,
+                              max_belief_growth: int) -> ValueFunction:
+        """The |V| limiter of the solve loop (``src/pomdp.py:2347-2365``): alpha-vectors that are the best one for no
+        belief of the set are "unuseful"; ``max_belief_growth`` of them, drawn with replacement and weights falling
+        linearly with their position, are deleted.  The usefulness scan -- ``argmax_v`` of the V x B_total score matrix --
+        runs on the engine when the value function is on the GPU (``pbvi_value_max_store`` over the belief store in
+        place, first maximum, exact indices); the draw stays ``np.random.choice`` on the host, as in the reference."""
+        n = len(value_function)
+        if value_function.is_on_gpu:
+            eng = value_function.model.engine
+            beliefs = belief_set.belief_list
+            eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values, owner=value_function)
+            b_ids = eng.row_ids('belief', beliefs, lambda b: b.values, owner=belief_set)
+            best = eng.best_alpha_of_store_rows(b_ids)
+        else:
+            best = np.argmax(np.matmul(value_function.alpha_vector_array, belief_set.belief_array.T), axis=0)
+        useful = np.unique(best)
+        useless = np.delete(np.arange(n), useful)
+        w = np.arange(len(useless))[::-1]
+        drop = np.random.choice(useless, size=max_belief_growth, p=w / np.sum(w))
+        self._last_useful_count = int(useful.shape[0])
+        if value_function.is_on_gpu:
+            # on the objects: the surviving vectors keep their rows in the device store, nothing is re-stacked
+            gone = set(int(i) for i in drop)
+            return ValueFunction(value_function.model, [v for i, v in enumerate(value_function.alpha_vector_list) if i not in gone])
+        return ValueFunction(model, np.delete(value_function.alpha_vector_array, drop, axis=0),
+                             np.delete(value_function.actions, drop))
+
     def solve(self, model: Model, expansions: int, full_backup: Union[bool, None] = None, update_passes: int = 1,
               max_belief_growth: int = 10, initial_belief=None, initial_value_function=None, prune_level: int = 1,
               prune_interval: int = 10, limit_value_function_size: int = -1, use_gpu: bool = False,
@@ -794,13 +835,7 @@ class PBVI_Solver(Solver):
                         history.add_prune_step((datetime.now() - t0).total_seconds(), len(value_function) - before)
 
                     if limit_value_function_size >= 0 and len(value_function) > limit_value_function_size:
-                        scores = np.matmul(value_function.alpha_vector_array, belief_set.belief_array.T)
-                        useful = np.unique(np.argmax(scores, axis=0))
-                        useless = np.delete(np.arange(len(value_function)), useful)
-                        w = np.arange(len(useless))[::-1]
-                        drop = np.random.choice(useless, size=max_belief_growth, p=w / np.sum(w))
-                        value_function = ValueFunction(model, np.delete(value_function.alpha_vector_array, drop, axis=0),
-                                                       np.delete(value_function.actions, drop))
+                        value_function = self._limit_value_function(model, value_function, belief_set, max_belief_growth)
 
                     max_change = self.compute_change(value_function, old_value_function, belief_set)
                     history.add_backup_step(backup_time, max_change, value_function)

@@ -498,7 +498,71 @@ def gen_hsvi():
     np.savez_compressed(os.path.join(HERE, 'hsvi_and_rollouts.npz'), **out)
 
 
+def gen_prune():
+    """``ValueFunction.prune(level=2)`` of the reference (src/mdp.py:857-866) on a seeded alpha set at S=600 that holds
+    undominated rows, rows dominated by one other row, rows dominating others, a pair that differs only in the sign of
+    a zero (different bytes -- both survive the constructor's dedup -- but each is >= the other, so BOTH go) and rows
+    equal to another one except in a single state.  Stored: the input rows / actions and what the reference kept."""
+    m = synth.olfactory_model(H=15, W=40, R=1)
+    base, acts = synth.alpha_set(m, 24)
+    u = synth.uniform01(99, np.arange(base.size, dtype=np.uint64)).reshape(base.shape)
+    rows = [base]
+    rows.append(base[:6] - 0.01 * u[:6])                       # strictly below one other row everywhere -> dominated
+    rows.append(base[6:10] + 0.02 * u[6:10])                   # strictly above -> their originals are dominated
+    bump = base[10:14].copy()
+    bump[np.arange(4), [3, 77, 300, 599]] += 0.5               # above the original in one state, equal elsewhere
+    rows.append(bump)
+    dip = base[14:16].copy()
+    dip[np.arange(2), [5, 410]] -= 0.25                        # below in one state, equal elsewhere -> dominated
+    rows.append(dip)
+    zpair = np.round(base[16:17], 1)
+    zpair[0, 7] = 0.0
+    znegv = zpair.copy()
+    znegv[0, 7] = -0.0                                         # same values, different bytes
+    rows += [zpair, znegv]
+    alpha = np.concatenate(rows).astype(np.float32).astype(np.float64)
+    actions = (synth.splitmix64(3, np.arange(alpha.shape[0], dtype=np.uint64)) % np.uint64(m.A)).astype(np.int64)
+    model = ref_model_from_synth(m)
+    vf = quiet(ref.ValueFunction, model, alpha, actions)
+    assert len(vf) == alpha.shape[0], 'the constructor must not have removed anything (all rows differ in bytes)'
+    quiet(vf.prune, 2)
+    kept_rows, kept_actions = np.asarray(vf.alpha_vector_array), np.asarray(vf.actions)
+    kept = np.array([int(np.flatnonzero([r.tobytes() == k.tobytes() for r in alpha])[0]) for k in kept_rows])
+    assert np.array_equal(alpha[kept], kept_rows) and np.array_equal(actions[kept], kept_actions)
+    mask = orc.prune_dominated_mask(alpha)
+    assert np.array_equal(np.flatnonzero(mask), kept), 'oracle prune differs from the reference'
+    n = alpha.shape[0]
+    assert not mask[n - 1] and not mask[n - 2], 'the +0 / -0 pair dominates each other'
+    np.savez_compressed(os.path.join(HERE, 'prune_level2.npz'), alpha=alpha, actions=actions, kept=kept)
+    print(f'[golden] prune_level2.npz: {n} rows -> reference keeps {len(kept)}')
+
+
+def gen_limiter():
+    """The |V| limiter of the reference's solve loop (src/pomdp.py:2347-2365): seeded FSVI solve of the S=600 olfactory
+    model with ``limit_value_function_size`` set, so most backups are followed by the usefulness scan
+    (matmul + argmax + unique) and the weighted random deletion.  Stored: belief-count and |V| trajectories, per-backup
+    changes, the final alpha set.  The deletion draws from np.random, so the trajectory only reproduces if every
+    ``useful`` set along the way is the reference's."""
+    import random as pyrandom
+    m = synth.olfactory_model(H=15, W=40, R=1, f32=False)
+    cfg = dict(expansions=14, max_belief_growth=8, limit_value_function_size=24)
+    model = quiet(ref.Model, states=m.S, actions=m.A, observations=m.O, reachable_states=m.reachable_states,
+                  observation_table=m.observation_table, end_states=[m.goal], start_probabilities=list(m.start_belief))
+    np.random.seed(0)
+    pyrandom.seed(0)
+    solver = ref.FSVI_Solver(gamma=m.gamma, eps=1e-6)
+    vf, hist = quiet(solver.solve, model, cfg['expansions'], max_belief_growth=cfg['max_belief_growth'],
+                     limit_value_function_size=cfg['limit_value_function_size'], print_progress=False)
+    counts = np.asarray(hist.alpha_vector_counts)
+    assert np.any(np.diff(counts) < 0), 'the limiter never fired: pick a tighter limit'
+    np.savez_compressed(os.path.join(HERE, 'limiter_fsvi.npz'), cfg=json.dumps(cfg),
+                        alpha_counts=counts, belief_counts=np.asarray(hist.beliefs_counts),
+                        changes=np.asarray(hist.value_function_changes, dtype=np.float64),
+                        final_alpha=np.asarray(vf.alpha_vector_array), final_actions=np.asarray(vf.actions))
+    print(f'[golden] limiter_fsvi.npz: |V| trajectory {counts.tolist()}')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['small', 'kat', 'c2']
     for w in which:
-        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve, 'e2e': gen_e2e, 'hsvi': gen_hsvi}[w]()
+        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve, 'e2e': gen_e2e, 'hsvi': gen_hsvi, 'prune': gen_prune, 'limiter': gen_limiter}[w]()

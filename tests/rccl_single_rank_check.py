@@ -33,9 +33,23 @@ def main():
     uniq, gidx, acts, keep = gather_packed(dist, None, meta, per, kw, per, shard.assemble)
     res = eng.fetch()
     assert np.array_equal(uniq.cpu().numpy(), res.unique_alpha)
-    assert np.array_equal(gidx.cpu().numpy(), res.index)
-    assert np.array_equal(acts.cpu().numpy(), res.actions)
-    assert np.array_equal(keep.cpu().numpy().astype(bool), res.keep.astype(bool))
+    assert np.array_equal(gidx, res.index)
+    assert np.array_equal(acts, res.actions)
+    assert np.array_equal(keep, res.keep.astype(bool))
+    # the product path's step: exchange + global dedup + append to the alpha store, rows never leave the device
+    from pomdp_pbvi_exploration_amd.dist import sharded_engine_step
+    n0 = eng._lib.pbvi_alpha_store_count(eng._h)
+    first, n_rows, i3, a3, k3, _ = sharded_engine_step(shard, dist, None, per)
+    assert first == n0 and n_rows == res.unique_alpha.shape[0] and eng._lib.pbvi_alpha_store_count(eng._h) == n0 + n_rows
+    assert np.array_equal(i3, res.index) and np.array_equal(a3, res.actions)
+    alpha_before = z['alpha']
+    eng.select_alpha(np.arange(first, first + n_rows))        # the appended rows are the backup's rows
+    eng.set_beliefs(z['beliefs'][:4])
+    val, _ = eng.max_value_resident()
+    exp = (z['beliefs'][:4].astype(np.float64) @ res.unique_alpha.astype(np.float64).T).max(axis=1)
+    np.testing.assert_allclose(val, exp, rtol=1e-12)
+    eng.set_alpha(alpha_before)
+    eng.set_beliefs(z['beliefs'])
     # the row exchange (PBVI_EXCHANGE=rows) gives the same rows
     rows, count, idx, a2, k2, _ = shard.run_resident_unique()
     u2, g2, _, _ = gather_unique(dist, None, rows, count, idx, a2, k2, per)

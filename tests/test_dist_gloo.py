@@ -1,5 +1,6 @@
-"""Belief-sharded backup over 2 ranks (gloo on CPU): the all-gather layer returns exactly the
-single-process result, in belief order, for even and ragged splits."""
+"""Belief-sharded backup over 2-3 ranks (gloo on CPU): the exchange layer returns exactly the single-process result,
+in belief order, for even, ragged and empty shards; ``PBVI_Solver.backup`` / ``solve`` take the sharded route on their
+own when a process group is up and every rank ends with the single-process value function."""
 import os
 import socket
 import sys
@@ -85,6 +86,8 @@ def _worker_unique(rank, world, port, out_dir):
         idx = torch.arange(per, dtype=torch.int32) % count
         acts = torch.full((per,), rank, dtype=torch.int32)
         keep = torch.ones(per, dtype=torch.uint8)
+        if rank == world - 1:                                # ragged split: the last rank holds one belief fewer
+            idx, acts, keep = idx[:-1], acts[:-1], keep[:-1]
         uniq, gidx, a, k = gather_unique(dist, None, rows, count, idx, acts, keep, world * per - 1)
         assert uniq.shape == (2 + 3, S) and gidx.shape == (world * per - 1,)
         full = uniq[gidx]                                    # per-belief rows in global belief order
@@ -121,16 +124,19 @@ def _worker_keys(rank, world, port, out_dir):
         keep = (torch.arange(per) % 2).to(torch.uint8)
 
         def assemble(all_keys):                              # stand-in for pbvi_assemble_rows: a row made of its key
-            assert all_keys.shape == (2 + 3, 1 + O)
-            return all_keys[:, 1:2].double().repeat(1, S) + all_keys[:, 0:1].double() / 10
+            assert isinstance(all_keys, np.ndarray) and all_keys.shape == (2 + 3, 1 + O)
+            k = torch.from_numpy(all_keys)
+            return k[:, 1:2].double().repeat(1, S) + k[:, 0:1].double() / 10
 
+        if rank == world - 1:                                # ragged split: the last rank holds one belief fewer
+            idx, acts, keep = idx[:-1], acts[:-1], keep[:-1]
         uniq, gidx, a, k = gather_keys(dist, None, keys, count, idx, acts, keep, world * per - 1, assemble)
         assert uniq.shape == (5, S) and gidx.shape == (world * per - 1,)
-        full = uniq[gidx][:, 0]
+        full = uniq[torch.from_numpy(gidx)][:, 0]
         exp = torch.cat([((torch.arange(per) % (r + 2)) * 10 + 1000 * r).double() + r / 10 for r in range(world)])[: world * per - 1]
         assert torch.equal(full, exp)
         assert a.tolist() == ([0] * per + [1] * per)[: world * per - 1]
-        assert k.tolist() == ([0, 1, 0, 1, 0] * world)[: world * per - 1]
+        assert k.tolist() == ([False, True, False, True, False] * world)[: world * per - 1]
         open(os.path.join(out_dir, f'kok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
@@ -141,3 +147,94 @@ def test_gather_keys_world2(tmp_path):
     port = _free_port()
     mp.spawn(_worker_keys, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / 'kok0') and os.path.exists(tmp_path / 'kok1')
+
+
+def test_merge_exchange_dedups_equal_keys_across_ranks_and_handles_empty_shards():
+    """Host side of the key exchange: the same key found by two ranks is one row; a rank without beliefs contributes a
+    zero-count message; per-belief indices follow the global belief order."""
+    from pomdp_pbvi_exploration_amd.dist import merge_exchange, shard_bounds
+    O, kw = 2, 3
+    world, n_total = 3, 5                                   # per = 2: ranks hold 2, 2, 1 beliefs
+    per = 2
+    n_meta = 1 + 3 * per + per * kw
+
+    def msg(keys, index, actions, keep):
+        m = np.zeros(n_meta, dtype=np.int32)
+        m[0] = len(keys)
+        m[1:1 + len(index)] = index
+        m[1 + per:1 + per + len(index)] = actions
+        m[1 + 2 * per:1 + 2 * per + len(index)] = keep
+        m[1 + 3 * per:1 + 3 * per + len(keys) * kw] = np.asarray(keys, dtype=np.int32).reshape(-1)
+        return m
+
+    allm = np.stack([msg([[1, 7, 8], [0, 3, 3]], [0, 1], [1, 0], [1, 1]),
+                     msg([[0, 3, 3]], [0, 0], [0, 0], [1, 0]),             # same key as rank 0's second row
+                     msg([[2, 9, 9]], [0], [2], [1])])
+    keys, idx, act, keep = merge_exchange(allm, per, kw, n_total)
+    assert keys.tolist() == [[1, 7, 8], [0, 3, 3], [2, 9, 9]]
+    assert idx.tolist() == [0, 1, 1, 1, 2] and act.tolist() == [1, 0, 0, 0, 2]
+    assert keep.tolist() == [True, True, True, False, True]
+    # B < world: the last rank has nothing
+    assert shard_bounds(2, 3, 2)[:2] == (2, 2)
+    n_meta1 = 1 + 3 + kw
+    z = np.zeros((3, n_meta1), dtype=np.int32)
+    z[0, :] = [1, 0, 4, 1, 4, 5, 6]
+    z[1, :] = [1, 0, 4, 1, 4, 5, 6]
+    keys, idx, act, keep = merge_exchange(z, 1, kw, 2)
+    assert keys.tolist() == [[4, 5, 6]] and idx.tolist() == [0, 0] and act.tolist() == [4, 4]
+
+
+def _worker_solver(rank, world, port, out_dir, case):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import random
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pomdp_pbvi_exploration_amd import (Belief, BeliefSet, FSVI_Solver, PBVI_Solver, ValueFunction, load_POMDP_file)
+        from pomdp_pbvi_exploration_amd import dist as pdist
+        assert pdist.active()
+        model, _ = load_POMDP_file(os.path.join(REPO, 'tests', 'golden', 'models', '4x3.95-no_loop_2_grid.POMDP'))
+        model.end_states = [3, 6]
+        z = np.load(os.path.join(REPO, 'tests', 'golden', 'grid4x3_fsvi.npz'), allow_pickle=False)
+        if case == 'solve':
+            # the reference's seeded FSVI run: every backup of the loop is sharded over the ranks, the trajectory and
+            # the final alpha set are the single-process (= reference) ones on every rank
+            np.random.seed(0)
+            random.seed(0)
+            vf, hist = FSVI_Solver(gamma=0.95, eps=1e-6).solve(model, expansions=10, max_belief_growth=10, print_progress=False)
+            assert hist.alpha_vector_counts == list(z['alpha_counts'])
+            last = int(z['n_calls']) - 1
+            np.testing.assert_allclose(vf.alpha_vector_array, z[f'c{last}_out_alpha'], rtol=1e-12, atol=1e-13)
+            assert np.array_equal(vf.actions, z[f'c{last}_out_actions'])
+        else:
+            # two consecutive direct backups (belief-dominance prune on, append on), B odd and B < world included
+            solver = PBVI_Solver(gamma=0.95)
+            for n_b in (7, 1):
+                rng = np.random.default_rng(5)
+                rows = rng.random((n_b, model.state_count))
+                rows /= rows.sum(axis=1, keepdims=True)
+                bs = BeliefSet(model, [Belief(model, r) for r in rows])
+                vf = ValueFunction(model, model.expected_rewards_table.T, model.actions)
+                os.environ['PBVI_NO_SHARD'] = '1'                 # the single-process answer, on this rank
+                ref1 = solver.backup(model, bs, vf, append=True, belief_dominance_prune=True)
+                ref2 = solver.backup(model, bs, ref1, append=True, belief_dominance_prune=True)
+                del os.environ['PBVI_NO_SHARD']
+                got1 = solver.backup(model, bs, vf, append=True, belief_dominance_prune=True)
+                got2 = solver.backup(model, bs, got1, append=True, belief_dominance_prune=True)
+                for got, ref in ((got1, ref1), (got2, ref2)):
+                    assert len(got) == len(ref)
+                    np.testing.assert_allclose(got.alpha_vector_array, ref.alpha_vector_array, rtol=1e-13, atol=0)
+                    assert np.array_equal(got.actions, ref.actions)
+        open(os.path.join(out_dir, f'sok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case,world', [('backup', 2), ('backup', 3), ('solve', 2)])
+def test_solver_takes_the_sharded_route(tmp_path, case, world):
+    """PBVI_Solver.backup / FSVI solve under a gloo process group: the host mirror shards the beliefs by itself and
+    every rank ends with the single-process value function (for ``solve``: the reference's own seeded trajectory)."""
+    port = _free_port()
+    mp.spawn(_worker_solver, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'sok{r}') for r in range(world))

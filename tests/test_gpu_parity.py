@@ -235,6 +235,45 @@ def test_prune_dominated_matches_reference_loop(dtype):
     eng.close()
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_prune_level2_matches_the_reference_fixture(dtype):
+    """SURVEY 8a row a12 pinned to the reference: the rows ``ValueFunction.prune(2)`` of the reference kept on the seeded
+    set of prune_level2.npz (make_golden.py prune), through ``pbvi_prune_dominated`` and through the Python seam."""
+    z = load_npz('prune_level2.npz')
+    alpha, kept = z['alpha'], z['kept']
+    S = alpha.shape[1]
+    rs = np.zeros((S, 1, 1), dtype=np.int64)
+    eng = Engine(S, 1, 1, 1, rs, np.ones((S, 1, 1, 1)), np.zeros((S, 1)), dtype=dtype)
+    keep = eng.prune_dominated(alpha)
+    assert np.array_equal(np.flatnonzero(keep), kept)
+    assert not keep[-1] and not keep[-2]                    # the +0 / -0 pair: each dominates the other
+    eng.close()
+    m = synth.olfactory_model(H=15, W=40, R=1)
+    from pomdp_pbvi_exploration_amd import Model
+    gm = Model(states=m.S, actions=m.A, observations=m.O, reachable_states=m.reachable_states,
+               observation_table=m.observation_table, end_states=[m.goal], start_probabilities=list(m.start_belief)).to_gpu(dtype)
+    vf = ValueFunction(gm, alpha, z['actions'])
+    assert len(vf) == alpha.shape[0]
+    vf.prune(2)
+    assert np.array_equal(np.asarray(vf.alpha_vector_array, dtype=np.float64), alpha[kept])
+    assert np.array_equal(vf.actions, z['actions'][kept])
+
+
+def test_value_function_size_limiter_on_the_engine():
+    """SURVEY 8f-1, second half (src/pomdp.py:2347-2365): the usefulness scan of the |V| limiter on the device
+    (``pbvi_value_max_store`` indices over the whole belief store) inside the reference's seeded FSVI run of
+    limiter_fsvi.npz -- the deletion draws from np.random, so the |V| trajectory only reproduces if every ``useful`` set
+    along the way is the reference's.  f64 engine: the reference's arithmetic."""
+    from test_host_api import _limiter_solve
+    z, vf, hist = _limiter_solve(use_gpu=True)
+    assert vf.is_on_gpu
+    assert hist.beliefs_counts == list(z['belief_counts'])
+    assert hist.alpha_vector_counts == list(z['alpha_counts'])
+    np.testing.assert_allclose(hist.value_function_changes, z['changes'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.asarray(vf.alpha_vector_array), z['final_alpha'], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(vf.actions, z['final_actions'])
+
+
 def test_gemm_alone_decides_almost_everything():
     """With the fp64 refinement window shut, the raw MFMA score GEMM must still reproduce the
     reference argmax except on genuine near-ties (guards against refinement masking a GEMM bug)."""
@@ -319,6 +358,76 @@ def test_full_size_against_reference_summary(R):
     np.testing.assert_allclose(np.sum(beliefs * pv.alpha, axis=1), np.sum(beliefs * res.alpha, axis=1), rtol=F32_RTOL)
     sc = eng.backup_full(alpha * 2.0, beliefs, m.gamma)                                                           # scaling by 2 is exact
     assert np.array_equal(sc.best_alpha_ind, res.best_alpha_ind)
+    eng.close()
+
+
+def _check_against_full_fixture(res, z, beliefs):
+    mism = int(np.sum(res.best_alpha_ind != z['core_best']))
+    assert mism == 0, f'{mism} of {res.best_alpha_ind.size} best_alpha_ind differ'
+    assert np.array_equal(res.actions, z['core_actions'])
+    a64 = res.alpha.astype(np.float64)
+    np.testing.assert_allclose(a64.sum(axis=1), z['row_sum'], rtol=F32_RTOL)
+    np.testing.assert_allclose(np.sum(beliefs * a64, axis=1), z['b_dot'], rtol=F32_RTOL)
+    np.testing.assert_allclose(a64[z['sample_b'], z['sample_s']], z['sample_val'], rtol=F32_RTOL, atol=1e-12)
+    assert len(orc.dedup_rows(res.alpha, res.actions)[1]) == int(z['n_unique'])
+
+
+def _full_fixture(R):
+    path = os.path.join(GOLDEN, f'olfactory_full_R{R}.npz')
+    if not os.path.exists(path):
+        pytest.skip('full-size fixture missing')
+    z = np.load(path, allow_pickle=False)
+    m, alpha, beliefs = full_inputs(R, int(z['V']), int(z['B']))
+    if synth.checksum(m.reachable_states, m.rto, m.expected_rewards, alpha, beliefs) != str(z['inputs_sha256']):
+        pytest.skip('host regenerated different input bits than the fixture machine (exp/libm); parity unpinned here')
+    return z, m, alpha, beliefs
+
+
+def test_full_size_dense_projection_against_reference():
+    """BASELINE config 2 (C3) at its full size: S=30000, V=B=1024, the projection as |A||O| MFMA GEMMs over the densified
+    65 GB of T.O matrices, against the reference's own outputs for this workload (olfactory_full_R1.npz).  Run twice:
+    with zero-tile skipping (what the engine does by itself) and with every tile of both GEMMs multiplied (what bench.py
+    measures as c3_dense) -- skipped tiles only ever add +0, so the results must be the same bits."""
+    from pomdp_pbvi_exploration_amd.engine import debug_gemm_dense
+    z, m, alpha, beliefs = _full_fixture(1)
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32', mode='dense')
+    res = eng.backup_full(alpha, beliefs, m.gamma)
+    _check_against_full_fixture(res, z, beliefs)
+    assert res.stats['project_flops'] == 2 * 18 * 1024 * 30000 * 30000
+    prev = debug_gemm_dense(True)
+    try:
+        full = eng.backup_full(alpha, beliefs, m.gamma)
+    finally:
+        debug_gemm_dense(prev)
+    assert full.stats['project_flops_executed'] >= full.stats['project_flops'] > res.stats['project_flops_executed']
+    assert np.array_equal(full.best_alpha_ind, res.best_alpha_ind) and np.array_equal(full.actions, res.actions)
+    assert np.array_equal(full.alpha, res.alpha)
+    print(f"dense C3: projection GEMM {full.stats['ms_project_gemm']:.1f} ms true-dense, {res.stats['ms_project_gemm']:.2f} ms with "
+          f"zero tiles skipped; step {full.stats['ms_total']:.1f} / {res.stats['ms_total']:.2f} ms")
+    eng.close()
+
+
+def test_full_size_poisoned_allocations():
+    """Regression for the round-1 abort: the full-size sparse backup with every fresh device allocation
+    filled with 0xFF (NaN / -1).  A kernel that reads memory the engine did not write -- or a poison fill that races
+    with the engine's streams, which is what the abort was -- shows up as wrong indices or a fault at THIS shape, where
+    the first call allocates ~4 GB inside pbvi_backup_run."""
+    from pomdp_pbvi_exploration_amd.engine import debug_poison
+    z, m, alpha, beliefs = _full_fixture(1)
+    prev = debug_poison(True)
+    try:
+        eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32')
+        res = eng.backup_full(alpha, beliefs, m.gamma, belief_dominance_prune=True)
+        _check_against_full_fixture(res, z, beliefs)
+        # second call with a smaller alpha set: buffers are re-used with shifted row groups and stale contents
+        half = eng.backup_full(alpha[:600], beliefs, m.gamma)
+        eng.close()
+    finally:
+        debug_poison(prev)
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32')
+    clean = eng.backup_full(alpha[:600], beliefs, m.gamma)
+    assert np.array_equal(half.best_alpha_ind, clean.best_alpha_ind) and np.array_equal(half.actions, clean.actions)
+    assert np.array_equal(half.alpha, clean.alpha)
     eng.close()
 
 
@@ -1028,3 +1137,22 @@ def test_rccl_exchange_single_rank_matches_direct_fetch():
     out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert 'rccl single-rank exchange ok' in out.stdout
+
+
+def test_sharded_backup_on_the_engine_two_ranks():
+    """SURVEY 8e as a product path: two ranks (one HIP engine each, sharing this box's GPU, gloo carrying the exchange)
+    run ``FSVI_Solver.solve(use_gpu=True)`` and direct ``PBVI_Solver.backup`` calls; the beliefs are sharded by the solver
+    itself, every replica appends the same rows, and the results equal the single-process engine's / the reference's
+    seeded trajectory.  (tests/dist_engine_check.py holds the ranks' code.)"""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dist_engine_check.py')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), script],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    assert 'sharded engine backup ok' in out.stdout

@@ -124,6 +124,31 @@ def test_grid4x3_seeded_fsvi_trajectory():
     assert np.array_equal(vf.actions, z[f'c{last}_out_actions'])
 
 
+def _limiter_solve(use_gpu: bool):
+    z = load_npz('limiter_fsvi.npz')
+    cfg = json.loads(str(z['cfg']))
+    m = synth.olfactory_model(H=15, W=40, R=1, f32=False)
+    model = Model(states=m.S, actions=m.A, observations=m.O, reachable_states=m.reachable_states,
+                  observation_table=m.observation_table, end_states=[m.goal], start_probabilities=list(m.start_belief))
+    np.random.seed(0)
+    random.seed(0)
+    vf, hist = FSVI_Solver(gamma=m.gamma, eps=1e-6).solve(
+        model, cfg['expansions'], max_belief_growth=cfg['max_belief_growth'],
+        limit_value_function_size=cfg['limit_value_function_size'], print_progress=False, use_gpu=use_gpu)
+    return z, vf, hist
+
+
+def test_value_function_size_limiter_reproduces_the_reference_run():
+    """SURVEY 8f-1, second half: the |V| limiter (usefulness scan + weighted random deletion, src/pomdp.py:2347-2365) in
+    the reference's seeded FSVI run of the S=600 olfactory model (limiter_fsvi.npz, made by make_golden.py limiter)."""
+    z, vf, hist = _limiter_solve(use_gpu=False)
+    assert hist.alpha_vector_counts == list(z['alpha_counts']) and hist.beliefs_counts == list(z['belief_counts'])
+    assert np.any(np.diff(z['alpha_counts']) < 0)            # the limiter fired
+    np.testing.assert_allclose(hist.value_function_changes, z['changes'], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(vf.alpha_vector_array, z['final_alpha'], rtol=1e-12, atol=1e-14)
+    assert np.array_equal(vf.actions, z['final_actions'])
+
+
 def test_value_function_container_semantics():
     model = _two_state(0.7)
     rows = np.array([[1., 2.], [3., 4.], [1., 2.]])

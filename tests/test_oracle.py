@@ -95,6 +95,15 @@ def test_prune_dominated_semantics():
     assert orc.prune_dominated_mask(a[:3]).tolist() == [True, False, True]
 
 
+def test_prune_level2_matches_the_reference_fixture():
+    """prune_level2.npz: what the reference's ValueFunction.prune(2) kept (make_golden.py prune) on a seeded set with
+    dominated, dominating and one-state-apart rows and a +0 / -0 pair."""
+    z = load_npz('prune_level2.npz')
+    mask = orc.prune_dominated_mask(z['alpha'])
+    assert np.array_equal(np.flatnonzero(mask), z['kept'])
+    assert not mask[-1] and not mask[-2]                    # the pair that differs only in the sign of a zero
+
+
 def test_dedup_first_position_last_action():
     v = np.array([[1., 2.], [3., 4.], [1., 2.]])
     rows, acts = orc.dedup_rows(v, np.array([0, 1, 2]))
