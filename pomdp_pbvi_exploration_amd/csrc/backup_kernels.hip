@@ -120,16 +120,22 @@ template <typename T>
 __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView<T> mv, T gamma,
                           T* __restrict__ gam, int ldg, const uint8_t* __restrict__ need, int k_tiles) {
 #pragma clang fp contract(off)   // einsum then scale: sum_r (rto*alpha), one rounding per op, as the reference
-    // 4 consecutive states per thread (16-byte table loads and Gamma stores; S_pad is a multiple of 32),
-    // 4 alpha-vectors x up to 4 observations per pass.
-    const int s = (blockIdx.x * 256 + threadIdx.x) * 4;
+    // NS consecutive states per thread = 16 bytes of every table load and Gamma store (float: 4, double: 2; S_pad is a
+    // multiple of 32), 4 alpha-vectors x up to 4 observations per pass: 16 NS-wide accumulators.  (With 4 doubles per
+    // thread the accumulators alone were 128 VGPRs and the kernel spilled 166 registers to scratch: 1.9 ms instead
+    // of 0.6 at C4.)
+    constexpr int NS = 16 / (int)sizeof(T);
+    typedef T TN __attribute__((ext_vector_type(NS)));
+    typedef int IN __attribute__((ext_vector_type(NS)));
+    const int s = (blockIdx.x * 256 + threadIdx.x) * NS;
     if (s >= mv.S_pad) return;
     const int v0 = blockIdx.y * 4;
     const int a = blockIdx.z;
     const int nv = (V - v0) < 4 ? (V - v0) : 4;
     const int kt = s >> 5;                                  // GEMM K tile of these states (32 states per tile)
-    typedef T T4 __attribute__((ext_vector_type(4)));
-    typedef int I4 __attribute__((ext_vector_type(4)));
+    TN zero;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) zero[j] = T(0);
     for (int o0 = 0; o0 < mv.O; o0 += 4) {
         const int no = (mv.O - o0) < 4 ? (mv.O - o0) : 4;
         // Gamma tiles the score GEMM never reads (no RTO support, or no belief mass in any row
@@ -144,31 +150,35 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
             }
             if (!any) continue;
         }
-        T4 acc[4][4];
+        TN acc[4][4];
 #pragma unroll
         for (int vj = 0; vj < 4; ++vj)
 #pragma unroll
-            for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = T4{T(0), T(0), T(0), T(0)};
+            for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = zero;
         for (int r = 0; r < mv.R; ++r) {
-            const I4 idx = *(const I4*)(mv.rs + ((int64_t)a * mv.R + r) * mv.S_pad + s);
-            const bool contig = (idx[1] == idx[0] + 1) && (idx[2] == idx[0] + 2) && (idx[3] == idx[0] + 3);
-            T4 w[4];
+            const IN idx = *(const IN*)(mv.rs + ((int64_t)a * mv.R + r) * mv.S_pad + s);
+            bool contig = true;
+#pragma unroll
+            for (int j = 1; j < NS; ++j) contig = contig && (idx[j] == idx[0] + j);
+            TN w[4];
 #pragma unroll
             for (int oj = 0; oj < 4; ++oj)
-                w[oj] = (oj < no && want[oj]) ? *(const T4*)(mv.rto + (((int64_t)a * mv.O + o0 + oj) * mv.R + r) * mv.S_pad + s)
-                                               : T4{T(0), T(0), T(0), T(0)};
+                w[oj] = (oj < no && want[oj]) ? *(const TN*)(mv.rto + (((int64_t)a * mv.O + o0 + oj) * mv.R + r) * mv.S_pad + s)
+                                               : zero;
 #pragma unroll
             for (int vj = 0; vj < 4; ++vj) {
                 if (vj < nv) {
                     const T* arow = alpha + (int64_t)(v0 + vj) * lda;
                     // successors of consecutive states are usually consecutive (grid moves): one 16-byte
-                    // (dword-aligned) load instead of four gathers
-                    T4 av;
+                    // (element-aligned) load instead of NS gathers
+                    TN av;
                     if (contig) {
                         const T* p = arow + idx[0];
-                        av = T4{p[0], p[1], p[2], p[3]};
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) av[j] = p[j];
                     } else {
-                        av = T4{arow[idx[0]], arow[idx[1]], arow[idx[2]], arow[idx[3]]};
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) av[j] = arow[idx[j]];
                     }
 #pragma unroll
                     for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = acc[vj][oj] + w[oj] * av;
@@ -184,7 +194,7 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
                     const int v = v0 + vj;
                     // alpha rows -> group-major rows; the magnitude row (v == V-1 of the Vt rows) -> tail
                     const int64_t row = (v < V - 1) ? ao * (V - 1) + v : (int64_t)mv.A * mv.O * (V - 1) + ao;
-                    *(T4*)(gam + row * ldg + s) = gamma * acc[vj][oj];
+                    *(TN*)(gam + row * ldg + s) = gamma * acc[vj][oj];
                 }
     }
 }
@@ -193,7 +203,8 @@ template <typename T>
 hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg,
                           const uint8_t* need, int k_tiles, hipStream_t st) {
     if (V <= 0) return hipSuccess;
-    dim3 grid((mv.S_pad / 4 + 255) / 256, (V + 3) / 4, mv.A);
+    constexpr int NS = 16 / (int)sizeof(T);
+    dim3 grid((mv.S_pad / NS + 255) / 256, (V + 3) / 4, mv.A);
     if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_project<T>, grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles);
     return hipGetLastError();
@@ -206,30 +217,32 @@ hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gam
 // zeros; tiles that are not needed are never read, so they may hold stale data.
 __global__ void k_need_tiles(const uint8_t* __restrict__ nzA, int tiles_m, const uint8_t* __restrict__ nzB, int G, int V,
                              int k_tiles, uint8_t* __restrict__ need) {
+    // one thread per (K tile, group): the loops over row blocks / neighbouring groups are a handful of loads each
+    // (as one thread per K tile looping over all groups this was 22 us of dependent loads in front of the projection)
     const int kt = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
     if (kt >= k_tiles) return;
     int any = 0;
     for (int m = 0; m < tiles_m; ++m) any |= nzA[(int64_t)m * k_tiles + kt];
-    int all = 0;                                            // support of anything in the tail tile
-    for (int g = 0; g <= G; ++g) all |= nzB[(int64_t)g * k_tiles + kt];
-    const int64_t tail0 = (int64_t)G * V;                   // first magnitude row
-    for (int g = 0; g < G; ++g) {
+    int f = 0;
+    if (any) {
+        const int64_t tail0 = (int64_t)G * V;               // first magnitude row
         const int64_t r0 = (int64_t)g * V, r1 = r0 + V - 1;
         const int64_t t0 = r0 >> 8, t1 = r1 >> 8;           // n-tiles holding rows of g
-        int f = 0;
-        if ((t1 << 8) + 255 >= tail0) {
-            f = all;                                        // shares a tile with the tail rows
+        if ((t1 << 8) + 255 >= tail0) {                     // shares a tile with the tail rows: support of anything there
+            for (int x = 0; x <= G; ++x) f |= nzB[(int64_t)x * k_tiles + kt];
         } else {
             const int g0 = (int)((t0 << 8) / V), g1 = (int)(((t1 << 8) + 255) / V);
             for (int x = g0; x <= g1 && x < G; ++x) f |= nzB[(int64_t)x * k_tiles + kt];
         }
-        need[(int64_t)g * k_tiles + kt] = (any && f) ? 1 : 0;
     }
+    need[(int64_t)g * k_tiles + kt] = (any && f) ? 1 : 0;
 }
 
 hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB, int AO, int V, int k_tiles,
                              uint8_t* need, hipStream_t st) {
-    hipLaunchKernelGGL(k_need_tiles, dim3((k_tiles + 255) / 256), dim3(256), 0, st, nzA, tiles_m, nzB, AO, V, k_tiles, need);
+    if (AO > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_need_tiles, dim3((k_tiles + 255) / 256, AO), dim3(256), 0, st, nzA, tiles_m, nzB, AO, V, k_tiles, need);
     return hipGetLastError();
 }
 
@@ -370,6 +383,34 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
     // one pass: running maximum (first index) and runner-up value per lane, merged across the wave
     T m = -std::numeric_limits<T>::infinity(), m2 = -std::numeric_limits<T>::infinity();
     int idx = 0x7fffffff;
+    // Fast path (alpha-side f32 slabs, groups aligned to 4 columns): a lane takes 4 consecutive columns per load
+    // (16 bytes per slab) and looks the pair's slab count up once per 4 columns instead of once per score; columns
+    // and chunks ascend per lane, so "first maximum" is unchanged.
+    bool vec4 = false;
+    if constexpr (sizeof(T) == 4) vec4 = !sv.push && sv.nchunks != nullptr && (V & 3) == 0 && (sv.ldc & 3) == 0;
+    if (vec4) {
+        typedef float F4 __attribute__((ext_vector_type(4)));
+        const int64_t col0 = (int64_t)g * V;
+        const float* rowp = (const float*)sv.slabs + (int64_t)b * sv.ldc + col0;
+        const int tm = b >> 8;
+        for (int c0 = lane * 4; c0 < V; c0 += 256) {
+            const int n = sv.nchunks[((col0 + c0) >> 8) * sv.tiles_m + tm];
+            F4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < n; ++z) acc = acc + *(const F4*)(rowp + c0 + (int64_t)z * sv.slab_stride);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const T sc = (T)acc[j];
+                const int v = c0 + j;
+                if (sc > m || idx == 0x7fffffff) {
+                    m2 = (idx == 0x7fffffff) ? m2 : m;
+                    m = sc;
+                    idx = v;
+                } else if (sc > m2) {
+                    m2 = sc;
+                }
+            }
+        }
+    } else
     for (int v0 = lane; v0 < V; v0 += 256) {               // four independent score reads in flight per lane
         T sc4[4];
 #pragma unroll
