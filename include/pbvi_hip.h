@@ -85,6 +85,9 @@ typedef struct pbvi_stats {
                                     to the GEMM path -- every alpha row re-scored -- stops listing) */
     double ms_project_gemm;  /* dense mode: the batched projection GEMM kernel alone (ms_project also holds the
                                 clears and the scale/copy pass around it); 0 in sparse mode */
+    int32_t screened;        /* fp64 engines: 1 when the scores came from the fp32 screen (fp32 stream-K GEMM on rounded
+                                copies of the operands, near-ties re-decided from the fp64 originals), 0 = pure fp64 */
+    int32_t reserved_;
 } pbvi_stats_t;
 
 /* Library / device queries. */
@@ -339,6 +342,17 @@ int pbvi_engine_set_rto_f64(pbvi_engine_t* e, const double* rto);
  *       when B << V, e.g. the solve loop's ~100 new beliefs against thousands of alpha-vectors.
  */
 int pbvi_set_formulation(pbvi_engine_t* e, int formulation);
+
+/*
+ * fp64 engines only (a no-op setting on fp32 ones): the fp32 SCREEN.  mode 1 (default): when the score GEMM is large
+ * the scores are computed by the fp32 stream-K GEMM on fp32-rounded copies of the operands, with the tie window widened
+ * by the input roundings, and every (belief, action, observation) and action whose winner is not clear is re-decided
+ * from the fp64 originals -- same indices and values as the pure fp64 pipeline up to that pipeline's own summation
+ * order, at about the fp32 engine's speed (the fp64 MFMA GEMM sustains a third of the fp32 one).  0: never (pure
+ * fp64 arithmetic throughout, src/pomdp.py:1485-1506 literally); 2: always, whatever the size (tests).
+ * PBVI_F64_SCREEN=off|auto|always in the environment sets the initial mode.
+ */
+int pbvi_set_f64_screen(pbvi_engine_t* e, int mode);
 
 /* Tuning knob for f32 engines: relative half-width of the near-tie window that sends an
  * argmax to fp64 refinement (<= 0 restores the default derived from |S|). */

@@ -108,7 +108,7 @@ template <typename T>
 hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dead, double tol_rel, double tol_abs,
                          const int* chain_steps /* device: K-tile steps of the longest f32 chain; used when tol_rel < 0 */,
                          int flag_all, int32_t* best_v, double* best_score, double* err, int32_t* queue, int* qcount,
-                         hipStream_t st);
+                         hipStream_t st, double tol_extra = 0.0 /* added to the relative window: input rounding of a screen */);
 
 // Work list of the refinement: entries with many near-tied candidates hand their (entry, candidate) pairs to a
 // grid-wide pass instead of scoring them one block per entry (device memory; items_v == nullptr: all in-block).
@@ -139,8 +139,10 @@ struct RefineWork {
 };
 
 // fp64 re-decision of queued near-ties.  PROJ: scores are b . Gamma[a,o,v,:]; else b . alpha[v,:]
-template <typename T>
-hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entries, const int32_t* queue,
+// T: type of the operands that are re-scored; TS: type of the score slabs the candidates are flagged from (TS = float,
+// T = double: an fp64 engine behind its fp32 screen).
+template <typename T, typename TS>
+hipError_t launch_refine(bool proj, SlabView<TS> sv, int V, int G, int max_entries, const int32_t* queue,
                          const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
                          double gamma, const int32_t* btl, const int32_t* btc /* belief tile lists or nullptr */,
                          const uint8_t* nzG /* PROJ: [G][k_tiles] support tiles of RTO per group, or nullptr */,
@@ -159,7 +161,7 @@ hipError_t launch_tail_rows(ModelView<T> mv, T* gam_tail, int ldg, hipStream_t s
 template <typename T>
 hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, const int* chain_steps,
                          const double* best_score, const double* err, double* rdot, double* rdot_err, int32_t* action,
-                         int32_t* aqueue, int* aqcount, hipStream_t st);
+                         int32_t* aqueue, int* aqcount, hipStream_t st, double tol_extra = 0.0);
 template <typename T>
 hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv, double gamma,
                                 const int32_t* btl, const int32_t* btc, const int32_t* aqueue, const int* aqcount,

@@ -366,7 +366,7 @@ hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const uint
 // ------------------------------------------------------------------------- //
 template <typename T>
 __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __restrict__ dead, double tol_rel,
-                         double tol_abs, const int* __restrict__ chain_steps, int flag_all, int32_t* __restrict__ best_v, double* __restrict__ best_score,
+                         double tol_abs, double tol_extra, const int* __restrict__ chain_steps, int flag_all, int32_t* __restrict__ best_v, double* __restrict__ best_score,
                          double* __restrict__ err, int32_t* __restrict__ queue, int* __restrict__ qcount) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -455,7 +455,7 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
         if (chain_steps != nullptr && tol_rel < 0.0)
             tr = 8.0 * 5.9604644775390625e-08 * (sqrt((double)chain_steps[0] * 32.0) + 1.0);
         if (sv.push) tr += 2.0 * 5.9604644775390625e-08;    // bp is rounded once to f32 after its f64 accumulation
-        E = tr * mag + tol_abs;
+        E = (tr + tol_extra) * mag + tol_abs;               // tol_extra: input rounding of an fp32 screen of fp64 operands
         push = (flag_all || (double)m2 >= (double)m - 2.0 * E) ? 1 : 0;
     }
     if (lane == 0) {
@@ -472,11 +472,11 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
 template <typename T>
 hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dead, double tol_rel, double tol_abs,
                          const int* chain_steps, int flag_all, int32_t* best_v, double* best_score, double* err,
-                         int32_t* queue, int* qcount, hipStream_t st) {
+                         int32_t* queue, int* qcount, hipStream_t st, double tol_extra) {
     const int64_t rows = (int64_t)B * G;
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_argmax<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sv, V, G, B, dead, tol_rel,
-                       tol_abs, chain_steps, flag_all, best_v, best_score, err, queue, qcount);
+                       tol_abs, tol_extra, chain_steps, flag_all, best_v, best_score, err, queue, qcount);
     return hipGetLastError();
 }
 
@@ -538,8 +538,8 @@ __device__ __forceinline__ double refine_wave_dot(const T* __restrict__ brow, co
     return wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
 }
 
-template <typename T, bool PROJ>
-__global__ void k_refine(SlabView<T> sv, int V, int G, const int32_t* __restrict__ queue,
+template <typename T, typename TS, bool PROJ>
+__global__ void k_refine(SlabView<TS> sv, int V, int G, const int32_t* __restrict__ queue,
                          const int* __restrict__ qcount,
                          const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
                          ModelView<T> mv, double gamma, const int32_t* __restrict__ btl, const int32_t* __restrict__ btc,
@@ -853,8 +853,8 @@ __global__ void k_refine_slot_argmax(RefineWork work, int V, int32_t* __restrict
     }
 }
 
-template <typename T>
-hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entries, const int32_t* queue,
+template <typename T, typename TS>
+hipError_t launch_refine(bool proj, SlabView<TS> sv, int V, int G, int max_entries, const int32_t* queue,
                          const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
                          double gamma, const int32_t* btl, const int32_t* btc, const uint8_t* nzG, int32_t* best_v,
                          double* best_score, double* err, int* cand_total, RefineWork work, hipStream_t st) {
@@ -865,10 +865,10 @@ hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entrie
         if ((e = hipMemsetAsync(work.cnt, 0, work.zero_bytes, st)) != hipSuccess) return e;
     }
     if (proj)
-        hipLaunchKernelGGL((k_refine<T, true>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,
+        hipLaunchKernelGGL((k_refine<T, TS, true>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,
                            alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
     else
-        hipLaunchKernelGGL((k_refine<T, false>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel,
+        hipLaunchKernelGGL((k_refine<T, TS, false>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel,
                            ldb, alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (work.items_v != nullptr) {
@@ -880,22 +880,24 @@ hipError_t launch_refine(bool proj, SlabView<T> sv, int V, int G, int max_entrie
         const int n_slots = h_cnt[1] < work.slot_cap ? h_cnt[1] : work.slot_cap;
         const int n_w = n_slots < work.w_slot_cap ? n_slots : work.w_slot_cap;
         if (n_w > 0) {   // GEMM path: weights -> tile map -> [n_w x S] x [V x S]^T in fp64 on the MFMA -> first max
-            if constexpr (sizeof(T) == 4) {
-                dim3 wgrid((mv.S_pad + 255) / 256, n_w);
-                if (proj)
-                    hipLaunchKernelGGL((k_refine_weights<T, true>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
-                else
-                    hipLaunchKernelGGL((k_refine_weights<T, false>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
-                if ((e = launch_tile_nonzero_f64(work.W, mv.S_pad, n_w, mv.S_pad / 32, work.nzW, st)) != hipSuccess) return e;
+            dim3 wgrid((mv.S_pad + 255) / 256, n_w);
+            if (proj)
+                hipLaunchKernelGGL((k_refine_weights<T, true>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
+            else
+                hipLaunchKernelGGL((k_refine_weights<T, false>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = launch_tile_nonzero_f64(work.W, mv.S_pad, n_w, mv.S_pad / 32, work.nzW, st)) != hipSuccess) return e;
+            if constexpr (sizeof(T) == 4) {   // fp32 alpha rows widened exactly on the way into LDS
                 if ((e = launch_gemm_nt_f64_bf32(work.W, mv.S_pad, n_w, (const float*)alpha, lda, V, work.Cx, V, mv.S_pad,
                                                  work.nzW, work.klistW, work.kcountW, st)) != hipSuccess)
                     return e;
-                hipLaunchKernelGGL(k_refine_slot_argmax, dim3(n_w), dim3(256), 0, st, work, V, best_v, best_score, err);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
-            } else {
-                return hipErrorInvalidValue;                 // refinement exists for f32 engines only
+            } else {                          // fp64 engine behind an fp32 screen: the fp64 originals
+                if ((e = launch_gemm_nt_f64(work.W, mv.S_pad, n_w, (const double*)alpha, lda, V, work.Cx, V, mv.S_pad,
+                                            work.nzW, nullptr, 0, 0, work.klistW, work.kcountW, st)) != hipSuccess)
+                    return e;
             }
+            hipLaunchKernelGGL(k_refine_slot_argmax, dim3(n_w), dim3(256), 0, st, work, V, best_v, best_score, err);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (n_items > 0) {
             const int blocks = 2048;                       // 8192 waves: every SIMD of the chip has work in flight
@@ -939,7 +941,7 @@ hipError_t launch_tail_rows(ModelView<T> mv, T* gam_tail, int ldg, hipStream_t s
 // K4, one thread per belief: val[a] = b.ER[:,a] + sum_o best_score[b][a][o]; first max; near-ties queued.
 // rdot comes from the score matrix (column rd_col0 + a, f32 engines: with error bound tol * b.|ER_a|).
 template <typename T>
-__global__ void k_action_select(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel,
+__global__ void k_action_select(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, double tol_extra,
                                 const int* __restrict__ chain_steps, const double* __restrict__ best_score,
                                 const double* __restrict__ err, double* __restrict__ rdot, double* __restrict__ rdot_err,
                                 int32_t* __restrict__ action, int32_t* __restrict__ aqueue, int* __restrict__ aqcount) {
@@ -947,6 +949,7 @@ __global__ void k_action_select(int B, ModelView<T> mv, SlabView<T> sv, int64_t 
     if (b >= B) return;
     double tr = tol_rel;
     if (chain_steps != nullptr && tol_rel < 0.0) tr = 8.0 * 5.9604644775390625e-08 * (sqrt((double)chain_steps[0] * 32.0) + 1.0);
+    tr += tol_extra;
     int best = 0;
     double bv = -std::numeric_limits<double>::infinity(), lo = bv;
     for (int a = 0; a < mv.A; ++a) {
@@ -993,9 +996,9 @@ __global__ void k_action_select(int B, ModelView<T> mv, SlabView<T> sv, int64_t 
 template <typename T>
 hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, const int* chain_steps,
                          const double* best_score, const double* err, double* rdot, double* rdot_err, int32_t* action,
-                         int32_t* aqueue, int* aqcount, hipStream_t st) {
+                         int32_t* aqueue, int* aqcount, hipStream_t st, double tol_extra) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_action_select<T>, dim3((B + 255) / 256), dim3(256), 0, st, B, mv, sv, rd_col0, tol_rel,
+    hipLaunchKernelGGL(k_action_select<T>, dim3((B + 255) / 256), dim3(256), 0, st, B, mv, sv, rd_col0, tol_rel, tol_extra,
                        chain_steps, best_score, err, rdot, rdot_err, action, aqueue, aqcount);
     return hipGetLastError();
 }
@@ -1571,12 +1574,12 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
                                        int32_t*, int*, hipStream_t);                                                   \
     template hipError_t launch_belief_tiles<T>(const T*, int, int, int, int, int32_t*, int32_t*, hipStream_t);         \
     template hipError_t launch_argmax<T>(SlabView<T>, int, int, int, const uint8_t*, double, double, const int*, int,  \
-                                         int32_t*, double*, double*, int32_t*, int*, hipStream_t);                     \
-    template hipError_t launch_refine<T>(bool, SlabView<T>, int, int, int, const int32_t*, const int*, const T*, int,  \
+                                         int32_t*, double*, double*, int32_t*, int*, hipStream_t, double);             \
+    template hipError_t launch_refine<T, T>(bool, SlabView<T>, int, int, int, const int32_t*, const int*, const T*, int, \
                                          const T*, int, ModelView<T>, double, const int32_t*, const int32_t*,          \
                                          const uint8_t*, int32_t*, double*, double*, int*, RefineWork, hipStream_t);   \
     template hipError_t launch_action<T>(int, ModelView<T>, SlabView<T>, int64_t, double, const int*, const double*,   \
-                                         const double*, double*, double*, int32_t*, int32_t*, int*, hipStream_t);      \
+                                         const double*, double*, double*, int32_t*, int32_t*, int*, hipStream_t, double); \
     template hipError_t launch_refine_action<T>(const T*, int, int, const T*, int, ModelView<T>, double,               \
                                                 const int32_t*, const int32_t*, const int32_t*, const int*,            \
                                                 const double*, const double*, const int32_t*, const double*,           \
@@ -1602,5 +1605,10 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
     template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
 PBVI_INST(float)
 PBVI_INST(double)
+// fp64 data re-scored behind an fp32 screen (candidates flagged from fp32 slabs)
+template hipError_t launch_refine<double, float>(bool, SlabView<float>, int, int, int, const int32_t*, const int*, const double*,
+                                                 int, const double*, int, ModelView<double>, double, const int32_t*,
+                                                 const int32_t*, const uint8_t*, int32_t*, double*, double*, int*, RefineWork,
+                                                 hipStream_t);
 
 }  // namespace pbvi

@@ -322,6 +322,30 @@ __global__ void k_unpermute(int B, int AO, const int32_t* __restrict__ perm, con
     for (int j = tid; j < AO; j += blockDim.x) best_o[(int64_t)d * AO + j] = best_v[(int64_t)b * AO + j];
 }
 
+// The scoring stage (K1, K2, first-max) runs on an engine or on an fp64 engine's fp32 screen (EngineT::stage_scores).
+struct ScoreIO {                      // the pipeline buffers the stage writes / reads: owned by the engine that continues
+    int32_t* best_v;
+    double* best_score;
+    double* err;
+    int32_t* queue;                   // near-tie queue (nullptr: no windows, exact arithmetic)
+    int* qcount;
+    const uint8_t* dead;              // exact dead-triple flags, or nullptr
+    const double* prd;                // [B][A] b.ER in f64 for the belief-side formulation, or nullptr
+    hipEvent_t join;                  // the side-stream work that produced dead / prd
+    hipStream_t side;                 // where the GEMM's tile lists may be built, or nullptr
+    hipEvent_t* ev;                   // ev[1] after the projection, ev[2] after the GEMM, ev[3] after the argmax
+    bool stats;
+    double tol_extra;                 // added to the relative tie window (input rounding of a screen)
+};
+template <typename TS>
+struct ScoreStage {
+    SlabView<TS> sv;
+    GemmPlan plan;
+    double tol_rel;
+    const int* chain;
+    int64_t rd_col0, extra_row0, f64_pairs;
+};
+
 class EngineBase {
    public:
     virtual ~EngineBase() {}
@@ -346,6 +370,7 @@ class EngineBase {
     virtual int set_tie_window(double rel) = 0;
     virtual int set_value_max_exact(int exact) = 0;
     virtual int set_formulation(int f) = 0;
+    virtual int set_screen(int mode) = 0;
     virtual int64_t device_bytes() const = 0;
     virtual int64_t store_append(int which, const void* rows, int64_t n) = 0;
     virtual int64_t store_append_unique(const int32_t* unique_idx, int64_t n) = 0;
@@ -422,9 +447,21 @@ class EngineT : public EngineBase {
     hipEvent_t ev_pg_[2] = {};                       // around the dense projection's GEMM kernel
     bool have_result_ = false, res_sorted_ = false;
     int64_t res_B_ = 0;
+    int screen_mode_ = 1;                                    // fp64 engines: 0 never screen, 1 when the GEMM is large, 2 always
+    bool owns_streams_ = true;                               // false: a screen running on its fp64 engine's streams
+    EngineT<float>* screen_ = nullptr;                       // fp64 engines: the fp32 screen (see ensure_screen)
+    std::vector<int32_t> h_reach_ref_;                       // fp64 engines: the tables in the reference's layout, kept
+    std::vector<double> h_rto_ref_, h_er_ref_;               //   to build the screen on first use
+    uint64_t alpha_ver_ = 1, bel_ver_ = 1;                   // bumped whenever alpha_ / bel_ change
+    uint64_t screen_alpha_seen_ = 0, screen_bel_seen_ = 0;
 
     ~EngineT() override {
         (void)hipSetDevice(device_);
+        if (screen_) {
+            (void)hipStreamSynchronize(stream_);
+            delete screen_;
+            screen_ = nullptr;
+        }
         DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
@@ -443,8 +480,10 @@ class EngineT : public EngineBase {
         if (ev_fork_) (void)hipEventDestroy(ev_fork_);
         if (ev_join_) (void)hipEventDestroy(ev_join_);
         if (ev_lists_) (void)hipEventDestroy(ev_lists_);
-        if (stream2_) (void)hipStreamDestroy(stream2_);
-        if (stream_) (void)hipStreamDestroy(stream_);
+        if (owns_streams_) {
+            if (stream2_) (void)hipStreamDestroy(stream2_);
+            if (stream_) (void)hipStreamDestroy(stream_);
+        }
     }
 
     ModelView<T> view() const {
@@ -461,7 +500,8 @@ class EngineT : public EngineBase {
         return mv;
     }
 
-    int init(int device, int S, int A, int O, int R, const int32_t* reach, const T* rto, const T* er, int mode) {
+    int init(int device, int S, int A, int O, int R, const int32_t* reach, const T* rto, const T* er, int mode,
+             hipStream_t shared_main = nullptr, hipStream_t shared_side = nullptr) {
         device_ = device;
         S_ = S;
         A_ = A;
@@ -469,13 +509,23 @@ class EngineT : public EngineBase {
         R_ = R;
         mode_ = mode;
         S_pad_ = (int)round_up(S, GEMM_BK);
+        if (const char* f = getenv("PBVI_F64_SCREEN")) {      // initial setting (tests run the whole suite with the screen forced)
+            const std::string v(f);
+            screen_mode_ = (v == "off" || v == "0") ? 0 : (v == "always" || v == "2") ? 2 : 1;
+        }
         if (const char* f = getenv("PBVI_FORMULATION")) {     // initial setting (tests run the whole suite both ways)
             const std::string v(f);
             formulation_ = (v == "alpha" || v == "1") ? 1 : (v == "belief" || v == "2") ? 2 : 0;
         }
         HIPCHK(hipSetDevice(device_));
+        if (shared_main != nullptr) {   // an fp32 screen lives on its fp64 engine's streams: one pipeline, one order
+            stream_ = shared_main;
+            stream2_ = shared_side;
+            owns_streams_ = false;
+        } else {
         HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-        {   // The side stream gets its own priority class.  Streams of one class share a small pool of hardware
+        }
+        if (owns_streams_) {   // The side stream gets its own priority class.  Streams of one class share a small pool of hardware
             // queues, assigned round-robin at creation: once a RCCL communicator has created its streams, two
             // normal-priority streams made afterwards can land on one queue and the side work no longer overlaps
             // the projection (measured: ms_project 0.35 -> 0.44 with an idle communicator in the process).
@@ -516,6 +566,19 @@ class EngineT : public EngineBase {
                 }
             }
         h_rs_ = h_rs;
+        if constexpr (!kF32) {   // reference-layout copies for the fp32 screen (built on the first large backup)
+            if (mode == PBVI_SPARSE && (size_t)S * A * O * R <= ((size_t)1 << 28)) {
+                try {
+                    h_reach_ref_.assign(reach, reach + (size_t)S * A * R);
+                    h_rto_ref_.assign(rto, rto + (size_t)S * A * O * R);
+                    h_er_ref_.assign(er, er + (size_t)S * A);
+                } catch (const std::bad_alloc&) {
+                    h_reach_ref_.clear();
+                    h_rto_ref_.clear();
+                    h_er_ref_.clear();
+                }
+            }
+        }
         int rc;
         if ((rc = rs_.ensure(n_rs * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = rto_.ensure(n_rto * sizeof(T), &bytes_))) return rc;
@@ -585,6 +648,7 @@ class EngineT : public EngineBase {
         HIPCHK(hipMemcpy2DAsync(alpha_.p, (size_t)S_pad_ * sizeof(T), alpha, (size_t)S_ * sizeof(T),
                                 (size_t)S_ * sizeof(T), (size_t)V, hipMemcpyHostToDevice, stream_));
         V_ = V;
+        ++alpha_ver_;
         rc = refresh_magnitude_row();
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(stream_));
@@ -616,6 +680,7 @@ class EngineT : public EngineBase {
         HIPCHK(hipMemcpy2DAsync(alpha_.as<T>() + (size_t)V_ * S_pad_, (size_t)S_pad_ * sizeof(T), alpha,
                                 (size_t)S_ * sizeof(T), (size_t)S_ * sizeof(T), (size_t)n, hipMemcpyHostToDevice, stream_));
         V_ = Vn;
+        ++alpha_ver_;
         int rc = refresh_magnitude_row();
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(stream_));
@@ -664,6 +729,7 @@ class EngineT : public EngineBase {
         HIPCHK(hipStreamSynchronize(stream_));
         B_ = B;
         B_pad_ = Bp;
+        ++bel_ver_;
         have_result_ = false;
         btl_valid_ = false;
         return PBVI_OK;
@@ -1055,6 +1121,7 @@ class EngineT : public EngineBase {
                 HIPCHK(hipGetLastError());
             }
             V_ = n;
+            ++alpha_ver_;
             if ((rc = refresh_magnitude_row())) return rc;
             HIPCHK(hipStreamSynchronize(stream_));
             have_result_ = false;
@@ -1089,6 +1156,14 @@ class EngineT : public EngineBase {
 
     int project_dense(double gamma);   // K1-dense: Gamma = gamma * alpha . D_ao^T as A*O (batched) GEMMs
     int backup_run(double gamma, int flags, pbvi_stats_t* st) override;
+
+    // ---- the scoring stage (K1, K2, first-max), runnable on this engine or on an fp64 engine's fp32 screen ---- //
+    bool choose_push(int64_t N) const;
+    int stage_scores(double gamma, bool use_push, const ScoreIO& io, ScoreStage<T>* out);
+    template <typename TS>
+    int run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_stats_t* st);
+    int ensure_screen();
+    int sync_screen();
 
     // per-belief alpha' matrix [B][S] (the reference seam) expanded from the unique rows on first use
     int ensure_full() {
@@ -1556,6 +1631,11 @@ class EngineT : public EngineBase {
         return !simple && m_rows * n_rows >= 64 * 64;
     }
 
+    int set_screen(int mode) override {
+        if (mode < 0 || mode > 2) FAIL(PBVI_EINVAL, "set_f64_screen: 0 = never, 1 = automatic, 2 = always");
+        screen_mode_ = mode;
+        return PBVI_OK;
+    }
     int set_formulation(int f) override {
         if (f < 0 || f > 2) FAIL(PBVI_EINVAL, "set_formulation: 0 = auto, 1 = project alpha-vectors, 2 = project beliefs");
         formulation_ = f;
@@ -1708,42 +1788,237 @@ int EngineT<T>::value_max_device() {
     return PBVI_OK;
 }
 
-template <typename T>
-int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
-    if (V_ <= 0) FAIL(PBVI_EINVAL, "backup_run: no alpha set resident (call pbvi_alpha_set)");
-    if (B_ <= 0) FAIL(PBVI_EINVAL, "backup_run: no belief block resident (call pbvi_beliefs_set)");
-    HIPCHK(hipSetDevice(device_));
-    int rc;
-    const int AO = A_ * O_;
-    const int64_t Vt = V_ + 1;                 // alpha rows + magnitude row
-    const int64_t N = (int64_t)AO * Vt + 2 * A_;   // Gamma rows: alpha groups, A*O magnitude rows, A reward + A |reward| rows
-    const int64_t pairs = B_ * AO;
-    if (N > 0x7fffffff || pairs > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "backup_run: A*O*(V+1) or B*A*O exceeds int32");
-    const ModelView<T> mv = view();
+// fp64 -> fp32 copy of operand rows for the screen (round to nearest even, like NumPy's astype)
+__global__ void k_narrow(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const double2 a = *(const double2*)(src + i), b = *(const double2*)(src + i + 2);
+        *(float4*)(dst + i) = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = (float)src[j];
+    }
+}
 
+template <typename T>
+bool EngineT<T>::choose_push(int64_t N) const {
     // Which operand is projected through the model (same scores, re-associated):
     //   alpha-side (the reference's order): Gamma = A*O*(V+1)+2A rows, GEMM  [B] x [Gamma rows]
     //   belief-side: bp = B*A*O rows,                                  GEMM  [B*A*O] x [V]
     // The belief side wins when B << V (the solve loop: ~100 new beliefs against thousands of alpha-vectors):
     // fewer rows to project and far less tile padding.  Sparse mode only.
-    bool use_push = false;
-    if (mode_ != PBVI_DENSE && (int64_t)B_ * AO <= 0x7fffffff && (kF32 || f64_uses_mfma(B_ * AO, V_))) {
-        const int64_t bm = kF32 ? GEMM_BM : 128;                       // GEMM tile edge and sustained rate per dtype
-        const double rate = kF32 ? 130e12 : 45e12;
-        // projection cost per row, measured at C4: the alpha side writes only the Gamma tiles the GEMM will read
-        // (0.34 ms for 18450 rows), the belief side writes every row in full and re-reads the inverse lists per
-        // belief (2.1 ms for 18432 rows)
-        auto cost = [&](int64_t m_rows, int64_t n_rows, int64_t proj_rows, double proj_rate) {
-            const double tiles = (double)((m_rows + bm - 1) / bm) * (double)((n_rows + bm - 1) / bm);
-            return tiles * S_pad_ * (2.0 * bm * bm / rate) + (double)proj_rows * S_pad_ * sizeof(T) / proj_rate;
-        };
-        const double c_pull = cost(B_, N, N, 6e12), c_push = cost(B_ * AO, V_, B_ * AO, 1e12);
-        use_push = formulation_ == 2 || (formulation_ == 0 && c_push < 0.8 * c_pull);
-    }
-    last_formulation_ = use_push ? 2 : 1;
+    const int AO = A_ * O_;
+    if (mode_ == PBVI_DENSE || (int64_t)B_ * AO > 0x7fffffff || !(kF32 || f64_uses_mfma(B_ * AO, V_))) return false;
+    const int64_t bm = kF32 ? GEMM_BM : 128;                       // GEMM tile edge and sustained rate per dtype
+    const double rate = kF32 ? 130e12 : 45e12;
+    // projection cost per row, measured at C4: the alpha side writes only the Gamma tiles the GEMM will read
+    // (0.34 ms for 18450 rows), the belief side writes every row in full and re-reads the inverse lists per
+    // belief (2.1 ms for 18432 rows)
+    auto cost = [&](int64_t m_rows, int64_t n_rows, int64_t proj_rows, double proj_rate) {
+        const double tiles = (double)((m_rows + bm - 1) / bm) * (double)((n_rows + bm - 1) / bm);
+        return tiles * S_pad_ * (2.0 * bm * bm / rate) + (double)proj_rows * S_pad_ * sizeof(T) / proj_rate;
+    };
+    const double c_pull = cost(B_, N, N, 6e12), c_push = cost(B_ * AO, V_, B_ * AO, 1e12);
+    return formulation_ == 2 || (formulation_ == 0 && c_push < 0.8 * c_pull);
+}
+
+// K1 + K2 + first-max: projection, score GEMM and the argmax over alpha-vectors with near-tie detection, of THIS
+// engine's resident alpha set and belief block (its element type T), into the pipeline buffers `io` names.  Run on
+// the engine itself, or -- by an fp64 engine -- on its fp32 screen.
+template <typename T>
+int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, ScoreStage<T>* out) {
+    int rc;
+    const int AO = A_ * O_;
+    const int64_t Vt = V_ + 1;                 // alpha rows + magnitude row
+    const int64_t N = (int64_t)AO * Vt + 2 * A_;   // Gamma rows: alpha groups, A*O magnitude rows, A reward + A |reward| rows
+    const int64_t pairs = B_ * AO;
+    const ModelView<T> mv = view();
+    const int k_tiles = S_pad_ / GEMM_BK;
     const int64_t n_rows_alloc = kF32 ? round_up(N, GEMM_BN) : N;
-    if (!use_push)
+    if (!use_push) {
         if ((rc = gam_.ensure((size_t)n_rows_alloc * S_pad_ * sizeof(T), &bytes_))) return rc;
+        if (n_rows_alloc > N)   // zero the Gamma pad rows the GEMM tiles read
+            HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)N * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
+    }
+    SlabView<T> sv;
+    out->extra_row0 = -1;
+    if (use_push) {
+        // K1 (belief side): every belief through every (a, o); K2: [B*A*O] x [V]
+        if ((rc = build_inverse_lists())) return rc;
+        // B extra rows behind the projected ones: the beliefs themselves, so the same GEMM also yields b . alpha_v --
+        // compute_change's max_v b.alpha_v of these beliefs against this alpha set (pbvi_backup_fetch_value_max)
+        // rides in the M padding (1800 + 100 rows of 2048 in a solve loop).
+        const int64_t M = (int64_t)AO * B_, Mx = M + B_, M_pad = round_up(Mx, GEMM_BM);
+        if ((rc = bp_.ensure((size_t)M_pad * S_pad_ * sizeof(T), &bytes_))) return rc;
+        if ((rc = pmag_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
+        if ((rc = nzP_.ensure((size_t)(M_pad / GEMM_BM) * k_tiles, &bytes_))) return rc;
+        HIPCHK(hipMemsetAsync(pmag_.p, 0, (size_t)pairs * sizeof(double), stream_));
+        HIPCHK(hipMemcpyAsync(bp_.as<T>() + (size_t)M * S_pad_, bel_.p, (size_t)B_ * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+        if (M_pad > Mx)
+            HIPCHK(hipMemsetAsync(bp_.as<T>() + (size_t)Mx * S_pad_, 0, (size_t)(M_pad - Mx) * S_pad_ * sizeof(T), stream_));
+        HIPCHK(launch_push_project<T>(bel_.as<T>(), S_pad_, (int)B_, mv, in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), gamma,
+                                      alpha_.as<T>() + (size_t)V_ * S_pad_, bp_.as<T>(), S_pad_, pmag_.as<double>(), stream_));
+        if constexpr (kF32)
+            HIPCHK(launch_tile_nonzero_f32((const float*)bp_.p, S_pad_, (int)M_pad, k_tiles, nzP_.as<uint8_t>(), stream_));
+        else
+            HIPCHK(launch_tile_nonzero_f64((const double*)bp_.p, S_pad_, (int)M_pad, k_tiles, nzP_.as<uint8_t>(), stream_));
+        HIPCHK(hipEventRecord(io.ev[1], stream_));
+        if ((rc = score_gemm(alpha_.as<T>(), V_, nullptr, 1, (int)V_, &sv, bp_.as<T>(), Mx, nzP_.as<uint8_t>()))) return rc;
+        out->extra_row0 = M;
+        sv.push = 1;
+        sv.push_B = (int)B_;
+        sv.push_A = A_;
+        sv.push_O = O_;
+        sv.aux_mag = pmag_.as<double>();
+        sv.aux_rd = io.prd;
+    } else {
+        // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
+        const uint8_t* need = nullptr;
+        // f64 engines: the 128-row tiles of their MFMA GEMM nest inside these 256-row ones, so the set is a superset;
+        // the plain kernel (tiny problems) reads every Gamma element and needs them all written.
+        if (kF32 || f64_uses_mfma(B_, N)) {
+            if ((rc = need_.ensure((size_t)AO * k_tiles, &bytes_))) return rc;
+            HIPCHK(launch_need_tiles(nzA_.as<uint8_t>(), (int)(B_pad_ / GEMM_BM), nzB_.as<uint8_t>(), AO, (int)V_, k_tiles,
+                                     need_.as<uint8_t>(), stream_));
+            need = need_.as<uint8_t>();
+        }
+        if (mode_ == PBVI_DENSE) {
+            if (Vt > 65535) FAIL(PBVI_EUNSUPPORTED, "dense mode: at most 65534 alpha-vectors");
+            // pad columns s >= S of the Gamma rows stay zero: clear them once per run (cheap) -- k_scale_rows writes s < S
+            HIPCHK(hipMemsetAsync(gam_.p, 0, (size_t)N * S_pad_ * sizeof(T), stream_));
+            if ((rc = project_dense(gamma))) return rc;
+            if (kF32 && io.stats) {
+                h_kcountD_.resize(kcountD_.cap / sizeof(int));
+                HIPCHK(hipMemcpyAsync(h_kcountD_.data(), kcountD_.p, kcountD_.cap, hipMemcpyDeviceToHost, stream_));
+            }
+        } else {
+            HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_));
+        }
+        HIPCHK(launch_tail_rows<T>(mv, gam_.as<T>() + (size_t)(AO * Vt) * S_pad_, S_pad_, stream_));
+        HIPCHK(hipEventRecord(io.ev[1], stream_));
+        // K2: scores
+        // (its tile lists and stream-K plan are built on the side stream, beside the projection)
+        if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv, nullptr, 0, nullptr, io.side))) return rc;
+    }
+    HIPCHK(hipEventRecord(io.ev[2], stream_));
+    HIPCHK(hipStreamWaitEvent(stream_, io.join, 0));       // dead flags + rdot ready
+    out->plan = plan_;    // value_max_device (K5) re-plans; keep this GEMM's for the stats
+    const int k_chunk = kF32 ? plan_.chunk_len * GEMM_BK : S_pad_;
+    out->tol_rel = tie_window(k_chunk);
+    out->chain = chain_steps();
+    out->rd_col0 = (int64_t)AO * Vt;
+    out->f64_pairs = f64_pairs_;
+    HIPCHK(launch_argmax<T>(sv, (int)V_, AO, (int)B_, io.dead, out->tol_rel, 0.0, out->chain, 0, io.best_v, io.best_score,
+                            io.err, io.queue, io.qcount, stream_, io.tol_extra));
+    HIPCHK(hipEventRecord(io.ev[3], stream_));
+    out->sv = sv;
+    return PBVI_OK;
+}
+
+// fp64 engines: an fp32 twin of the model on the same device and streams, used as a SCREEN.  The fp64 MFMA GEMM runs at
+// its instruction's ceiling (47.6 TFLOP/s measured) -- a third of the fp32 stream-K GEMM -- and decides
+// nothing the fp32 one cannot decide except near-ties.  So the scores are computed in fp32 on rounded copies of the
+// operands, with the tie window widened by the input roundings, and every (belief, action, observation) whose winner
+// is not clear is re-scored from the fp64 originals (the refinement fp32 engines already have, instantiated for
+// double).  Indices and values are those of the pure fp64 path up to its own summation-order noise.
+template <typename T>
+int EngineT<T>::ensure_screen() {
+    if constexpr (kF32) {
+        return PBVI_OK;
+    } else {
+        if (screen_) return PBVI_OK;
+        if (h_rto_ref_.empty()) FAIL(PBVI_ERUNTIME, "screen: host tables were not kept");
+        std::vector<float> rto32(h_rto_ref_.begin(), h_rto_ref_.end()), er32(h_er_ref_.begin(), h_er_ref_.end());
+        auto* e = new (std::nothrow) EngineT<float>();
+        if (!e) FAIL(PBVI_ENOMEM, "screen: host allocation failed");
+        const int rc = e->init(device_, S_, A_, O_, R_, h_reach_ref_.data(), rto32.data(), er32.data(), PBVI_SPARSE, stream_, stream2_);
+        if (rc != PBVI_OK) {
+            delete e;
+            return rc;
+        }
+        e->formulation_ = formulation_;
+        screen_ = e;
+        return PBVI_OK;
+    }
+}
+
+template <typename T>
+int EngineT<T>::sync_screen() {
+    if constexpr (kF32) {
+        return PBVI_OK;
+    } else {
+        EngineT<float>* sc = screen_;
+        int rc;
+        if (screen_alpha_seen_ != alpha_ver_) {
+            const size_t rows = alpha_rows_cap(V_);
+            if ((rc = sc->alpha_.ensure(rows * S_pad_ * sizeof(float), &sc->bytes_))) return rc;
+            const int64_t n = (int64_t)V_ * S_pad_;
+            hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, alpha_.as<double>(),
+                               sc->alpha_.template as<float>(), n);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemsetAsync(sc->alpha_.template as<float>() + n, 0, (rows - (size_t)V_) * S_pad_ * sizeof(float), stream_));
+            sc->V_ = V_;
+            if ((rc = sc->refresh_magnitude_row())) return rc;
+            sc->have_result_ = false;
+            screen_alpha_seen_ = alpha_ver_;
+        }
+        if (screen_bel_seen_ != bel_ver_) {
+            const int k_tiles = S_pad_ / GEMM_BK;
+            if ((rc = sc->bel_.ensure((size_t)B_pad_ * S_pad_ * sizeof(float), &sc->bytes_))) return rc;
+            if ((rc = sc->nzA_.ensure((size_t)(B_pad_ / GEMM_BM) * k_tiles, &sc->bytes_))) return rc;
+            const int64_t n = (int64_t)B_pad_ * S_pad_;      // same row order as this engine's block (pad rows are zero)
+            hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, bel_.as<double>(),
+                               sc->bel_.template as<float>(), n);
+            HIPCHK(hipGetLastError());
+            HIPCHK(launch_tile_nonzero_f32(sc->bel_.template as<float>(), S_pad_, (int)B_pad_, k_tiles, sc->nzA_.template as<uint8_t>(), stream_));
+            sc->B_ = B_;
+            sc->B_pad_ = B_pad_;
+            sc->sorted_ = false;
+            sc->btl_valid_ = false;
+            sc->have_result_ = false;
+            screen_bel_seen_ = bel_ver_;
+        }
+        sc->formulation_ = formulation_;
+        sc->tie_rel_user_ = tie_rel_user_;
+        return PBVI_OK;
+    }
+}
+
+template <typename T>
+int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
+    if (V_ <= 0) FAIL(PBVI_EINVAL, "backup_run: no alpha set resident (call pbvi_alpha_set)");
+    if (B_ <= 0) FAIL(PBVI_EINVAL, "backup_run: no belief block resident (call pbvi_beliefs_set)");
+    HIPCHK(hipSetDevice(device_));
+    if constexpr (!kF32) {
+        const int64_t N = (int64_t)A_ * O_ * (V_ + 1) + 2 * A_;
+        // worth it once the score GEMM is more than a few tiles (tiger, the 4x3 grid, S = 600 models stay pure fp64)
+        const double gemm_flops = 2.0 * (double)round_up(B_, 128) * (double)N * (double)S_pad_;   // ~0.4 ms of fp64 MFMA
+        const bool want = screen_mode_ == 2 || (screen_mode_ == 1 && f64_uses_mfma(B_, N) && gemm_flops >= 2e10);
+        if (want && mode_ == PBVI_SPARSE && !h_rto_ref_.empty()) {
+            int rc = ensure_screen();
+            if (rc) return rc;
+            if ((rc = sync_screen())) return rc;
+            return run_pipeline<float>(*screen_, gamma, flags, st);
+        }
+    }
+    return run_pipeline<T>(*this, gamma, flags, st);
+}
+
+// One backup: `scorer` (this engine, or its fp32 screen) produces scores and first maxima; this engine, which owns
+// the operands in their original precision, decides near-ties, actions and assembles the rows.
+template <typename T>
+template <typename TS>
+int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_stats_t* st) {
+    constexpr bool windows = sizeof(TS) == 4;              // fp32 scores: tie windows + fp64 re-decision
+    constexpr bool screened = sizeof(TS) != sizeof(T);
+    int rc;
+    const int AO = A_ * O_;
+    const int64_t Vt = V_ + 1;                 // alpha rows + magnitude row
+    const int64_t N = (int64_t)AO * Vt + 2 * A_;
+    const int64_t pairs = B_ * AO;
+    if (N > 0x7fffffff || pairs > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "backup_run: A*O*(V+1) or B*A*O exceeds int32");
+    const ModelView<T> mv = view();
+    const bool use_push = scorer.choose_push(N);
+    last_formulation_ = use_push ? 2 : 1;
     if ((rc = best_v_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc;
     if ((rc = best_score_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
     if ((rc = err_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
@@ -1757,8 +2032,6 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     int* qcount = counters_.as<int>();
     int* aqcount = counters_.as<int>() + 1;
     HIPCHK(hipMemsetAsync(counters_.p, 0, 8 * sizeof(int), stream_));
-    if (!use_push && n_rows_alloc > N)   // zero the Gamma pad rows the GEMM tiles read
-        HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)N * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
 
     HIPCHK(hipEventRecord(ev_[0], stream_));
     // Belief-only work (dead triples, b.ER: ~0.1 ms each) on the side stream, beside the projection.
@@ -1768,7 +2041,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     const int k_tiles = S_pad_ / GEMM_BK;
     HIPCHK(hipEventRecord(ev_fork_, stream_));
     HIPCHK(hipStreamWaitEvent(side, ev_fork_, 0));
-    if (kF32) {
+    if (windows) {   // exact, from the supports of the ORIGINAL operands (an fp32 copy may have flushed tiny values to zero)
         if ((rc = btl_.ensure((size_t)B_ * k_tiles * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = btc_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = val_exact_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
@@ -1778,105 +2051,60 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     }
     if (use_push) {   // b . ER[:,a] in f64 (the alpha-side gets it from Gamma's reward rows)
         if ((rc = prd_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
-        HIPCHK(launch_rdot<T>(bel_.as<T>(), S_pad_, (int)B_, mv, btl_.as<int32_t>(), btc_.as<int32_t>(), prd_.as<double>(), side));
+        HIPCHK(launch_rdot<T>(bel_.as<T>(), S_pad_, (int)B_, mv, windows ? btl_.as<int32_t>() : nullptr,
+                              windows ? btc_.as<int32_t>() : nullptr, prd_.as<double>(), side));
     }
     HIPCHK(hipEventRecord(ev_join_, side));
-    SlabView<T> sv;
-    if (use_push) {
-        // K1 (belief side): every belief through every (a, o); K2: [B*A*O] x [V]
-        if ((rc = build_inverse_lists())) return rc;
-        // B extra rows behind the projected ones: the beliefs themselves, so the same GEMM also yields b . alpha_v --
-        // compute_change's max_v b.alpha_v of these beliefs against this alpha set (pbvi_backup_fetch_value_max)
-        // rides in the M padding (1800 + 100 rows of 2048 in a solve loop).
-        const int64_t M = (int64_t)AO * B_, Mx = M + B_, M_pad = round_up(Mx, GEMM_BM);
-        if ((rc = bp_.ensure((size_t)M_pad * S_pad_ * sizeof(T), &bytes_))) return rc;
+
+    ScoreIO io;
+    io.best_v = best_v_.as<int32_t>();
+    io.best_score = best_score_.as<double>();
+    io.err = err_.as<double>();
+    io.queue = windows ? queue_.as<int32_t>() : nullptr;
+    io.qcount = qcount;
+    io.dead = windows ? dead_.as<uint8_t>() : nullptr;
+    io.prd = use_push ? prd_.as<double>() : nullptr;
+    io.join = ev_join_;
+    io.side = no_side ? nullptr : side;
+    io.ev = ev_;
+    io.stats = st != nullptr;
+    // a screen multiplies operands rounded to fp32 (alpha, belief, RTO: 2^-24 relative each) and gamma in fp32
+    io.tol_extra = screened ? 4.0 * 5.9604644775390625e-08 : 0.0;
+    ScoreStage<TS> sc;
+    if ((rc = scorer.stage_scores(gamma, use_push, io, &sc))) return rc;
+    const SlabView<TS>& sv = sc.sv;
+    const GemmPlan plan = sc.plan;
+    if (use_push && !screened) {   // max_v b.alpha_v of these beliefs from the GEMM's extra rows (exact engines only)
         if ((rc = vmax_bk_.ensure((size_t)B_ * sizeof(double), &bytes_))) return rc;
-        if ((rc = pmag_.ensure((size_t)pairs * sizeof(double), &bytes_))) return rc;
-        if ((rc = nzP_.ensure((size_t)(M_pad / GEMM_BM) * k_tiles, &bytes_))) return rc;
-        HIPCHK(hipMemsetAsync(pmag_.p, 0, (size_t)pairs * sizeof(double), stream_));
-        HIPCHK(hipMemcpyAsync(bp_.as<T>() + (size_t)M * S_pad_, bel_.p, (size_t)B_ * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
-        if (M_pad > Mx)
-            HIPCHK(hipMemsetAsync(bp_.as<T>() + (size_t)Mx * S_pad_, 0, (size_t)(M_pad - Mx) * S_pad_ * sizeof(T), stream_));
-        HIPCHK(launch_push_project<T>(bel_.as<T>(), S_pad_, (int)B_, mv, in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), gamma,
-                                      alpha_.as<T>() + (size_t)V_ * S_pad_, bp_.as<T>(), S_pad_, pmag_.as<double>(), stream_));
-        if constexpr (kF32)
-            HIPCHK(launch_tile_nonzero_f32((const float*)bp_.p, S_pad_, (int)M_pad, k_tiles, nzP_.as<uint8_t>(), stream_));
-        else
-            HIPCHK(launch_tile_nonzero_f64((const double*)bp_.p, S_pad_, (int)M_pad, k_tiles, nzP_.as<uint8_t>(), stream_));
-        HIPCHK(hipEventRecord(ev_[1], stream_));
-        if ((rc = score_gemm(alpha_.as<T>(), V_, nullptr, 1, (int)V_, &sv, bp_.as<T>(), Mx, nzP_.as<uint8_t>()))) return rc;
-        hipLaunchKernelGGL(k_extra_rowmax<T>, dim3((unsigned)((B_ + 3) / 4)), dim3(256), 0, stream_, sv, M, (int)B_, (int)V_,
-                           sorted_ ? perm_.as<int32_t>() : nullptr, vmax_bk_.as<double>());
+        hipLaunchKernelGGL(k_extra_rowmax<TS>, dim3((unsigned)((B_ + 3) / 4)), dim3(256), 0, stream_, sv, sc.extra_row0, (int)B_,
+                           (int)V_, sorted_ ? perm_.as<int32_t>() : nullptr, vmax_bk_.as<double>());
         HIPCHK(hipGetLastError());
-        sv.push = 1;
-        sv.push_B = (int)B_;
-        sv.push_A = A_;
-        sv.push_O = O_;
-        sv.aux_mag = pmag_.as<double>();
-        sv.aux_rd = prd_.as<double>();
-    } else {
-    // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
-    const uint8_t* need = nullptr;
-    // f64 engines: the 128-row tiles of their MFMA GEMM nest inside these 256-row ones, so the set is a superset;
-    // the plain kernel (tiny problems) reads every Gamma element and needs them all written.
-    if (kF32 || f64_uses_mfma(B_, N)) {
-        if ((rc = need_.ensure((size_t)AO * k_tiles, &bytes_))) return rc;
-        HIPCHK(launch_need_tiles(nzA_.as<uint8_t>(), (int)(B_pad_ / GEMM_BM), nzB_.as<uint8_t>(), AO, (int)V_, k_tiles,
-                                 need_.as<uint8_t>(), stream_));
-        need = need_.as<uint8_t>();
     }
-    if (mode_ == PBVI_DENSE) {
-        if (Vt > 65535) FAIL(PBVI_EUNSUPPORTED, "dense mode: at most 65534 alpha-vectors");
-        // pad columns s >= S of the Gamma rows stay zero: clear them once per run (cheap) -- k_scale_rows writes s < S
-        HIPCHK(hipMemsetAsync(gam_.p, 0, (size_t)N * S_pad_ * sizeof(T), stream_));
-        if ((rc = project_dense(gamma))) return rc;
-        if (kF32 && st) {
-            h_kcountD_.resize(kcountD_.cap / sizeof(int));
-            HIPCHK(hipMemcpyAsync(h_kcountD_.data(), kcountD_.p, kcountD_.cap, hipMemcpyDeviceToHost, stream_));
-        }
-    } else {
-        HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_));
-    }
-    HIPCHK(launch_tail_rows<T>(mv, gam_.as<T>() + (size_t)(AO * Vt) * S_pad_, S_pad_, stream_));
-    HIPCHK(hipEventRecord(ev_[1], stream_));
-    // K2: scores
-    // (its tile lists and stream-K plan are built on the side stream, beside the projection)
-    if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv, nullptr, 0, nullptr, no_side ? nullptr : side))) return rc;
-    }
-    HIPCHK(hipEventRecord(ev_[2], stream_));
-    HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));       // dead flags + rdot ready
-    const GemmPlan plan = plan_;    // value_max_device (K5) re-plans; keep this GEMM's for the stats
-    const int k_chunk = kF32 ? plan.chunk_len * GEMM_BK : S_pad_;
-    HIPCHK(launch_argmax<T>(sv, (int)V_, AO, (int)B_, kF32 ? dead_.as<uint8_t>() : nullptr, tie_window(k_chunk), 0.0,
-                            chain_steps(), 0,
-                            best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(),
-                            kF32 ? queue_.as<int32_t>() : nullptr, qcount, stream_));
-    HIPCHK(hipEventRecord(ev_[3], stream_));
     std::vector<int> h_kcount;
-    const int64_t f64_pairs = f64_pairs_;
-    if (!kF32 && st && f64_pairs > 0) {
+    const int64_t f64_pairs = sc.f64_pairs;
+    if (!windows && st && f64_pairs > 0) {
         h_kcount.resize((size_t)f64_pairs);
-        HIPCHK(hipMemcpyAsync(h_kcount.data(), kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipMemcpyAsync(h_kcount.data(), scorer.kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
     }
-    if (kF32 && st) {   // list lengths of this GEMM (K5 rebuilds the lists for its own GEMM later)
+    if (windows && st) {   // list lengths of this GEMM (K5 rebuilds the lists for its own GEMM later)
         h_kcount.resize((size_t)plan.tiles_m * plan.tiles_n);
-        HIPCHK(hipMemcpyAsync(h_kcount.data(), kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipMemcpyAsync(h_kcount.data(), scorer.kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
     }
-    RefineWork work;
-    if (kF32)
+    if (windows) {
+        RefineWork work;
         if ((rc = refine_work(pairs, V_, &work))) return rc;
-    if (kF32)
-        HIPCHK(launch_refine<T>(true, sv, (int)V_, AO, (int)pairs, queue_.as<int32_t>(), qcount, bel_.as<T>(), S_pad_,
-                                alpha_.as<T>(), S_pad_, mv, gamma, btl_.as<int32_t>(), btc_.as<int32_t>(), nzB_.as<uint8_t>(),
-                                best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), counters_.as<int>() + 4,
-                                work, stream_));
+        HIPCHK((launch_refine<T, TS>(true, sv, (int)V_, AO, (int)pairs, queue_.as<int32_t>(), qcount, bel_.as<T>(), S_pad_,
+                                     alpha_.as<T>(), S_pad_, mv, gamma, btl_.as<int32_t>(), btc_.as<int32_t>(), nzB_.as<uint8_t>(),
+                                     best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), counters_.as<int>() + 4,
+                                     work, stream_)));
+    }
     HIPCHK(hipEventRecord(ev_[4], stream_));
     // K4: action
     double* rdot_err = rdot_.as<double>() + (size_t)B_ * A_;
-    HIPCHK(launch_action<T>((int)B_, mv, sv, (int64_t)AO * Vt, tie_window(k_chunk), chain_steps(), best_score_.as<double>(),
-                            err_.as<double>(), rdot_.as<double>(), rdot_err, action_.as<int32_t>(),
-                            kF32 ? aqueue_.as<int32_t>() : nullptr, aqcount, stream_));
-    if (kF32)
+    HIPCHK(launch_action<TS>((int)B_, scorer.view(), sv, sc.rd_col0, sc.tol_rel, sc.chain, best_score_.as<double>(),
+                             err_.as<double>(), rdot_.as<double>(), rdot_err, action_.as<int32_t>(),
+                             windows ? aqueue_.as<int32_t>() : nullptr, aqcount, stream_, io.tol_extra));
+    if (windows)
         HIPCHK(launch_refine_action<T>(bel_.as<T>(), S_pad_, (int)B_, alpha_.as<T>(), S_pad_, mv, gamma,
                                        btl_.as<int32_t>(), btc_.as<int32_t>(),
                                        aqueue_.as<int32_t>(), aqcount, rdot_.as<double>(), rdot_err, best_v_.as<int32_t>(),
@@ -1923,20 +2151,18 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
     HIPCHK(hipEventRecord(ev_[7], stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     have_result_ = true;
-    have_bk_vmax_ = use_push;
+    have_bk_vmax_ = use_push && !screened;
     res_B_ = B_;
     const int h_ucount = h_cnt[3];
     res_unique_ = h_ucount;
 
     if (st) {
         std::memset(st, 0, sizeof(*st));
-        float ms = 0.f;
         auto el = [&](int i, int j) {
             float t = 0.f;
             (void)hipEventElapsedTime(&t, ev_[i], ev_[j]);
             return (double)t;
         };
-        (void)ms;
         st->ms_project = el(0, 1);
         st->ms_score = el(1, 2);
         st->ms_argmax = el(2, 3);
@@ -1952,7 +2178,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
         st->n_refined_actions = h[1];
         st->n_unique = h_ucount;
         st->formulation = last_formulation_;
-        st->n_dead = kF32 ? h[5] : 0;                        // counted by k_dead
+        st->n_dead = windows ? h[5] : 0;                     // counted by k_dead
         if (mode_ == PBVI_DENSE) {
             if (kF32) {
                 float t = 0.f;
@@ -1968,7 +2194,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
             }
         }
         st->score_flops = 2 * B_ * (int64_t)S_ * AO * V_;
-        if (kF32) {
+        if (windows) {
             int64_t kt_sum = 0;
             for (int c : h_kcount) kt_sum += c;
             st->score_flops_executed = kt_sum * 2LL * GEMM_BM * GEMM_BN * GEMM_BK;
@@ -1986,6 +2212,7 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
             st->score_flops_executed = st->score_flops;
             st->split_k = 1;
         }
+        st->screened = screened ? 1 : 0;
     }
     return PBVI_OK;
 }
@@ -2360,6 +2587,10 @@ int pbvi_belief_update(pbvi_engine_t* e, const int32_t* actions, const int32_t* 
 int pbvi_set_formulation(pbvi_engine_t* e, int formulation) {
     NEED(e);
     return e->impl->set_formulation(formulation);
+}
+int pbvi_set_f64_screen(pbvi_engine_t* e, int mode) {
+    NEED(e);
+    return e->impl->set_screen(mode);
 }
 int pbvi_set_value_max_exact(pbvi_engine_t* e, int exact) {
     NEED(e);

@@ -722,6 +722,81 @@ def test_adversarial_near_ties(S, B):
 
 
 # --------------------------------------------------------------------------- #
+# fp64 engines behind their fp32 screen (pbvi_set_f64_screen)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize('R', [1, 5])
+def test_f64_engine_screened_equals_pure_at_full_size(R):
+    """fp64 engine at |S|=30000: by default its scores come from the fp32 stream-K GEMM on rounded copies of the operands
+    and every unclear (belief, action, observation) is re-decided from the fp64 originals.  Against the reference's own
+    outputs (indices exact, values to 1e-12) and against the pure fp64 pipeline of the same engine (same bits)."""
+    z, m, alpha, beliefs = _full_fixture(R)
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f64')
+    res = eng.backup_full(alpha, beliefs, m.gamma, belief_dominance_prune=True)
+    assert res.stats['screened'] == 1
+    assert np.array_equal(res.best_alpha_ind, z['core_best']), int(np.sum(res.best_alpha_ind != z['core_best']))
+    assert np.array_equal(res.actions, z['core_actions'])
+    a64 = np.asarray(res.alpha, dtype=np.float64)
+    np.testing.assert_allclose(a64.sum(axis=1), z['row_sum'], rtol=F64_RTOL)
+    np.testing.assert_allclose(np.sum(beliefs * a64, axis=1), z['b_dot'], rtol=F64_RTOL)
+    np.testing.assert_allclose(a64[z['sample_b'], z['sample_s']], z['sample_val'], rtol=F64_RTOL, atol=1e-15)
+    assert np.array_equal(res.keep, z['core_keep'])
+    eng.set_f64_screen('off')
+    pure = eng.backup_full(alpha, beliefs, m.gamma, belief_dominance_prune=True)
+    assert pure.stats['screened'] == 0
+    assert np.array_equal(pure.best_alpha_ind, res.best_alpha_ind) and np.array_equal(pure.actions, res.actions)
+    assert np.array_equal(pure.alpha, res.alpha) and np.array_equal(pure.keep, res.keep)
+    print(f"R={R}: screened {res.stats['ms_total']:.2f} ms (refined {res.stats['n_refined']}/{res.stats['n_pairs']}), "
+          f"pure fp64 {pure.stats['ms_total']:.2f} ms")
+    eng.close()
+
+
+@pytest.mark.parametrize('formulation', ['alpha', 'belief'])
+@pytest.mark.parametrize('R', [1, 5])
+def test_f64_screen_forced_on_small_models(R, formulation):
+    """The screen forced on the S=600 fixtures (where it would not engage by itself), both formulations: the reference's
+    indices, actions, keep mask and values as for the pure fp64 engine."""
+    z, rs, rto, er = small(R)
+    S, A, Rr = rs.shape
+    eng = Engine(S, A, rto.shape[2], Rr, rs, rto, er, dtype='f64')
+    eng.set_f64_screen('always')
+    eng.set_formulation(formulation)
+    res = eng.backup_full(z['alpha'], z['beliefs'], float(z['gamma']), belief_dominance_prune=True)
+    assert res.stats['screened'] == 1 and res.stats['formulation'] == (1 if formulation == 'alpha' else 2)
+    assert np.array_equal(res.best_alpha_ind, z['core_best']) and np.array_equal(res.actions, z['core_actions'])
+    assert_alpha_close(res.alpha, z['core_alpha'], F64_RTOL)
+    assert np.array_equal(res.keep, z['core_keep'])
+    eng.close()
+
+
+def test_f64_screen_decides_what_fp32_cannot_see():
+    """Genuinely fp64 operands: alpha-vectors 1e-7 ... 1e-11 apart (many of them the SAME fp32 number after rounding),
+    beliefs and tables that are not fp32-representable.  The screen sees exact ties or noise there; every argmax must
+    still be the fp64 reference's, which only the re-decision from the fp64 originals can deliver."""
+    rng = np.random.default_rng(43)
+    S, A, O, R, V, B = 3000, 2, 2, 2, 96, 128
+    rs, rto, er = random_model(rng, S, A, O, R)
+    rto = rto * (1.0 + 1e-9 * rng.standard_normal(rto.shape))          # not fp32-representable
+    base = rng.random(S) * 10.0 + 1.0
+    alpha = np.empty((V, S))
+    for v in range(V):
+        alpha[v] = base * (1.0 + 10.0 ** -(7 + (v % 5)) * rng.standard_normal(S))
+    alpha[7] = alpha[3]                                                 # and exact duplicates
+    b = rng.random((B, S)) * (rng.random((B, S)) < 0.05)
+    b[:, 0] += 1e-3
+    b = b / b.sum(axis=1, keepdims=True)
+    new, act, best = orc.backup_core(alpha, b, rs, rto, er, 0.95)
+    eng = Engine(S, A, O, R, rs, rto, er, dtype='f64')
+    eng.set_f64_screen('always')
+    res = eng.backup_full(alpha, b, 0.95)
+    assert res.stats['screened'] == 1
+    assert np.array_equal(res.best_alpha_ind, best), int(np.sum(res.best_alpha_ind != best))
+    assert np.array_equal(res.actions, act)
+    assert_alpha_close(res.alpha, new, F64_RTOL)
+    assert res.stats['n_refined'] > 0.5 * res.stats['n_pairs']
+    eng.close()
+
+
+# --------------------------------------------------------------------------- #
 # MDP value iteration on the device (SURVEY.md section 8f-4)
 # --------------------------------------------------------------------------- #
 def test_device_value_iteration_reproduces_reference_csv():

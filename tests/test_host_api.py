@@ -488,3 +488,16 @@ def test_fsvi_solves_of_example_models_match_reference_host(name, tmp_path):
     assert hist.alpha_vector_counts == list(want['alphas'])
     assert np.array_equal(np.asarray(vf.actions), want['actions'])
     np.testing.assert_allclose(vf.alpha_vector_array, want['alpha'], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/Experiments'), reason='build container only: reads the notebooks in place')
+def test_reference_toy_notebooks_run_unchanged_against_this_src():
+    """North star: "the Experiments notebooks run unchanged".  tests/golden/run_notebooks.py executes the code cells of
+    tiger_problem_from_file.ipynb and observation_variation_comparisson.ipynb (read in place from /root/reference) with
+    ``src`` resolving to this repo's shim and compares what they print with the outputs the notebook files store."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MPLBACKEND='Agg')
+    out = subprocess.run([sys.executable, os.path.join(GOLDEN, 'run_notebooks.py')], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0 and 'notebooks ok' in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
