@@ -78,7 +78,10 @@ hipError_t launch_support(ModelView<T> mv, uint8_t* sup, hipStream_t st);
 // (a,o) group is exactly V rows and stays aligned to the GEMM's 256-row tiles when V % 256 == 0.
 template <typename T>
 hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg,
-                          const uint8_t* need /* [A*O][k_tiles] or nullptr = all */, int k_tiles, hipStream_t st);
+                          const uint8_t* need /* [A*O][k_tiles] or nullptr = all */, int k_tiles, hipStream_t st,
+                          const uint8_t* mat = nullptr /* [ceil(rows/256)]: 1 = write this 256-row tile of Gamma; the
+                                                          others are generated inside the fused score GEMM */,
+                          const int* vlist = nullptr, int n_vlist = 0 /* device list of the 4-row alpha blocks to visit */);
 hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB /* [AO+1][k_tiles] */, int AO, int V,
                              int k_tiles, uint8_t* need, hipStream_t st);
 

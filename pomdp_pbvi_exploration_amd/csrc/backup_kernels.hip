@@ -118,7 +118,9 @@ hipError_t launch_support(ModelView<T> mv, uint8_t* sup, hipStream_t st) {
 // ------------------------------------------------------------------------- //
 template <typename T>
 __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView<T> mv, T gamma,
-                          T* __restrict__ gam, int ldg, const uint8_t* __restrict__ need, int k_tiles) {
+                          T* __restrict__ gam, int ldg, const uint8_t* __restrict__ need, int k_tiles,
+                          const uint8_t* __restrict__ mat /* per 256-row tile of Gamma: write it? (nullptr = all) */,
+                          const int* __restrict__ vlist /* blocks of 4 alpha rows to visit (nullptr = blockIdx.y) */) {
 #pragma clang fp contract(off)   // einsum then scale: sum_r (rto*alpha), one rounding per op, as the reference
     // NS consecutive states per thread = 16 bytes of every table load and Gamma store (float: 4, double: 2; S_pad is a
     // multiple of 32), 4 alpha-vectors x up to 4 observations per pass: 16 NS-wide accumulators.  (With 4 doubles per
@@ -129,7 +131,7 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
     typedef int IN __attribute__((ext_vector_type(NS)));
     const int s = (blockIdx.x * 256 + threadIdx.x) * NS;
     if (s >= mv.S_pad) return;
-    const int v0 = blockIdx.y * 4;
+    const int v0 = (vlist != nullptr ? vlist[blockIdx.y] : (int)blockIdx.y) * 4;
     const int a = blockIdx.z;
     const int nv = (V - v0) < 4 ? (V - v0) : 4;
     const int kt = s >> 5;                                  // GEMM K tile of these states (32 states per tile)
@@ -146,6 +148,16 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
 #pragma unroll
             for (int oj = 0; oj < 4; ++oj) {
                 want[oj] = (oj < no) && need[((int64_t)a * mv.O + o0 + oj) * k_tiles + kt];
+                any |= want[oj];
+            }
+            if (!any) continue;
+        }
+        if (mat != nullptr && v0 + nv < V) {               // tiles the fused GEMM generates itself are not projected
+            bool any = false;
+#pragma unroll
+            for (int oj = 0; oj < 4; ++oj) {
+                const int64_t r0 = ((int64_t)a * mv.O + o0 + oj) * (V - 1) + v0;
+                want[oj] = want[oj] && (oj < no) && (mat[r0 >> 8] | mat[(r0 + nv - 1) >> 8]);
                 any |= want[oj];
             }
             if (!any) continue;
@@ -194,19 +206,20 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
                     const int v = v0 + vj;
                     // alpha rows -> group-major rows; the magnitude row (v == V-1 of the Vt rows) -> tail
                     const int64_t row = (v < V - 1) ? ao * (V - 1) + v : (int64_t)mv.A * mv.O * (V - 1) + ao;
-                    *(TN*)(gam + row * ldg + s) = gamma * acc[vj][oj];
+                    if (mat == nullptr || mat[row >> 8]) *(TN*)(gam + row * ldg + s) = gamma * acc[vj][oj];
                 }
     }
 }
 
 template <typename T>
 hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg,
-                          const uint8_t* need, int k_tiles, hipStream_t st) {
+                          const uint8_t* need, int k_tiles, hipStream_t st, const uint8_t* mat, const int* vlist, int n_vlist) {
     if (V <= 0) return hipSuccess;
+    if (vlist != nullptr && n_vlist <= 0) return hipSuccess;
     constexpr int NS = 16 / (int)sizeof(T);
-    dim3 grid((mv.S_pad / NS + 255) / 256, (V + 3) / 4, mv.A);
+    dim3 grid((mv.S_pad / NS + 255) / 256, vlist != nullptr ? n_vlist : (V + 3) / 4, mv.A);
     if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_project<T>, grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles);
+    hipLaunchKernelGGL(k_project<T>, grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist);
     return hipGetLastError();
 }
 
@@ -1568,7 +1581,7 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
 #define PBVI_INST(T)                                                                                                   \
     template hipError_t launch_support<T>(ModelView<T>, uint8_t*, hipStream_t);                                        \
     template hipError_t launch_project<T>(const T*, int, int, ModelView<T>, T, T*, int, const uint8_t*, int,           \
-                                          hipStream_t);                                                                \
+                                          hipStream_t, const uint8_t*, const int*, int);                               \
     template hipError_t launch_tail_rows<T>(ModelView<T>, T*, int, hipStream_t);                                       \
     template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const uint8_t*, int, uint8_t*, int32_t*,      \
                                        int32_t*, int*, hipStream_t);                                                   \

@@ -448,6 +448,12 @@ class EngineT : public EngineBase {
     bool have_result_ = false, res_sorted_ = false;
     int64_t res_B_ = 0;
     int screen_mode_ = 1;                                    // fp64 engines: 0 never screen, 1 when the GEMM is large, 2 always
+    bool fuse_project_ = true;                               // fp32, R = 1: Gamma tiles generated inside the score GEMM
+    DevBuf irr_;                                             // [A][k_tiles] 1 = a 4-state chunk of the K tile has non-consecutive successors
+    DevBuf mat_, vlist_;                                     // [n-tiles] 1 = projected (straddles groups / tail), 0 = generated
+    std::vector<uint8_t> h_mat_;
+    std::vector<int> h_vlist_;
+    int64_t mat_V_ = -1;
     bool owns_streams_ = true;                               // false: a screen running on its fp64 engine's streams
     EngineT<float>* screen_ = nullptr;                       // fp64 engines: the fp32 screen (see ensure_screen)
     std::vector<int32_t> h_reach_ref_;                       // fp64 engines: the tables in the reference's layout, kept
@@ -468,7 +474,7 @@ class EngineT : public EngineBase {
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &snz_, &sbtl_, &sbtc_, &vmax_bk_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
-                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_};
+                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_};
         for (auto& e : walk_ev_)
             if (e) (void)hipEventDestroy(e);
         for (DevBuf* b : all) b->release();
@@ -602,6 +608,17 @@ class EngineT : public EngineBase {
                     if (h_er[(size_t)a * S_pad_ + s] != T(0)) h_nz[(size_t)A * O * k_tiles + s / GEMM_BK] = 1;
             if ((rc = nzB_.ensure(h_nz.size(), &bytes_))) return rc;
             HIPCHK(hipMemcpyAsync(nzB_.p, h_nz.data(), h_nz.size(), hipMemcpyHostToDevice, stream_));
+            std::vector<int32_t> h_irr;
+            if (kF32 && R == 1 && mode == PBVI_SPARSE) {   // for the fused score GEMM: which K tiles need gathers
+                h_irr.assign((size_t)A * k_tiles, 0);
+                for (int a = 0; a < A; ++a)
+                    for (int c = 0; c < S_pad_ / 4; ++c) {
+                        const int32_t* q = h_rs.data() + (size_t)a * S_pad_ + (size_t)c * 4;
+                        if (q[1] != q[0] + 1 || q[2] != q[0] + 2 || q[3] != q[0] + 3) h_irr[(size_t)a * k_tiles + c / 8] = 1;
+                    }
+                if ((rc = irr_.ensure(h_irr.size() * sizeof(int32_t), &bytes_))) return rc;
+                HIPCHK(hipMemcpyAsync(irr_.p, h_irr.data(), h_irr.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+            }
             HIPCHK(hipStreamSynchronize(stream_));
         }
         if (mode_ == PBVI_DENSE) {   // D[ao] = dense |S| x |S| transition-observation matrices
@@ -1152,7 +1169,8 @@ class EngineT : public EngineBase {
     // G row groups of v_group rows with support nzB (nullptr = dense Y).
     // scores of X rows (default: the resident belief block) against the rows of Y
     int score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv,
-                   const T* X = nullptr, int64_t x_rows = 0, const uint8_t* nzX = nullptr, hipStream_t list_stream = nullptr);
+                   const T* X = nullptr, int64_t x_rows = 0, const uint8_t* nzX = nullptr, hipStream_t list_stream = nullptr,
+                   const FusedB* fused = nullptr);
 
     int project_dense(double gamma);   // K1-dense: Gamma = gamma * alpha . D_ao^T as A*O (batched) GEMMs
     int backup_run(double gamma, int flags, pbvi_stats_t* st) override;
@@ -1658,7 +1676,7 @@ class EngineT : public EngineBase {
 
 template <typename T>
 int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G, int v_group, SlabView<T>* sv,
-                           const T* X, int64_t x_rows, const uint8_t* nzX, hipStream_t list_stream) {
+                           const T* X, int64_t x_rows, const uint8_t* nzX, hipStream_t list_stream, const FusedB* fused) {
     int rc;
     const int64_t m_rows = X ? x_rows : B_;
     const int64_t m_pad = X ? round_up(x_rows, GEMM_BM) : B_pad_;
@@ -1678,7 +1696,8 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
         if ((rc = skws_.ensure(streamk_workspace_ints(plan_) * sizeof(int), &bytes_))) return rc;
         HIPCHK(launch_gemm_nt_f32((const float*)X, S_pad_, (const float*)Y, S_pad_, slabs_.as<float>(), plan_,
                                   nzX, nzB, G, v_group, (int)rows_y, klist_.as<int>(), kcount_.as<int>(),
-                                  nchunks_.as<int>(), stream_, 1, 0, 0, skws_.as<int>(), list_stream, ev_lists_));
+                                  nchunks_.as<int>(), stream_, 1, 0, 0, skws_.as<int>(), list_stream, ev_lists_, nullptr, nullptr,
+                                  fused));
         sv->slabs = slabs_.as<T>();
         sv->slab_stride = plan_.slab_stride;
         sv->ldc = plan_.ldc;
@@ -1873,6 +1892,8 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
     } else {
         // K1: Gamma projection of the V alpha rows and the magnitude row (only tiles the GEMM will read)
         const uint8_t* need = nullptr;
+        FusedB fb{};
+        const FusedB* fused = nullptr;
         // f64 engines: the 128-row tiles of their MFMA GEMM nest inside these 256-row ones, so the set is a superset;
         // the plain kernel (tiny problems) reads every Gamma element and needs them all written.
         if (kF32 || f64_uses_mfma(B_, N)) {
@@ -1891,13 +1912,56 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
                 HIPCHK(hipMemcpyAsync(h_kcountD_.data(), kcountD_.p, kcountD_.cap, hipMemcpyDeviceToHost, stream_));
             }
         } else {
-            HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_));
+            // One reachable state per (s, a) -- every large model of the reference -- on an fp32 engine: the score GEMM
+            // generates the Gamma tiles that lie inside one (a, o) group itself (gemm.hip, scheduler 2b); only the tiles
+            // that straddle two groups and the tail tile are projected here.
+            if constexpr (kF32) {
+                static const bool no_fuse = getenv("PBVI_NO_FUSED_PROJECT") != nullptr;     // debug / A-B only
+                if (R_ == 1 && !no_fuse && fuse_project_ && irr_.p != nullptr) {
+                    const int tiles_n = (int)(round_up(N, GEMM_BN) / GEMM_BN);
+                    if (mat_V_ != V_ || (int)h_mat_.size() != tiles_n) {
+                        h_mat_.assign((size_t)tiles_n, 0);
+                        for (int tn = 0; tn < tiles_n; ++tn) {
+                            const int64_t r0 = (int64_t)tn * 256, r1 = r0 + 255;
+                            h_mat_[(size_t)tn] = (r1 >= (int64_t)AO * V_ || r0 / V_ != r1 / V_) ? 1 : 0;
+                        }
+                        // the 4-row blocks of alpha rows the projection still has to visit: those with a row in a
+                        // projected tile for some group, and the block that holds the magnitude row
+                        h_vlist_.clear();
+                        for (int64_t vb = 0; vb * 4 < Vt; ++vb) {
+                            bool hit = vb * 4 + 4 > V_;
+                            for (int ao = 0; ao < AO && !hit; ++ao)
+                                for (int64_t v = vb * 4; v < vb * 4 + 4 && v < V_ && !hit; ++v) hit = h_mat_[(size_t)((ao * V_ + v) >> 8)] != 0;
+                            if (hit) h_vlist_.push_back((int)vb);
+                        }
+                        if ((rc = mat_.ensure((size_t)tiles_n, &bytes_))) return rc;
+                        if ((rc = vlist_.ensure(h_vlist_.size() * sizeof(int), &bytes_))) return rc;
+                        HIPCHK(hipMemcpyAsync(mat_.p, h_mat_.data(), (size_t)tiles_n, hipMemcpyHostToDevice, stream_));
+                        HIPCHK(hipMemcpyAsync(vlist_.p, h_vlist_.data(), h_vlist_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+                        mat_V_ = V_;
+                    }
+                    fb.alpha = (const float*)alpha_.p;
+                    fb.lda = S_pad_;
+                    fb.rs = rs_.as<int32_t>();
+                    fb.rto = (const float*)rto_.p;
+                    fb.S_pad = S_pad_;
+                    fb.O = O_;
+                    fb.V = (int)V_;
+                    fb.gamma = (float)gamma;
+                    fb.mat = mat_.as<uint8_t>();
+                    fb.irr = irr_.as<int32_t>();
+                    fused = &fb;
+                }
+            }
+            HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_,
+                                     fused ? mat_.as<uint8_t>() : nullptr, fused ? vlist_.as<int>() : nullptr,
+                                     fused ? (int)h_vlist_.size() : 0));
         }
         HIPCHK(launch_tail_rows<T>(mv, gam_.as<T>() + (size_t)(AO * Vt) * S_pad_, S_pad_, stream_));
         HIPCHK(hipEventRecord(io.ev[1], stream_));
         // K2: scores
         // (its tile lists and stream-K plan are built on the side stream, beside the projection)
-        if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv, nullptr, 0, nullptr, io.side))) return rc;
+        if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv, nullptr, 0, nullptr, io.side, fused))) return rc;
     }
     HIPCHK(hipEventRecord(io.ev[2], stream_));
     HIPCHK(hipStreamWaitEvent(stream_, io.join, 0));       // dead flags + rdot ready

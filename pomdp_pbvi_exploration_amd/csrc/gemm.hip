@@ -35,6 +35,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TILE_FLOATS = 256 * GEMM_BK;          // one operand tile: 256 rows x 32 k = 32 KiB
+constexpr int KL_IRR_BIT = 30;                      // tile-list entries: K tile index | (needs gathers << 30), see k_build_klists
+constexpr int KL_MASK = (1 << KL_IRR_BIT) - 1;
 constexpr int GEMM_LDS_BYTES = 4 * TILE_FLOATS * 4;  // 2 buffers x (A tile + B tile) = 128 KiB
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
@@ -83,37 +85,40 @@ __device__ __forceinline__ void tile_stage(const TileThread& t, float* lds, int 
     }
 }
 
-__device__ __forceinline__ void tile_compute(const TileThread& t, const float* lds, int buf, f32x16 (&acc)[4][2]) {
+// MFMA group g of the four 8-wide K groups of a staged tile pair (one ds_read_b128 feeds four MFMAs)
+__device__ __forceinline__ void tile_compute_group(const TileThread& t, const float* lds, int buf, f32x16 (&acc)[4][2], int g) {
     const float* la = lds + buf * 2 * TILE_FLOATS;
     const float* lb = la + TILE_FLOATS;
+    f32x4 af[4], bf[2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 af[4], bf[2];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int pc = (2 * g + t.h) ^ ((t.a_row[mi] >> 1) & 7);
-            af[mi] = *(const f32x4*)(la + t.a_row[mi] * GEMM_BK + pc * 4);
-        }
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int pc = (2 * g + t.h) ^ ((t.b_row[ni] >> 1) & 7);
-            bf[ni] = *(const f32x4*)(lb + t.b_row[ni] * GEMM_BK + pc * 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+    for (int mi = 0; mi < 4; ++mi) {
+        const int pc = (2 * g + t.h) ^ ((t.a_row[mi] >> 1) & 7);
+        af[mi] = *(const f32x4*)(la + t.a_row[mi] * GEMM_BK + pc * 4);
     }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int pc = (2 * g + t.h) ^ ((t.b_row[ni] >> 1) & 7);
+        bf[ni] = *(const f32x4*)(lb + t.b_row[ni] * GEMM_BK + pc * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+}
+
+__device__ __forceinline__ void tile_compute(const TileThread& t, const float* lds, int buf, f32x16 (&acc)[4][2]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) tile_compute_group(t, lds, buf, acc, g);
 }
 
 // Multiply list entries [i0, i1) of one pair into acc (double-buffered LDS-DMA pipeline).
 __device__ __forceinline__ void tile_run(const TileThread& t, float* lds, const float* Ablk, int lda, const float* Bblk,
                                          int ldb, const int* __restrict__ kl, int i0, int i1, f32x16 (&acc)[4][2]) {
-    tile_stage(t, lds, 0, Ablk, lda, Bblk, ldb, kl[i0]);
-    int k_next = (i0 + 1 < i1) ? kl[i0 + 1] : 0;         // list entries are read one step ahead of their use
+    tile_stage(t, lds, 0, Ablk, lda, Bblk, ldb, kl[i0] & KL_MASK);
+    int k_next = (i0 + 1 < i1) ? (kl[i0 + 1] & KL_MASK) : 0;   // list entries are read one step ahead of their use
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
@@ -121,7 +126,7 @@ __device__ __forceinline__ void tile_run(const TileThread& t, float* lds, const 
         int k_after = 0;
         if (it + 1 < i1) {
             tile_stage(t, lds, buf ^ 1, Ablk, lda, Bblk, ldb, k_next);
-            if (it + 2 < i1) k_after = kl[it + 2];
+            if (it + 2 < i1) k_after = kl[it + 2] & KL_MASK;
         }
         tile_compute(t, lds, buf, acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -302,6 +307,197 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk(
 }
 
 // --------------------------------------------------------------------------- //
+// scheduler 2b: stream-K with the Gamma projection FUSED into the B-operand staging (one reachable state per (s, a))
+// --------------------------------------------------------------------------- //
+// Gamma[(g, v)][s] = gamma * rto[g][s] * alpha[v][rs[a][s]]   (g = a*O + o; src/pomdp.py:1485-1491 with R = 1)
+// is not written to HBM for n-tiles that lie inside one (action, observation) group: the block that multiplies the
+// tile generates it on the way into LDS -- per thread and K step one 16-byte load each of the successor indices and
+// of RTO (a thread's four 16-byte chunks of the tile sit in rows 64 apart at the same 4 states), four 16-byte alpha
+// loads (a grid move maps 4 consecutive states to 4 consecutive successors; otherwise four gathers each), 16
+// multiplies, four ds_write_b128 into the same swizzled image the LDS-DMA path produces.  The belief operand still
+// arrives by LDS-DMA.  Same products, same rounding (rto*alpha, then *gamma, contraction off) and same summation
+// order as projecting first, so the scores are bit-identical to the unfused pipeline -- without its 0.8 GB of Gamma
+// writes and the 0.3 ms kernel that makes them.  Tiles flagged in `mat` (those that straddle two groups, and the tail
+// tile with the magnitude / reward rows) are projected as before and take the LDS-DMA path from B.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#ifndef PBVI_FUSED_EXP
+#define PBVI_FUSED_EXP 0      // diagnosis builds only: 1 = no alpha loads, 2 = no LDS stores (wrong results, timing only)
+#endif
+
+// Loads of the generated operand are issued as inline assembly and waited for with explicit s_waitcnt: vector
+// memory operations return in issue order, so "vmcnt(n)" means "all but the last n issued have arrived".  Left to the
+// compiler, every use of a loaded value was preceded by vmcnt(0) -- which also waits for the belief tile's LDS-DMA
+// loads issued a moment earlier, in the middle of the MFMA stream.
+__device__ __forceinline__ void ld16(f32x4& dst, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ld16i(i32x4& dst, const int32_t* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ld4(float& dst, const float* p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+
+__device__ __forceinline__ f32x4 fused_value(float gamma, f32x4 w, f32x4 av) {
+#pragma clang fp contract(off)
+    const f32x4 pr = w * av;                 // one rounding, then the scale: exactly k_project's arithmetic
+    return gamma * pr;
+}
+
+// Multiply list entries [i0, i1) of one pair whose B tile (rows of ONE group) is generated (see above).
+// rsrow / rtorow: the group's successor and RTO rows; arow0: alpha row of the tile's first row + this thread's row;
+// A list entry with bit KL_IRR_BIT set: that K tile holds a 4-state chunk whose successors are not 4 consecutive states
+// (gathers instead of one 16-byte load; block-uniform).
+__device__ __forceinline__ void tile_run_fused(const TileThread& t, float* lds, const float* Ablk, int lda,
+                                               const int32_t* __restrict__ rsrow, const float* __restrict__ rtorow,
+                                               const float* __restrict__ arow0, int64_t a_step /* 64 rows of alpha */,
+                                               float gamma, const int* __restrict__ kl,
+                                               int i0, int i1, f32x16 (&acc)[4][2]) {
+    const int tid = threadIdx.x;
+    auto stage_a = [&](int buf, int entry) {
+        const int kt = entry & KL_MASK;
+        float* la = lds + buf * 2 * TILE_FLOATS;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            glds16(Ablk + (int64_t)t.srow[it] * lda + kt * GEMM_BK + t.scol[it], la + (it * 512 + t.wid * 64) * 4);
+    };
+    // scol is the same for a thread's four chunks (their rows differ by 64): one table load pair serves all four.
+    // Schedule of a K step -- the MFMA groups g0..g3 of the CURRENT tile carry the latencies of the NEXT tile's operands:
+    //   tables, belief DMA | g0 | wait tables; alpha loads | g1 | g2 | wait all; scale + 4 ds_write_b128 | g3 | barrier
+    i32x4 idx;
+    f32x4 w, av[4];
+    auto tables = [&](int entry) {
+        const int s = (entry & KL_MASK) * GEMM_BK + t.scol[0];
+        ld16i(idx, rsrow + s);
+        ld16(w, rtorow + s);
+    };
+    auto alphas = [&](int entry) {
+        if (entry >> KL_IRR_BIT) {                        // block-uniform: the list entry carries the flag (k_build_klists)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float* arow = arow0 + it * a_step;
+                float e0, e1, e2, e3;
+                ld4(e0, arow + idx[0]);
+                ld4(e1, arow + idx[1]);
+                ld4(e2, arow + idx[2]);
+                ld4(e3, arow + idx[3]);
+                // (assembled before the wait: register moves of values still in flight would be wrong, so the vector is
+                // built by the same asm that waits)
+                asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                             : "=&v"(av[it].x), "=&v"(av[it].y), "=&v"(av[it].z), "=&v"(av[it].w)
+                             : "v"(e0), "v"(e1), "v"(e2), "v"(e3)
+                             : "memory");
+            }
+        } else {
+#if PBVI_FUSED_EXP == 1
+#pragma unroll
+            for (int it = 0; it < 4; ++it) av[it] = w;
+#else
+#pragma unroll
+            for (int it = 0; it < 4; ++it) ld16(av[it], arow0 + it * a_step + idx[0]);
+#endif
+        }
+    };
+    auto store_b = [&](int buf) {
+        float* lb = lds + buf * 2 * TILE_FLOATS + TILE_FLOATS;
+#if PBVI_FUSED_EXP == 2
+        if (gamma == 12345.f)
+#endif
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *(f32x4*)(lb + (it * 512 + tid) * 4) = fused_value(gamma, w, av[it]);
+    };
+    // first tile of the segment: nothing to overlap with
+    tables(kl[i0]);
+    stage_a(0, kl[i0]);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(idx), "+v"(w)::"memory");
+    alphas(kl[i0]);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3])::"memory");
+    store_b(0);
+    int k_next = (i0 + 1 < i1) ? kl[i0 + 1] : 0;         // list entries are read one step ahead of their use
+    __syncthreads();
+    int buf = 0;
+    for (int it = i0; it < i1; ++it) {
+        int k_after = 0;
+        const bool more = it + 1 < i1;                    // block-uniform
+        if (more) {
+            tables(k_next);                               // the 2 small loads first, then the 4 DMA loads of the belief tile
+            stage_a(buf ^ 1, k_next);
+            if (it + 2 < i1) k_after = kl[it + 2];
+        }
+        tile_compute_group(t, lds, buf, acc, 0);
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(idx), "+v"(w)::"memory");      // the tables are here; the DMA may not be
+            alphas(k_next);
+        }
+        tile_compute_group(t, lds, buf, acc, 1);
+        tile_compute_group(t, lds, buf, acc, 2);
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3])::"memory");
+            store_b(buf ^ 1);
+        }
+        tile_compute_group(t, lds, buf, acc, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+        k_next = k_after;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk_fused(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, FusedB fb, float* __restrict__ C, int ldc,
+    int64_t slab_stride, int tiles_m, int pairs, int k_tiles, const int* __restrict__ klist, const int* __restrict__ kcount,
+    const int* __restrict__ prefix, const int* __restrict__ start_pair, const int* __restrict__ first_block,
+    const int* __restrict__ plan, int ovh) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nb = gridDim.x;
+    int L;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, qq = nb >> 3, r = nb & 7;
+        const int base = (xcd < r) ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq;
+        L = base + (bid >> 3);
+    }
+    const int q = plan[0], T = plan[1];
+    int64_t pos = (int64_t)L * q;
+    if (pos >= T) return;
+    const int64_t end = (pos + q < T) ? pos + q : T;
+    int p = start_pair[L];
+    if (p < 0) return;
+    TileThread t;
+    t.init();
+    while (pos < end && p < pairs) {
+        const int cnt = kcount[p];
+        if (cnt == 0) {                                  // block-uniform
+            ++p;
+            continue;
+        }
+        const int u_lo = (int)(pos - prefix[p]);
+        const int64_t room = end - pos;
+        const int u_hi = (u_lo + room < cnt + ovh) ? (int)(u_lo + room) : cnt + ovh;
+        const int lo = u_lo > ovh ? u_lo - ovh : 0;
+        const int hi = u_hi > ovh ? u_hi - ovh : 0;
+        if (hi > lo) {
+            const int tm = p % tiles_m, tn = p / tiles_m;
+            f32x16 acc[4][2];
+            tile_zero(acc);
+            if (fb.mat[tn]) {                            // block-uniform: projected rows, the LDS-DMA path
+                tile_run(t, lds, A + (int64_t)tm * 256 * lda, lda, B + (int64_t)tn * 256 * ldb, ldb,
+                         klist + (int64_t)p * k_tiles, lo, hi, acc);
+            } else {
+                const int r0 = tn * 256;
+                const int g = r0 / fb.V, v0 = r0 - g * fb.V;                 // scalar: all 256 rows belong to group g
+                tile_run_fused(t, lds, A + (int64_t)tm * 256 * lda, lda, fb.rs + (int64_t)(g / fb.O) * fb.S_pad,
+                               fb.rto + (int64_t)g * fb.S_pad, fb.alpha + (int64_t)(v0 + t.srow[0]) * fb.lda,
+                               (int64_t)64 * fb.lda, fb.gamma,
+                               klist + (int64_t)p * k_tiles, lo, hi, acc);
+            }
+            tile_store(t, C + (int64_t)(L - first_block[p]) * slab_stride, ldc, tm, tn, acc);
+        }
+        pos += u_hi - u_lo;
+        ++p;
+    }
+}
+
+// --------------------------------------------------------------------------- //
 // Zero-tile bookkeeping
 // --------------------------------------------------------------------------- //
 // nz[tile][kt] = 1 iff the 256-row x 32-column block of X has a non-zero entry.
@@ -328,9 +524,12 @@ __global__ void k_tile_nonzero(const float* __restrict__ X, int ld, int k_tiles,
 // one (action, observation)); rows >= G*v_group (magnitude and reward rows) may touch any group or the extra
 // support row nzB[G] (so nzB is [G+1][k_tiles]); G == 0 -> per n-tile flags nzB[batch][tn][kt]; nzB == nullptr
 // -> dense.
+// irr != nullptr (fused projection): an entry of a tile that lies inside one row group carries, in bit KL_IRR_BIT, whether
+// its K tile needs gathers for that group's action (irr[a][kt], a = group / groups_per_action); consumers mask it off.
 __global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* __restrict__ nzB, int G,
                                int v_group, int n_rows, int tiles_m, int k_tiles, int chunk_len, int force_dense,
-                               int* __restrict__ klist, int* __restrict__ kcount, int* __restrict__ nchunks) {
+                               int* __restrict__ klist, int* __restrict__ kcount, int* __restrict__ nchunks,
+                               const int32_t* __restrict__ irr, int groups_per_action) {
     __shared__ int wcount[4];
     __shared__ int total;
     const int tiles_n = gridDim.x / tiles_m;
@@ -372,7 +571,11 @@ __global__ void k_build_klists(const uint8_t* __restrict__ nzA, const uint8_t* _
         __syncthreads();
         int off = total;
         for (int w = 0; w < wid; ++w) off += wcount[w];
-        if (f) klist[(int64_t)pair * k_tiles + off + __popcll(mask & ((1ull << lane) - 1ull))] = kt;
+        if (f) {
+            int entry = kt;
+            if (irr != nullptr && g0 == g1 && g1 < G && irr[(int64_t)(g0 / groups_per_action) * k_tiles + kt]) entry |= 1 << KL_IRR_BIT;
+            klist[(int64_t)pair * k_tiles + off + __popcll(mask & ((1ull << lane) - 1ull))] = entry;
+        }
         __syncthreads();
         if (tid == 0) total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
         __syncthreads();
@@ -436,6 +639,9 @@ static hipError_t set_lds_attr() {
     e = hipFuncSetAttribute((const void*)k_gemm_nt_f32_streamk, hipFuncAttributeMaxDynamicSharedMemorySize,
                             GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_gemm_nt_f32_streamk_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
     done = true;
     return hipSuccess;
 }
@@ -444,7 +650,7 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
                               const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int n_rows, int* klist,
                               int* kcount, int* nchunks, hipStream_t stream, int batch, int64_t batch_stride_b,
                               int64_t batch_stride_c, int* streamk_ws, hipStream_t list_stream, hipEvent_t list_event,
-                              hipEvent_t ev_before, hipEvent_t ev_after) {
+                              hipEvent_t ev_before, hipEvent_t ev_after, const FusedB* fused) {
     hipError_t e = set_lds_attr();
     if (e != hipSuccess) return e;
     if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
@@ -453,8 +659,10 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
     // The tile lists and the stream-K plan depend on the zero maps only, not on the operands' values: with a
     // list_stream they are built beside whatever `stream` is still doing (the Gamma projection) and the GEMM waits.
     hipStream_t ls = (list_stream != nullptr && list_event != nullptr) ? list_stream : stream;
+    if (fused != nullptr && !pl.streamk) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_build_klists, dim3(pairs, batch), dim3(256), 0, ls, nzA, nzB, G, v_group, n_rows,
-                       pl.tiles_m, pl.k_tiles, pl.chunk_len, force_dense, klist, kcount, nchunks);
+                       pl.tiles_m, pl.k_tiles, pl.chunk_len, force_dense, klist, kcount, nchunks,
+                       fused != nullptr ? fused->irr : nullptr, fused != nullptr ? fused->O : 1);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (pl.streamk) {
@@ -472,9 +680,14 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
             if ((e = hipEventRecord(list_event, ls)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(stream, list_event, 0)) != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_gemm_nt_f32_streamk, dim3(pl.nblocks), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B, ldb, C,
-                           pl.ldc, pl.slab_stride, pl.tiles_m, pairs, pl.k_tiles, klist, kcount, prefix, start_pair,
-                           first_block, plan, ovh);
+        if (fused != nullptr)
+            hipLaunchKernelGGL(k_gemm_nt_f32_streamk_fused, dim3(pl.nblocks), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B, ldb,
+                               *fused, C, pl.ldc, pl.slab_stride, pl.tiles_m, pairs, pl.k_tiles, klist, kcount, prefix, start_pair,
+                               first_block, plan, ovh);
+        else
+            hipLaunchKernelGGL(k_gemm_nt_f32_streamk, dim3(pl.nblocks), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B, ldb, C,
+                               pl.ldc, pl.slab_stride, pl.tiles_m, pairs, pl.k_tiles, klist, kcount, prefix, start_pair,
+                               first_block, plan, ovh);
         return hipGetLastError();
     }
     if (ls != stream) {

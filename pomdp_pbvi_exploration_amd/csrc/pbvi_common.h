@@ -34,6 +34,20 @@ struct GemmPlan {
 int set_gemm_force_dense(int enable);   // returns the previous setting (see gemm.hip)
 int gemm_force_dense();
 size_t streamk_workspace_ints(const GemmPlan& pl);   // ints of device workspace the stream-K plan needs
+// B operand generated inside the stream-K GEMM instead of read from HBM (gemm.hip, "scheduler 2b"): row (g, v) of an
+// n-tile with mat[tile] == 0 -- all of whose 256 rows belong to one group g -- is gamma * rto[g][s] * alpha[v][rs[g / O][s]]
+// (one reachable state per (s, a)); tiles with mat[tile] != 0 are read from B as usual.
+struct FusedB {
+    const float* alpha;   // [V][lda]
+    int lda;
+    const int32_t* rs;    // [A][S_pad]
+    const float* rto;     // [A*O][S_pad]
+    int S_pad, O, V;      // groups of V rows each
+    float gamma;
+    const uint8_t* mat;   // [tiles_n] device
+    const int32_t* irr;   // [A][K_pad/32] device (int32: read with scalar loads): 1 = the K tile holds a 4-state chunk
+                          // with non-consecutive successors
+};
 // single_chunk: one K chunk per pair, i.e. slab 0 is the finished product (no split-K).
 GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad, bool single_chunk = false);
 hipError_t launch_tile_nonzero_f32(const float* X, int ld, int rows_pad, int k_tiles, uint8_t* nz, hipStream_t stream);
@@ -44,7 +58,9 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
                               int* kcount, int* nchunks, hipStream_t stream, int batch = 1,
                               int64_t batch_stride_b = 0, int64_t batch_stride_c = 0, int* streamk_ws = nullptr,
                               hipStream_t list_stream = nullptr, hipEvent_t list_event = nullptr,
-                              hipEvent_t ev_before = nullptr, hipEvent_t ev_after = nullptr);   // around the GEMM kernel (non-stream-K)
+                              hipEvent_t ev_before = nullptr, hipEvent_t ev_after = nullptr,   // around the GEMM kernel (non-stream-K)
+                              const FusedB* fused = nullptr);
+// fused: generate the B tiles that lie inside one row group (stream-K only); the others are read from B.
 // list_stream + list_event: build the tile lists / stream-K plan on that stream (they need the zero maps only) and
 // make `stream` wait for them before the GEMM kernel.
 // streamk_ws layout: prefix[pairs+1], start_pair[nblocks], first_block[pairs], plan[2] = {steps per block, total steps}

@@ -64,6 +64,7 @@ def load_library(path: str = LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    path = os.environ.get('PBVI_LIB_PATH', path)         # A/B of experimental builds of the same ABI
     if not os.path.exists(path):
         raise EngineUnavailable(f'{path} not found: build it with `python -m pomdp_pbvi_exploration_amd.build`')
     try:
