@@ -152,6 +152,19 @@ hipError_t launch_refine(bool proj, SlabView<TS> sv, int V, int G, int max_entri
                          int32_t* best_v, double* best_score, double* err, int* cand_total /* += candidates, or nullptr */,
                          RefineWork work, hipStream_t st);
 
+// The same in two parts, for callers that do not want to synchronise in between: the per-entry pass (what it deferred
+// lands in counts_host[2], pinned, via the stream) and the pass over the deferred entries.
+template <typename T, typename TS>
+hipError_t launch_refine_scan(bool proj, SlabView<TS> sv, int V, int G, int max_entries, const int32_t* queue,
+                              const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
+                              double gamma, const int32_t* btl, const int32_t* btc, const uint8_t* nzG, int32_t* best_v,
+                              double* best_score, double* err, int* cand_total, RefineWork work, int* counts_host,
+                              hipStream_t st);
+template <typename T>
+hipError_t launch_refine_deferred(bool proj, int V, int G, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
+                                  double gamma, int32_t* best_v, double* best_score, double* err, RefineWork work,
+                                  int h_items, int h_slots, hipStream_t st);
+
 // btl [B][k_tiles] / btc [B]: compact lists of each belief's non-zero 32-state tiles
 template <typename T>
 hipError_t launch_belief_tiles(const T* bel, int ldb, int B, int S, int k_tiles, int32_t* btl, int32_t* btc,
@@ -169,7 +182,7 @@ template <typename T>
 hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv, double gamma,
                                 const int32_t* btl, const int32_t* btc, const int32_t* aqueue, const int* aqcount,
                                 const double* rdot, const double* rdot_err, const int32_t* best_v,
-                                const double* best_score, const double* err, double* val_exact /* [B][A] scratch */,
+                                const double* best_score, const double* err, double* val_exact /* [B][A][1+O] scratch */,
                                 int32_t* action, hipStream_t st);
 
 // K3: out[u][s] = ER[s,a*] + sum_o gamma * sum_r rto[a*][o][r][s] * alpha[v*[b,a*,o]][rs[a*][r][s]], b = rows[u]

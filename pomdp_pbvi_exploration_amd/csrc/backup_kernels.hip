@@ -866,11 +866,14 @@ __global__ void k_refine_slot_argmax(RefineWork work, int V, int32_t* __restrict
     }
 }
 
+// Part 1: the per-entry pass.  What it deferred (work.cnt: items, slots) is copied to counts_host (pinned, 2 ints) on
+// the stream; the caller synchronises -- or speculates that nothing was deferred and checks later.
 template <typename T, typename TS>
-hipError_t launch_refine(bool proj, SlabView<TS> sv, int V, int G, int max_entries, const int32_t* queue,
-                         const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
-                         double gamma, const int32_t* btl, const int32_t* btc, const uint8_t* nzG, int32_t* best_v,
-                         double* best_score, double* err, int* cand_total, RefineWork work, hipStream_t st) {
+hipError_t launch_refine_scan(bool proj, SlabView<TS> sv, int V, int G, int max_entries, const int32_t* queue,
+                              const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
+                              double gamma, const int32_t* btl, const int32_t* btc, const uint8_t* nzG, int32_t* best_v,
+                              double* best_score, double* err, int* cand_total, RefineWork work, int* counts_host,
+                              hipStream_t st) {
     if (max_entries <= 0) return hipSuccess;
     hipError_t e;
     if (work.items_v != nullptr) {
@@ -884,49 +887,71 @@ hipError_t launch_refine(bool proj, SlabView<TS> sv, int V, int G, int max_entri
         hipLaunchKernelGGL((k_refine<T, TS, false>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel,
                            ldb, alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (work.items_v != nullptr) {
-        // how much was deferred decides what is launched next (one 8-byte read-back; most launches defer nothing)
-        int h_cnt[2] = {0, 0};
-        if ((e = hipMemcpyAsync(h_cnt, work.cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-        const int n_items = h_cnt[0] < work.item_cap ? h_cnt[0] : work.item_cap;
-        const int n_slots = h_cnt[1] < work.slot_cap ? h_cnt[1] : work.slot_cap;
-        const int n_w = n_slots < work.w_slot_cap ? n_slots : work.w_slot_cap;
-        if (n_w > 0) {   // GEMM path: weights -> tile map -> [n_w x S] x [V x S]^T in fp64 on the MFMA -> first max
-            dim3 wgrid((mv.S_pad + 255) / 256, n_w);
-            if (proj)
-                hipLaunchKernelGGL((k_refine_weights<T, true>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
-            else
-                hipLaunchKernelGGL((k_refine_weights<T, false>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            if ((e = launch_tile_nonzero_f64(work.W, mv.S_pad, n_w, mv.S_pad / 32, work.nzW, st)) != hipSuccess) return e;
-            if constexpr (sizeof(T) == 4) {   // fp32 alpha rows widened exactly on the way into LDS
-                if ((e = launch_gemm_nt_f64_bf32(work.W, mv.S_pad, n_w, (const float*)alpha, lda, V, work.Cx, V, mv.S_pad,
-                                                 work.nzW, work.klistW, work.kcountW, st)) != hipSuccess)
-                    return e;
-            } else {                          // fp64 engine behind an fp32 screen: the fp64 originals
-                if ((e = launch_gemm_nt_f64(work.W, mv.S_pad, n_w, (const double*)alpha, lda, V, work.Cx, V, mv.S_pad,
-                                            work.nzW, nullptr, 0, 0, work.klistW, work.kcountW, st)) != hipSuccess)
-                    return e;
-            }
-            hipLaunchKernelGGL(k_refine_slot_argmax, dim3(n_w), dim3(256), 0, st, work, V, best_v, best_score, err);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (work.items_v != nullptr && counts_host != nullptr)
+        if ((e = hipMemcpyAsync(counts_host, work.cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+// Part 2: the entries the per-entry pass handed on (h_items / h_slots as read back from work.cnt).
+template <typename T>
+hipError_t launch_refine_deferred(bool proj, int V, int G, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
+                                  double gamma, int32_t* best_v, double* best_score, double* err, RefineWork work,
+                                  int h_items, int h_slots, hipStream_t st) {
+    hipError_t e;
+    if (work.items_v == nullptr) return hipSuccess;
+    const int n_items = h_items < work.item_cap ? h_items : work.item_cap;
+    const int n_slots = h_slots < work.slot_cap ? h_slots : work.slot_cap;
+    const int n_w = n_slots < work.w_slot_cap ? n_slots : work.w_slot_cap;
+    if (n_w > 0) {   // GEMM path: weights -> tile map -> [n_w x S] x [V x S]^T in fp64 on the MFMA -> first max
+        dim3 wgrid((mv.S_pad + 255) / 256, n_w);
+        if (proj)
+            hipLaunchKernelGGL((k_refine_weights<T, true>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
+        else
+            hipLaunchKernelGGL((k_refine_weights<T, false>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = launch_tile_nonzero_f64(work.W, mv.S_pad, n_w, mv.S_pad / 32, work.nzW, st)) != hipSuccess) return e;
+        if constexpr (sizeof(T) == 4) {   // fp32 alpha rows widened exactly on the way into LDS
+            if ((e = launch_gemm_nt_f64_bf32(work.W, mv.S_pad, n_w, (const float*)alpha, lda, V, work.Cx, V, mv.S_pad,
+                                             work.nzW, work.klistW, work.kcountW, st)) != hipSuccess)
+                return e;
+        } else {                          // fp64 engine behind an fp32 screen: the fp64 originals
+            if ((e = launch_gemm_nt_f64(work.W, mv.S_pad, n_w, (const double*)alpha, lda, V, work.Cx, V, mv.S_pad,
+                                        work.nzW, nullptr, 0, 0, work.klistW, work.kcountW, st)) != hipSuccess)
+                return e;
         }
-        if (n_items > 0) {
-            const int blocks = 2048;                       // 8192 waves: every SIMD of the chip has work in flight
-            if (proj)
-                hipLaunchKernelGGL((k_refine_items<T, true>), dim3(blocks), dim3(256), 0, st, G, bel, ldb, alpha, lda, mv,
-                                   gamma, work);
-            else
-                hipLaunchKernelGGL((k_refine_items<T, false>), dim3(blocks), dim3(256), 0, st, G, bel, ldb, alpha, lda, mv,
-                                   gamma, work);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_refine_first, dim3(1024), dim3(256), 0, st, work);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        if (n_slots > n_w) hipLaunchKernelGGL(k_refine_merge, dim3(64), dim3(256), 0, st, work, best_v, best_score, err);
+        hipLaunchKernelGGL(k_refine_slot_argmax, dim3(n_w), dim3(256), 0, st, work, V, best_v, best_score, err);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    if (n_items > 0) {
+        const int blocks = 2048;                       // 8192 waves: every SIMD of the chip has work in flight
+        if (proj)
+            hipLaunchKernelGGL((k_refine_items<T, true>), dim3(blocks), dim3(256), 0, st, G, bel, ldb, alpha, lda, mv,
+                               gamma, work);
+        else
+            hipLaunchKernelGGL((k_refine_items<T, false>), dim3(blocks), dim3(256), 0, st, G, bel, ldb, alpha, lda, mv,
+                               gamma, work);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_refine_first, dim3(1024), dim3(256), 0, st, work);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (n_slots > n_w) hipLaunchKernelGGL(k_refine_merge, dim3(64), dim3(256), 0, st, work, best_v, best_score, err);
     return hipGetLastError();
+}
+
+template <typename T, typename TS>
+hipError_t launch_refine(bool proj, SlabView<TS> sv, int V, int G, int max_entries, const int32_t* queue,
+                         const int* qcount, const T* bel, int ldb, const T* alpha, int lda, ModelView<T> mv,
+                         double gamma, const int32_t* btl, const int32_t* btc, const uint8_t* nzG, int32_t* best_v,
+                         double* best_score, double* err, int* cand_total, RefineWork work, hipStream_t st) {
+    if (max_entries <= 0) return hipSuccess;
+    int h_cnt[2] = {0, 0};
+    hipError_t e = launch_refine_scan<T, TS>(proj, sv, V, G, max_entries, queue, qcount, bel, ldb, alpha, lda, mv, gamma, btl,
+                                             btc, nzG, best_v, best_score, err, cand_total, work, h_cnt, st);
+    if (e != hipSuccess || work.items_v == nullptr) return e;
+    // how much was deferred decides what is launched next (one 8-byte read-back; most launches defer nothing)
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    return launch_refine_deferred<T>(proj, V, G, bel, ldb, alpha, lda, mv, gamma, best_v, best_score, err, work, h_cnt[0],
+                                     h_cnt[1], st);
 }
 
 // ------------------------------------------------------------------------- //
@@ -1016,63 +1041,75 @@ hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0
     return hipGetLastError();
 }
 
-// Exact (f64) value of every candidate action of a flagged belief: one block per (belief, action).
+// Exact (f64) value of every candidate action of a flagged belief.  One block per (queued belief, action, term):
+// term 0 is b . ER[:,a], term 1 + o the score of observation o -- the 1 + O dots of an action used to run one after the
+// other in one block (60 us of dependent latency for two dozen beliefs); k_action_final adds them in that same order.
 template <typename T>
 __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
                                 ModelView<T> mv, double gamma, const int32_t* __restrict__ btl,
                                 const int32_t* __restrict__ btc, const int32_t* __restrict__ aqueue, const int* __restrict__ aqcount,
                                 const double* __restrict__ rdot, const double* __restrict__ rdot_err,
                                 const int32_t* __restrict__ best_v, const double* __restrict__ best_score,
-                                const double* __restrict__ err, double* __restrict__ val_exact) {
+                                const double* __restrict__ err, double* __restrict__ val_parts /* [B][A][1+O] */) {
     __shared__ double red[4];
     __shared__ int cand_sh;
-    if ((int)blockIdx.x >= *aqcount) return;
-    const int b = aqueue[blockIdx.x], a = blockIdx.y, tid = threadIdx.x;
-    if (tid == 0) {   // is action a within the error window of the best lower bound?
-        double lo = -std::numeric_limits<double>::infinity(), va = 0.0, Ea = 0.0;
-        for (int x = 0; x < mv.A; ++x) {
-            double v = rdot[(int64_t)b * mv.A + x], E = rdot_err[(int64_t)b * mv.A + x];
-            for (int o = 0; o < mv.O; ++o) {
-                const int64_t e = ((int64_t)b * mv.A + x) * mv.O + o;
-                v += best_score[e];
-                E += err[e];
+    const int n_q = *aqcount;
+    const int terms = 1 + mv.O;
+    const int a = blockIdx.y / terms, term = blockIdx.y % terms, tid = threadIdx.x;
+    for (int q = blockIdx.x; q < n_q; q += gridDim.x) {
+        const int b = aqueue[q];
+        __syncthreads();
+        if (tid == 0) {   // is action a within the error window of the best lower bound?
+            double lo = -std::numeric_limits<double>::infinity(), va = 0.0, Ea = 0.0;
+            for (int x = 0; x < mv.A; ++x) {
+                double v = rdot[(int64_t)b * mv.A + x], E = rdot_err[(int64_t)b * mv.A + x];
+                for (int o = 0; o < mv.O; ++o) {
+                    const int64_t e = ((int64_t)b * mv.A + x) * mv.O + o;
+                    v += best_score[e];
+                    E += err[e];
+                }
+                lo = fmax(lo, v - E);
+                if (x == a) {
+                    va = v;
+                    Ea = E;
+                }
             }
-            lo = fmax(lo, v - E);
-            if (x == a) {
-                va = v;
-                Ea = E;
-            }
+            cand_sh = (va + Ea >= lo) ? 1 : 0;
         }
-        cand_sh = (va + Ea >= lo) ? 1 : 0;
+        __syncthreads();
+        double* part = val_parts + ((int64_t)b * mv.A + a) * terms + term;
+        if (!cand_sh) {
+            if (tid == 0) *part = -std::numeric_limits<double>::infinity();
+            continue;
+        }
+        const T* brow = bel + (int64_t)b * ldb;
+        const int k_tiles = mv.S_pad >> 5;
+        const TileList tl{btl ? btl + (int64_t)b * k_tiles : nullptr, btl ? btc[b] : k_tiles};
+        double v;
+        if (term == 0) {
+            v = block_sum(plain_dot_partial(brow, mv.er + (int64_t)a * mv.S_pad, mv.S, tl), red);
+        } else {
+            const int o = term - 1;
+            const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
+            v = best_score[e];
+            if (err[e] > 0.0)                                       // block-uniform
+                v = block_sum(proj_dot_partial(brow, alpha + (int64_t)best_v[e] * lda, mv, a, o, gamma, tl), red);
+        }
+        if (tid == 0) *part = v;
     }
-    __syncthreads();
-    if (!cand_sh) {
-        if (tid == 0) val_exact[(int64_t)b * mv.A + a] = -std::numeric_limits<double>::infinity();
-        return;
-    }
-    const T* brow = bel + (int64_t)b * ldb;
-    const int k_tiles = mv.S_pad >> 5;
-    const TileList tl{btl ? btl + (int64_t)b * k_tiles : nullptr, btl ? btc[b] : k_tiles};
-    double v = block_sum(plain_dot_partial(brow, mv.er + (int64_t)a * mv.S_pad, mv.S, tl), red);
-    for (int o = 0; o < mv.O; ++o) {
-        const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
-        double sc = best_score[e];
-        if (err[e] > 0.0)                                       // block-uniform
-            sc = block_sum(proj_dot_partial(brow, alpha + (int64_t)best_v[e] * lda, mv, a, o, gamma, tl), red);
-        v += sc;
-    }
-    if (tid == 0) val_exact[(int64_t)b * mv.A + a] = v;
 }
 
-__global__ void k_action_final(int A, const int32_t* __restrict__ aqueue, const int* __restrict__ aqcount,
-                               const double* __restrict__ val_exact, int32_t* __restrict__ action) {
+__global__ void k_action_final(int A, int terms, const int32_t* __restrict__ aqueue, const int* __restrict__ aqcount,
+                               const double* __restrict__ val_parts, int32_t* __restrict__ action) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= *aqcount) return;
     const int b = aqueue[i];
     int best = 0;
     double bv = -std::numeric_limits<double>::infinity();
     for (int a = 0; a < A; ++a) {
-        const double v = val_exact[(int64_t)b * A + a];
+        const double* p = val_parts + ((int64_t)b * A + a) * terms;
+        double v = p[0];                                        // b.ER, then the observations in order: the association
+        for (int j = 1; j < terms; ++j) v += p[j];              // the one-block version used (-inf stays -inf)
         if (v > bv) {                                           // first maximum among the candidates
             bv = v;
             best = a;
@@ -1088,12 +1125,14 @@ hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, in
                                 const double* best_score, const double* err, double* val_exact, int32_t* action,
                                 hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    if (mv.A > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_refine_action<T>, dim3(B, mv.A), dim3(256), 0, st, bel, ldb, alpha, lda, mv, gamma, btl, btc,
+    const int terms = 1 + mv.O;
+    if ((int64_t)mv.A * terms > 65535) return hipErrorInvalidValue;
+    const int gx = B < 512 ? B : 512;                           // queued beliefs are few: a bounded grid strides over them
+    hipLaunchKernelGGL(k_refine_action<T>, dim3(gx, mv.A * terms), dim3(256), 0, st, bel, ldb, alpha, lda, mv, gamma, btl, btc,
                        aqueue, aqcount, rdot, rdot_err, best_v, best_score, err, val_exact);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_action_final, dim3((B + 255) / 256), dim3(256), 0, st, mv.A, aqueue, aqcount, val_exact, action);
+    hipLaunchKernelGGL(k_action_final, dim3((B + 255) / 256), dim3(256), 0, st, mv.A, terms, aqueue, aqcount, val_exact, action);
     return hipGetLastError();
 }
 
@@ -1105,29 +1144,33 @@ hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, in
 template <typename T>
 __global__ void k_assemble(const T* __restrict__ alpha, int lda, ModelView<T> mv, double gamma,
                            const int32_t* __restrict__ action, const int32_t* __restrict__ best_v,
-                           const int32_t* __restrict__ rows, const int* __restrict__ n_rows, T* __restrict__ out, int ldo) {
+                           const int32_t* __restrict__ rows, const int* __restrict__ n_rows, int max_rows,
+                           T* __restrict__ out, int ldo) {
 #pragma clang fp contract(off)
     // Output row u is the alpha' of belief rows[u] (the first belief carrying that (a*, v*) key): only
     // unique rows are materialised.  rows == nullptr: u is the belief itself.
+    // The number of rows is known on the device only: a bounded grid strides over them (a grid of max_rows row
+    // blocks was 120 000 blocks at C4 of which 8 000 had work -- 37 us of launch for 10 us of arithmetic).
     const int s = blockIdx.x * 256 + threadIdx.x;
-    const int u = blockIdx.y;
-    if (n_rows != nullptr && u >= *n_rows) return;
     if (s >= mv.S) return;
-    const int b = rows ? rows[u] : u;
-    const int a = action[b];
-    const int32_t* rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
-    double total = 0.0;
-    for (int o = 0; o < mv.O; ++o) {
-        const int v = best_v[((int64_t)b * mv.A + a) * mv.O + o];
-        const T* arow = alpha + (int64_t)v * lda;
-        const T* rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
-        double g = 0.0;
-        for (int r = 0; r < mv.R; ++r)
-            g = g + (double)rto[(int64_t)r * mv.S_pad + s] * (double)arow[rs[(int64_t)r * mv.S_pad + s]];
-        const double go = gamma * g;
-        total = (o == 0) ? go : total + go;
+    const int n = n_rows != nullptr ? *n_rows : max_rows;
+    for (int u = blockIdx.y; u < n; u += gridDim.y) {
+        const int b = rows ? rows[u] : u;
+        const int a = action[b];
+        const int32_t* rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
+        double total = 0.0;
+        for (int o = 0; o < mv.O; ++o) {
+            const int v = best_v[((int64_t)b * mv.A + a) * mv.O + o];
+            const T* arow = alpha + (int64_t)v * lda;
+            const T* rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
+            double g = 0.0;
+            for (int r = 0; r < mv.R; ++r)
+                g = g + (double)rto[(int64_t)r * mv.S_pad + s] * (double)arow[rs[(int64_t)r * mv.S_pad + s]];
+            const double go = gamma * g;
+            total = (o == 0) ? go : total + go;
+        }
+        out[(int64_t)u * ldo + s] = (T)((double)mv.er[(int64_t)a * mv.S_pad + s] + total);
     }
-    out[(int64_t)u * ldo + s] = (T)((double)mv.er[(int64_t)a * mv.S_pad + s] + total);
 }
 
 template <typename T>
@@ -1135,9 +1178,13 @@ hipError_t launch_assemble(const T* alpha, int lda, ModelView<T> mv, double gamm
                            const int32_t* best_v, const int32_t* rows, const int* n_rows, int max_rows, T* out, int ldo,
                            hipStream_t st) {
     if (max_rows <= 0) return hipSuccess;
-    if (max_rows > 65535) return hipErrorInvalidValue;
-    dim3 grid((mv.S + 255) / 256, max_rows);
-    hipLaunchKernelGGL(k_assemble<T>, grid, dim3(256), 0, st, alpha, lda, mv, gamma, action, best_v, rows, n_rows, out, ldo);
+    const int sx = (mv.S + 255) / 256;
+    int gy = (8192 + sx - 1) / sx;                       // ~8k blocks keep the chip busy whatever the row count turns out to be
+    if (gy > max_rows) gy = max_rows;
+    if (gy > 65535) gy = 65535;
+    dim3 grid(sx, gy);
+    hipLaunchKernelGGL(k_assemble<T>, grid, dim3(256), 0, st, alpha, lda, mv, gamma, action, best_v, rows, n_rows, max_rows, out,
+                       ldo);
     return hipGetLastError();
 }
 
@@ -1618,6 +1665,18 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
     template hipError_t launch_dominated<T>(const T*, int, int, int, int*, hipStream_t);
 PBVI_INST(float)
 PBVI_INST(double)
+#define PBVI_INST_REFINE(T, TS)                                                                                        \
+    template hipError_t launch_refine_scan<T, TS>(bool, SlabView<TS>, int, int, int, const int32_t*, const int*, const T*, \
+                                                  int, const T*, int, ModelView<T>, double, const int32_t*, const int32_t*, \
+                                                  const uint8_t*, int32_t*, double*, double*, int*, RefineWork, int*,   \
+                                                  hipStream_t);
+PBVI_INST_REFINE(float, float)
+PBVI_INST_REFINE(double, double)
+PBVI_INST_REFINE(double, float)
+template hipError_t launch_refine_deferred<float>(bool, int, int, const float*, int, const float*, int, ModelView<float>, double,
+                                                  int32_t*, double*, double*, RefineWork, int, int, hipStream_t);
+template hipError_t launch_refine_deferred<double>(bool, int, int, const double*, int, const double*, int, ModelView<double>,
+                                                   double, int32_t*, double*, double*, RefineWork, int, int, hipStream_t);
 // fp64 data re-scored behind an fp32 screen (candidates flagged from fp32 slabs)
 template hipError_t launch_refine<double, float>(bool, SlabView<float>, int, int, int, const int32_t*, const int*, const double*,
                                                  int, const double*, int, ModelView<double>, double, const int32_t*,

@@ -11,6 +11,7 @@
 //   results : out_alpha [B][S], action [B], best_v [B][A][O], keep [B]
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -441,6 +442,8 @@ class EngineT : public EngineBase {
     int64_t rows_pad_s_ = 0, dense_pairs_ = 0;
     std::vector<int> h_kcountD_;
     hipStream_t stream2_ = nullptr;                  // belief-only kernels run beside projection + GEMM
+    hipStream_t stream3_ = nullptr;                  // the score GEMM's tile lists / stream-K plan: beside both (a few us of
+                                                     // work that the GEMM waits for must not queue behind k_dead's 100 us)
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_lists_ = nullptr;
     GemmPlan plan_ = {};
     hipEvent_t ev_[9] = {};
@@ -454,6 +457,8 @@ class EngineT : public EngineBase {
     std::vector<uint8_t> h_mat_;
     std::vector<int> h_vlist_;
     int64_t mat_V_ = -1;
+    int* rf_counts_ = nullptr;                               // [2] in host_stage_: what the refinement's per-entry pass deferred
+    bool last_deferred_nothing_ = false;                     // (the first backup of an engine reads the counts mid-pipeline)
     bool owns_streams_ = true;                               // false: a screen running on its fp64 engine's streams
     EngineT<float>* screen_ = nullptr;                       // fp64 engines: the fp32 screen (see ensure_screen)
     std::vector<int32_t> h_reach_ref_;                       // fp64 engines: the tables in the reference's layout, kept
@@ -475,21 +480,29 @@ class EngineT : public EngineBase {
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &snz_, &sbtl_, &sbtc_, &vmax_bk_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
                          &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_};
+        // every call is checked only to name a failure when PBVI_DEBUG is set; the thread's sticky last-error is cleared at
+        // the end either way, so that a later launch check does not report a stale error of this teardown
+        static const bool dbg = getenv("PBVI_DEBUG") != nullptr;
+        auto chk = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && dbg) fprintf(stderr, "[pbvi] engine teardown: %s: %s\n", what, hipGetErrorString(e));
+        };
         for (auto& e : walk_ev_)
-            if (e) (void)hipEventDestroy(e);
+            if (e) chk(hipEventDestroy(e), "hipEventDestroy(walk)");
         for (DevBuf* b : all) b->release();
-        if (host_stage_) (void)hipHostFree(host_stage_);
+        if (host_stage_) chk(hipHostFree(host_stage_), "hipHostFree(stage)");
         for (auto& e : ev_)
-            if (e) (void)hipEventDestroy(e);
+            if (e) chk(hipEventDestroy(e), "hipEventDestroy(ev)");
         for (auto& e : ev_pg_)
-            if (e) (void)hipEventDestroy(e);
-        if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-        if (ev_join_) (void)hipEventDestroy(ev_join_);
-        if (ev_lists_) (void)hipEventDestroy(ev_lists_);
+            if (e) chk(hipEventDestroy(e), "hipEventDestroy(ev_pg)");
+        if (ev_fork_) chk(hipEventDestroy(ev_fork_), "hipEventDestroy(fork)");
+        if (ev_join_) chk(hipEventDestroy(ev_join_), "hipEventDestroy(join)");
+        if (ev_lists_) chk(hipEventDestroy(ev_lists_), "hipEventDestroy(lists)");
         if (owns_streams_) {
-            if (stream2_) (void)hipStreamDestroy(stream2_);
-            if (stream_) (void)hipStreamDestroy(stream_);
+            if (stream3_) chk(hipStreamDestroy(stream3_), "hipStreamDestroy(3)");
+            if (stream2_) chk(hipStreamDestroy(stream2_), "hipStreamDestroy(2)");
+            if (stream_) chk(hipStreamDestroy(stream_), "hipStreamDestroy(1)");
         }
+        chk(hipGetLastError(), "sticky error left by an earlier call");
     }
 
     ModelView<T> view() const {
@@ -507,7 +520,7 @@ class EngineT : public EngineBase {
     }
 
     int init(int device, int S, int A, int O, int R, const int32_t* reach, const T* rto, const T* er, int mode,
-             hipStream_t shared_main = nullptr, hipStream_t shared_side = nullptr) {
+             hipStream_t shared_main = nullptr, hipStream_t shared_side = nullptr, hipStream_t shared_lists = nullptr) {
         device_ = device;
         S_ = S;
         A_ = A;
@@ -527,6 +540,7 @@ class EngineT : public EngineBase {
         if (shared_main != nullptr) {   // an fp32 screen lives on its fp64 engine's streams: one pipeline, one order
             stream_ = shared_main;
             stream2_ = shared_side;
+            stream3_ = shared_lists;
             owns_streams_ = false;
         } else {
         HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -538,10 +552,13 @@ class EngineT : public EngineBase {
             int lo = 0, hi = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
             static const bool plain_side = getenv("PBVI_SIDE_STREAM_NORMAL") != nullptr;      // debug / A-B only
-            if (hi < lo && !plain_side)
+            if (hi < lo && !plain_side) {
                 HIPCHK(hipStreamCreateWithPriority(&stream2_, hipStreamNonBlocking, hi));
-            else
+                HIPCHK(hipStreamCreateWithPriority(&stream3_, hipStreamNonBlocking, hi));
+            } else {
                 HIPCHK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+                HIPCHK(hipStreamCreateWithFlags(&stream3_, hipStreamNonBlocking));
+            }
         }
         for (auto& e : ev_) HIPCHK(hipEventCreate(&e));
         for (auto& e : ev_pg_) HIPCHK(hipEventCreate(&e));
@@ -1994,7 +2011,7 @@ int EngineT<T>::ensure_screen() {
         std::vector<float> rto32(h_rto_ref_.begin(), h_rto_ref_.end()), er32(h_er_ref_.begin(), h_er_ref_.end());
         auto* e = new (std::nothrow) EngineT<float>();
         if (!e) FAIL(PBVI_ENOMEM, "screen: host allocation failed");
-        const int rc = e->init(device_, S_, A_, O_, R_, h_reach_ref_.data(), rto32.data(), er32.data(), PBVI_SPARSE, stream_, stream2_);
+        const int rc = e->init(device_, S_, A_, O_, R_, h_reach_ref_.data(), rto32.data(), er32.data(), PBVI_SPARSE, stream_, stream2_, stream3_);
         if (rc != PBVI_OK) {
             delete e;
             return rc;
@@ -2105,10 +2122,13 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     const int k_tiles = S_pad_ / GEMM_BK;
     HIPCHK(hipEventRecord(ev_fork_, stream_));
     HIPCHK(hipStreamWaitEvent(side, ev_fork_, 0));
+    static const bool lists_on_side = getenv("PBVI_LISTS_ON_SIDE") != nullptr;      // debug / A-B only: lists behind k_dead
+    hipStream_t lists = no_side ? nullptr : (lists_on_side ? side : stream3_);
+    if (lists != nullptr && lists != side) HIPCHK(hipStreamWaitEvent(lists, ev_fork_, 0));
     if (windows) {   // exact, from the supports of the ORIGINAL operands (an fp32 copy may have flushed tiny values to zero)
         if ((rc = btl_.ensure((size_t)B_ * k_tiles * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = btc_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
-        if ((rc = val_exact_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
+        if ((rc = val_exact_.ensure((size_t)B_ * A_ * (1 + O_) * sizeof(double), &bytes_))) return rc;
         HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(),
                               btl_.as<int32_t>(), btc_.as<int32_t>(), counters_.as<int>() + 5, side));
         btl_valid_ = true;
@@ -2129,7 +2149,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     io.dead = windows ? dead_.as<uint8_t>() : nullptr;
     io.prd = use_push ? prd_.as<double>() : nullptr;
     io.join = ev_join_;
-    io.side = no_side ? nullptr : side;
+    io.side = lists;
     io.ev = ev_;
     io.stats = st != nullptr;
     // a screen multiplies operands rounded to fp32 (alpha, belief, RTO: 2^-24 relative each) and gamma in fp32
@@ -2154,66 +2174,106 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         h_kcount.resize((size_t)plan.tiles_m * plan.tiles_n);
         HIPCHK(hipMemcpyAsync(h_kcount.data(), scorer.kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
     }
+    // fp64 re-decision of near-ties.  The per-entry pass hands entries with many tied candidates on to grid-wide
+    // passes whose launch needs the host to know how many there are -- a read-back in the middle of the pipeline
+    // (~30 us of idle device).  A value function either has such ties (absorbing goals, unexplored regions: every backup
+    // of a solve loop) or it has not (the synthetic sets): after a backup that deferred nothing the next one SPECULATES
+    // that it will not either -- the later stages are enqueued at once, the counts are read at the end, and if there was
+    // deferred work after all it runs then and the later stages are repeated.
+    RefineWork work;
+    bool speculate = false;
     if (windows) {
-        RefineWork work;
         if ((rc = refine_work(pairs, V_, &work))) return rc;
-        HIPCHK((launch_refine<T, TS>(true, sv, (int)V_, AO, (int)pairs, queue_.as<int32_t>(), qcount, bel_.as<T>(), S_pad_,
-                                     alpha_.as<T>(), S_pad_, mv, gamma, btl_.as<int32_t>(), btc_.as<int32_t>(), nzB_.as<uint8_t>(),
-                                     best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), counters_.as<int>() + 4,
-                                     work, stream_)));
+        // the counts land in the engine's pinned bounce buffer (idle during a backup: results are staged through it only
+        // by the fetch calls that follow)
+        if ((rc = stage_reserve(256))) return rc;
+        rf_counts_ = reinterpret_cast<int*>(host_stage_);
+        rf_counts_[0] = rf_counts_[1] = 0;
+        static const bool no_spec = getenv("PBVI_NO_SPECULATION") != nullptr;      // debug / A-B only
+        // (not with the belief-dominance test: its own value-max refinement re-uses the work-list buffers, so the
+        // deferred entries of this one have to be finished first)
+        speculate = !no_spec && last_deferred_nothing_ && work.items_v != nullptr && !(flags & PBVI_BELIEF_DOMINANCE);
+        HIPCHK((launch_refine_scan<T, TS>(true, sv, (int)V_, AO, (int)pairs, queue_.as<int32_t>(), qcount, bel_.as<T>(), S_pad_,
+                                          alpha_.as<T>(), S_pad_, mv, gamma, btl_.as<int32_t>(), btc_.as<int32_t>(),
+                                          nzB_.as<uint8_t>(), best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(),
+                                          counters_.as<int>() + 4, work, rf_counts_, stream_)));
+        if (!speculate && work.items_v != nullptr) {
+            HIPCHK(hipStreamSynchronize(stream_));
+            last_deferred_nothing_ = rf_counts_[0] == 0 && rf_counts_[1] == 0;
+            HIPCHK(launch_refine_deferred<T>(true, (int)V_, AO, bel_.as<T>(), S_pad_, alpha_.as<T>(), S_pad_, mv, gamma,
+                                             best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), work,
+                                             rf_counts_[0], rf_counts_[1], stream_));
+        }
     }
     HIPCHK(hipEventRecord(ev_[4], stream_));
-    // K4: action
-    double* rdot_err = rdot_.as<double>() + (size_t)B_ * A_;
-    HIPCHK(launch_action<TS>((int)B_, scorer.view(), sv, sc.rd_col0, sc.tol_rel, sc.chain, best_score_.as<double>(),
-                             err_.as<double>(), rdot_.as<double>(), rdot_err, action_.as<int32_t>(),
-                             windows ? aqueue_.as<int32_t>() : nullptr, aqcount, stream_, io.tol_extra));
-    if (windows)
-        HIPCHK(launch_refine_action<T>(bel_.as<T>(), S_pad_, (int)B_, alpha_.as<T>(), S_pad_, mv, gamma,
-                                       btl_.as<int32_t>(), btc_.as<int32_t>(),
-                                       aqueue_.as<int32_t>(), aqcount, rdot_.as<double>(), rdot_err, best_v_.as<int32_t>(),
-                                       best_score_.as<double>(), err_.as<double>(), val_exact_.as<double>(),
-                                       action_.as<int32_t>(), stream_));
-    HIPCHK(hipEventRecord(ev_[5], stream_));
-    // results to the caller's belief order, then K6: dedup by (a*, v*) key
     const int32_t* perm = sorted_ ? perm_.as<int32_t>() : nullptr;
-    if (sorted_) {
-        if ((rc = action_res_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
-        if ((rc = best_res_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc;
-        hipLaunchKernelGGL(k_unpermute, dim3((unsigned)B_), dim3(64), 0, stream_, (int)B_, AO, perm, action_.as<int32_t>(),
-                           best_v_.as<int32_t>(), action_res_.as<int32_t>(), best_res_.as<int32_t>());
-        HIPCHK(hipGetLastError());
-        res_action_ = action_res_.as<int32_t>();
-        res_best_ = best_res_.as<int32_t>();
-    } else {
-        res_action_ = action_.as<int32_t>();
-        res_best_ = best_v_.as<int32_t>();
-    }
+    int* ucount = counters_.as<int>() + 3;
+    int h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // all counters in the one read-back that precedes the final sync
+    auto later_stages = [&]() -> int {
+        // K4: action
+        double* rdot_err = rdot_.as<double>() + (size_t)B_ * A_;
+        HIPCHK(launch_action<TS>((int)B_, scorer.view(), sv, sc.rd_col0, sc.tol_rel, sc.chain, best_score_.as<double>(),
+                                 err_.as<double>(), rdot_.as<double>(), rdot_err, action_.as<int32_t>(),
+                                 windows ? aqueue_.as<int32_t>() : nullptr, aqcount, stream_, io.tol_extra));
+        if (windows)
+            HIPCHK(launch_refine_action<T>(bel_.as<T>(), S_pad_, (int)B_, alpha_.as<T>(), S_pad_, mv, gamma,
+                                           btl_.as<int32_t>(), btc_.as<int32_t>(),
+                                           aqueue_.as<int32_t>(), aqcount, rdot_.as<double>(), rdot_err, best_v_.as<int32_t>(),
+                                           best_score_.as<double>(), err_.as<double>(), val_exact_.as<double>(),
+                                           action_.as<int32_t>(), stream_));
+        HIPCHK(hipEventRecord(ev_[5], stream_));
+        // results to the caller's belief order, then K6: dedup by (a*, v*) key
+        if (sorted_) {
+            int rc2;
+            if ((rc2 = action_res_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc2;
+            if ((rc2 = best_res_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc2;
+            hipLaunchKernelGGL(k_unpermute, dim3((unsigned)B_), dim3(64), 0, stream_, (int)B_, AO, perm, action_.as<int32_t>(),
+                               best_v_.as<int32_t>(), action_res_.as<int32_t>(), best_res_.as<int32_t>());
+            HIPCHK(hipGetLastError());
+            res_action_ = action_res_.as<int32_t>();
+            res_best_ = best_res_.as<int32_t>();
+        } else {
+            res_action_ = action_.as<int32_t>();
+            res_best_ = best_v_.as<int32_t>();
+        }
+        HIPCHK(launch_dedup((int)B_, A_, O_, res_action_, res_best_, rep_.as<int32_t>(), uniq_.as<int32_t>(),
+                            inv_.as<int32_t>(), slot_.as<int32_t>(), ucount, stream_));
+        // K3: alpha' rows of the unique keys only
+        HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, mv, gamma, res_action_, res_best_, uniq_.as<int32_t>(), ucount,
+                                  (int)B_, out_.as<T>(), S_, stream_));
+        HIPCHK(hipEventRecord(ev_[6], stream_));
+        // K5: belief dominance (keep is written in caller order)
+        if (flags & PBVI_BELIEF_DOMINANCE) {
+            int rc2;
+            if ((rc2 = value_max_device())) return rc2;
+            HIPCHK(launch_keep<T>(bel_.as<T>(), S_pad_, out_.as<T>(), S_, (int)B_, S_, bs2_.as<double>(), inv_.as<int32_t>(),
+                                  perm, keep_.as<uint8_t>(), stream_));
+        } else {
+            HIPCHK(hipMemsetAsync(keep_.p, 1, (size_t)B_, stream_));
+        }
+        HIPCHK(hipMemcpyAsync(h_cnt, counters_.p, sizeof(h_cnt), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipEventRecord(ev_[7], stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        return PBVI_OK;
+    };
     if ((rc = rep_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
     if ((rc = uniq_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
     if ((rc = inv_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
     if ((rc = slot_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
-    int* ucount = counters_.as<int>() + 3;
-    HIPCHK(launch_dedup((int)B_, A_, O_, res_action_, res_best_, rep_.as<int32_t>(), uniq_.as<int32_t>(),
-                        inv_.as<int32_t>(), slot_.as<int32_t>(), ucount, stream_));
-    // K3: alpha' rows of the unique keys only
-    HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, mv, gamma, res_action_, res_best_, uniq_.as<int32_t>(), ucount,
-                              (int)B_, out_.as<T>(), S_, stream_));
-    HIPCHK(hipEventRecord(ev_[6], stream_));
-    // K5: belief dominance (keep is written in caller order)
-    if (flags & PBVI_BELIEF_DOMINANCE) {
-        if ((rc = value_max_device())) return rc;
-        HIPCHK(launch_keep<T>(bel_.as<T>(), S_pad_, out_.as<T>(), S_, (int)B_, S_, bs2_.as<double>(), inv_.as<int32_t>(),
-                              perm, keep_.as<uint8_t>(), stream_));
-    } else {
-        HIPCHK(hipMemsetAsync(keep_.p, 1, (size_t)B_, stream_));
+    if ((rc = later_stages())) return rc;
+    if (speculate) {
+        last_deferred_nothing_ = rf_counts_[0] == 0 && rf_counts_[1] == 0;
+        if (!last_deferred_nothing_) {   // there was deferred work after all: do it, then the later stages again
+            HIPCHK(launch_refine_deferred<T>(true, (int)V_, AO, bel_.as<T>(), S_pad_, alpha_.as<T>(), S_pad_, mv, gamma,
+                                             best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), work,
+                                             rf_counts_[0], rf_counts_[1], stream_));
+            HIPCHK(hipMemsetAsync(counters_.as<int>() + 1, 0, sizeof(int), stream_));       // aqcount
+            HIPCHK(hipMemsetAsync(counters_.as<int>() + 3, 0, sizeof(int), stream_));       // ucount (value_max's counter [2] is reset there)
+            if ((rc = later_stages())) return rc;
+        }
     }
-    int h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // all counters in the one read-back that precedes the final sync
-    HIPCHK(hipMemcpyAsync(h_cnt, counters_.p, sizeof(h_cnt), hipMemcpyDeviceToHost, stream_));
     full_valid_ = false;
     res_sorted_ = sorted_;
-    HIPCHK(hipEventRecord(ev_[7], stream_));
-    HIPCHK(hipStreamSynchronize(stream_));
     have_result_ = true;
     have_bk_vmax_ = use_push && !screened;
     res_B_ = B_;

@@ -49,8 +49,8 @@ def main():
     root, out = sys.argv[1], sys.argv[2]
     os.makedirs(out, exist_ok=True)
     lines = ['# Kernel profile (MI355X, rocprofv3)', '',
-             'Workload: `python3 bench.py --steps 10 --warmup 2 --cpu-sample 0` (olfactory-30000 reachable-sparse R=1, '
-             'V=1024, B=1024, f32 engine).', '']
+             'Workload: `python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --secondary none` (olfactory-30000 '
+             'reachable-sparse R=1, V=1024, B=1024, f32 engine; every step = pbvi_backup_run + pbvi_backup_fetch_compact).', '']
     ks = find(os.path.join(root, 'prof_k'), '*kernel_stats.csv')
     if ks:
         rows = kernel_stats(ks)
@@ -74,17 +74,18 @@ def main():
             table.append((2 * fv + wv, name, n, fv, wv))
         for tot, name, n, fv, wv in sorted(table, reverse=True)[:10]:
             lines.append(f'| `{name[:60]}` | {n} | {fv:.1f} | {wv:.1f} | {tot * 1024 / 1e6:.1f} |')
-        gem = [t for t in table if 'k_gemm_nt_f32_streamk' in t[1]]
+        gem = sorted((t for t in table if 'k_gemm_nt_f32_streamk' in t[1]), reverse=True)   # the one that moved the most
         if gem:
             tot, name, n, fv, wv = gem[0]
             with open(os.path.join(out, 'pmc_traffic.json'), 'w') as fh:
-                json.dump({'kernel': 'k_gemm_nt_f32_streamk',
+                json.dump({'kernel': re.sub(r'^void ', '', name).split('(')[0].replace('pbvi::', ''),
                            'workload': 'olfactory-30000 reachable-sparse R=1 V=1024 B=1024 f32',
                            'launches_averaged': n, 'FETCH_SIZE_KB': fv, 'WRITE_SIZE_KB': wv,
                            'traffic_bytes': tot * 1024,
                            'other_kernels': {re.sub(r'^void ', '', nm).split('(')[0].split('<')[0].replace('pbvi::', ''):
                                              {'launches': nn, 'traffic_bytes': tt * 1024}
-                                             for tt, nm, nn, _, _ in sorted(table, reverse=True)[1:8] if 'pbvi::' in nm},
+                                             for tt, nm, nn, _, _ in sorted(table, reverse=True)[:10]
+                                             if 'pbvi::' in nm and nm != name},
                            'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bytes = '
                                      '(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md section HBM'}, fh, indent=1)
         lines.append('')

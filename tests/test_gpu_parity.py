@@ -966,6 +966,44 @@ def test_exact_ties_with_hundreds_of_candidates(formulation):
     eng.close()
 
 
+def test_speculative_refinement_recovers_when_ties_appear():
+    """After a backup whose refinement deferred nothing the engine stops reading the deferred-work counts in the middle of
+    the pipeline: it enqueues the later stages at once and checks the counts at the end.  Here the first backup has no
+    ties (distinct random alpha rows), the second one -- same engine -- has ~140 exactly tied candidates per triple, so
+    the speculation fails: the deferred passes run late and the later stages are repeated.  Results must be the oracle's
+    either way, and the third backup (ties again) takes the synchronous route."""
+    rng = np.random.default_rng(78)
+    S, A, O, R, V, B = 300, 2, 2, 1, 700, 40
+    rs = rng.integers(0, S, size=(S, A, R))
+    pick = rng.random((S, A)) < 0.5
+    rto = np.empty((S, A, O, R))
+    rto[:, :, 0, 0] = np.where(pick, 0.25, 0.75)
+    rto[:, :, 1, 0] = 1.0 - rto[:, :, 0, 0]
+    er = rng.integers(-4, 5, size=(S, A)).astype(np.float64)
+    plain = rng.normal(scale=3.0, size=(V, S)).astype(np.float32).astype(np.float64)
+    base = rng.integers(-8, 9, size=(5, S)).astype(np.float64)
+    tied = base[rng.integers(0, 5, size=V)]
+    b = np.zeros((B, S))
+    for i in range(B):
+        np.add.at(b[i], rng.integers(0, S, size=64), 1.0 / 64.0)
+    eng = Engine(S, A, O, R, rs, rto, er, dtype='f32')
+    eng.set_formulation('alpha')
+    eng.set_beliefs(b)
+    for k, alpha in enumerate((plain, plain, plain, tied, tied, plain, tied)):
+        want_rows, want_a, want_v = orc.backup_core(alpha, b, rs, rto, er, 0.5)
+        eng.set_alpha(alpha)
+        st = eng.run(0.5, belief_dominance_prune=(k % 2 == 0))
+        res = eng.fetch()
+        assert np.array_equal(res.best_alpha_ind, want_v), k
+        assert np.array_equal(res.actions, want_a), k
+        if alpha is tied:
+            assert st['n_refine_candidates'] > 8 * st['n_refined'] > 0
+            np.testing.assert_array_equal(res.alpha, want_rows)
+        else:
+            assert_alpha_close(res.alpha, want_rows, F32_RTOL)
+    eng.close()
+
+
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_belief_walk_matches_host_updates(dtype):
     """pbvi_belief_walk: chained Bayes updates with restarts equal Belief.update applied step by step (fp64 engines:
