@@ -103,6 +103,23 @@ def gemm_roofline(stats, dtype: str, mode: str):
             'tiles_run_over_dense': stats[0]['score_tiles_run'] / max(1, stats[0]['score_tiles_dense'])}
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when its first communicator comes up; the driver expects ONE JSON line
+    there.  File descriptor 1 points at stderr while the process group and the warm-up collectives are set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def timed_steps(step, steps: int, warmup: int, fence):
     """``warmup`` untimed steps, then ``steps`` timed ones between two fences.  Returns (per-step seconds, whole-region
     seconds, list of what step() returned)."""
@@ -187,7 +204,9 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        with stdout_to_stderr():
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.barrier()                                          # brings the communicator (and its banner) up now
 
     from pomdp_pbvi_exploration_amd import synth
     from pomdp_pbvi_exploration_amd.engine import Engine

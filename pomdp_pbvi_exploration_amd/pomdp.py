@@ -1052,18 +1052,47 @@ class _HostBeliefBlock:
 
 
 class _DeviceBeliefBlock:
-    """Belief block resident in the HIP engine: ``pbvi_value_max`` + ``pbvi_beliefs_advance``."""
+    """Belief block resident in the HIP engine: ``pbvi_value_max`` + ``pbvi_beliefs_advance``.
+
+    The engine holds one block of at most 65535 beliefs.  Larger simulations (the reference takes any ``n``) run in
+    chunks of ``CHUNK`` rows that live on the host between steps and pass through the engine one after the other --
+    correct, but every step then moves the beliefs over PCIe; the resident path is the one that is fast."""
+
+    CHUNK = 32768
 
     def __init__(self, model: Model, value_function: ValueFunction, beliefs: np.ndarray):
         self.eng = model.engine
         self.eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values)
-        self.eng.set_beliefs(beliefs)
+        self.chunks = None
+        if beliefs.shape[0] <= 65535:
+            self.eng.set_beliefs(beliefs)
+        else:
+            self.chunks = [np.ascontiguousarray(beliefs[i:i + self.CHUNK]) for i in range(0, beliefs.shape[0], self.CHUNK)]
 
     def best_vectors(self) -> np.ndarray:
-        return self.eng.max_value_resident()[1]
+        if self.chunks is None:
+            return self.eng.max_value_resident()[1]
+        out = []
+        for c in self.chunks:
+            self.eng.set_beliefs(c)
+            out.append(self.eng.max_value_resident()[1])
+        return np.concatenate(out) if out else np.zeros(0, dtype=np.int64)
 
     def advance(self, actions: np.ndarray, observations: np.ndarray, keep: np.ndarray) -> None:
-        self.eng.advance_beliefs(actions, observations, keep)
+        if self.chunks is None:
+            self.eng.advance_beliefs(actions, observations, keep)
+            return
+        nxt, i0 = [], 0
+        for c in self.chunks:
+            n = c.shape[0]
+            self.eng.set_beliefs(c)
+            if self.eng.advance_beliefs(actions[i0:i0 + n], observations[i0:i0 + n], keep[i0:i0 + n]) > 0:
+                nxt.append(self.eng.fetch_beliefs())
+            i0 += n
+        self.chunks = nxt
+        if sum(c.shape[0] for c in nxt) <= 65535 and nxt:       # few enough simulations left: stay on the device from here on
+            self.eng.set_beliefs(np.concatenate(nxt))
+            self.chunks = None
 
 
 class Agent:
@@ -1087,8 +1116,11 @@ class Agent:
         if vf.is_on_gpu:
             eng = vf.model.engine
             eng.sync_rows('alpha', vf.alpha_vector_list, lambda v: v.values)
-            eng.set_beliefs(arr)
-            best = eng.max_value_resident()[1]
+            parts = []
+            for i0 in range(0, arr.shape[0], _DeviceBeliefBlock.CHUNK):      # the engine takes 65535 beliefs at a time
+                eng.set_beliefs(arr[i0:i0 + _DeviceBeliefBlock.CHUNK])
+                parts.append(eng.max_value_resident()[1])
+            best = parts[0] if len(parts) == 1 else np.concatenate(parts)
         else:
             best = np.argmax(np.matmul(arr, vf.alpha_vector_array.T), axis=1)
         acts = vf.actions[best]

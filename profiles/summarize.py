@@ -49,7 +49,7 @@ def main():
     root, out = sys.argv[1], sys.argv[2]
     os.makedirs(out, exist_ok=True)
     lines = ['# Kernel profile (MI355X, rocprofv3)', '',
-             'Workload: `python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --secondary none` (olfactory-30000 '
+             'Workload: `python3 bench.py --steps 10 --warmup 10 --cpu-sample 0 --secondary none` (olfactory-30000 '
              'reachable-sparse R=1, V=1024, B=1024, f32 engine; every step = pbvi_backup_run + pbvi_backup_fetch_compact).', '']
     ks = find(os.path.join(root, 'prof_k'), '*kernel_stats.csv')
     if ks:

@@ -181,6 +181,33 @@ def test_parallel_simulations_match_reference_gpu(R, tag, dtype):
 
 
 @pytest.mark.gpu
+def test_more_simulations_than_one_engine_block_holds():
+    """The reference takes any n; the engine holds 65535 beliefs per block.  70 001 tiger simulations run through the
+    engine in chunks (and return to the resident path once few enough are left); the device run equals the host run of
+    the same seeds step for step, and Agent.get_best_action takes an array of that length too."""
+    z = load_npz('tiger_sim.npz')
+    model, _ = load_POMDP_file(os.path.join(GOLDEN, 'models', 'tiger.95.POMDP'))
+    model.end_actions = [1, 2]
+    n = 70001
+    out = {}
+    for on_gpu in (False, True):
+        m = model.gpu_model if on_gpu else model
+        agent = Agent(m, ValueFunction(m, z['alpha'], z['alpha_actions'].astype(int)))
+        np.random.seed(3)
+        random.seed(3)
+        totals, hists = agent.run_n_simulations_parallel(n=n, max_steps=6, print_progress=False, print_stats=False)
+        out[on_gpu] = (np.asarray(totals), [np.asarray(h.actions) for h in hists[:50]])
+        if on_gpu:
+            rows = np.random.default_rng(0).random((n, 2))
+            rows /= rows.sum(axis=1, keepdims=True)
+            got = agent.get_best_action(rows)
+            want = np.asarray(z['alpha_actions'].astype(int))[np.argmax(rows @ np.asarray(z['alpha'], dtype=np.float64).T, axis=1)]
+            assert got.shape == (n,) and np.array_equal(got, want)
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    assert all(np.array_equal(a, b) for a, b in zip(out[True][1], out[False][1]))
+
+
+@pytest.mark.gpu
 def test_single_simulations_gpu():
     z, _, agent = olfactory_agent(1, on_gpu=True)
     n, steps, seed = (int(x) for x in z['seq_cfg'])
