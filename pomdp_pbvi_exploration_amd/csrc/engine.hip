@@ -1688,7 +1688,7 @@ class EngineT : public EngineBase {
         tie_rel_user_ = rel;
         return PBVI_OK;
     }
-    int64_t device_bytes() const override { return bytes_; }
+    int64_t device_bytes() const override { return bytes_ + (screen_ ? screen_->bytes_ : 0); }
 };
 
 template <typename T>

@@ -277,6 +277,54 @@ def gen_full():
         print(f'  stored; keep={int(keep.sum())}/{B}', flush=True)
 
 
+def gen_c5():
+    """BASELINE config 5's workload, |S|=30000, V=1024, B=8192 (the belief set that is sharded over 8 GPUs): the
+    reference's own backup, run here in 8 blocks of 1024 beliefs -- row b of every intermediate depends on belief b
+    only (src/pomdp.py:1495-1506), and 8192 beliefs at once would need ~115 GB for its temporaries -- with the oracle
+    asserted equal to it block by block.  Stored: per-belief output summaries (as olfactory_full_R1.npz) and the size of
+    the de-duplicated alpha set over all 8192 beliefs."""
+    R, V, B, blk = 1, 1024, 8192, 1024
+    m = synth.olfactory_model(R=R)
+    alpha, acts = synth.alpha_set(m, V)
+    model = ref_model_from_synth(m)
+    a_star, v_star, row_sum, b_dot, vmax = [], [], [], [], []
+    idx = synth.splitmix64(98, np.arange(4096, dtype=np.uint64))
+    sb = (idx % np.uint64(B)).astype(np.int64)
+    ss = ((idx >> np.uint64(20)) % np.uint64(m.S)).astype(np.int64)
+    sval = np.zeros(4096)
+    import hashlib
+    h = hashlib.sha256()
+    for a in (m.reachable_states, m.rto, m.expected_rewards, alpha):
+        h.update(np.ascontiguousarray(a).tobytes())
+    keys = {}
+    t_ref = 0.0
+    for b0 in range(0, B, blk):
+        beliefs = synth.belief_points(m, blk, start=b0)
+        h.update(np.ascontiguousarray(beliefs).tobytes())
+        t0 = time.time()
+        rows, ra = ref_backup(model, alpha, acts, beliefs, m.gamma, False, False)
+        t_ref += time.time() - t0
+        a_new, a_s, v_s = orc.backup_core_tiled(alpha, beliefs, m.reachable_states, m.rto, m.expected_rewards, m.gamma)
+        d_rows, d_acts = orc.dedup_rows(a_new, a_s)
+        assert d_rows.shape == rows.shape and np.array_equal(d_acts, ra) and np.allclose(d_rows, rows, rtol=1e-12, atol=0)
+        for r, a in zip(d_rows, d_acts):
+            keys[r.tobytes()] = int(a)                       # ValueFunction's byte dedup over the whole set
+        a_star.append(a_s)
+        v_star.append(v_s)
+        row_sum.append(a_new.sum(axis=1))
+        b_dot.append(np.sum(beliefs * a_new, axis=1))
+        vmax.append(orc.max_value_per_belief(alpha, beliefs))
+        sel = (sb >= b0) & (sb < b0 + blk)
+        sval[sel] = a_new[sb[sel] - b0, ss[sel]]
+        print(f'  c5 block {b0 // blk}: reference {t_ref:.0f}s so far, |V_out| block {len(ra)}, global {len(keys)}', flush=True)
+    np.savez_compressed(os.path.join(HERE, 'olfactory_c5_B8192.npz'),
+                        R=R, V=V, B=B, gamma=m.gamma, ref_seconds=t_ref, n_unique=len(keys), inputs_sha256=h.hexdigest(),
+                        core_actions=np.concatenate(a_star).astype(np.int8), core_best=np.concatenate(v_star).astype(np.int16),
+                        row_sum=np.concatenate(row_sum), b_dot=np.concatenate(b_dot), sample_b=sb, sample_s=ss, sample_val=sval,
+                        value_max=np.concatenate(vmax))
+    print(f'[golden] olfactory_c5_B8192.npz: reference {t_ref:.0f}s for 8192 beliefs, {len(keys)} distinct rows', flush=True)
+
+
 # --------------------------------------------------------------------------- #
 def _pack_histories(hists):
     """Ragged per-simulation sequences -> flat arrays + lengths."""
@@ -565,4 +613,4 @@ def gen_limiter():
 if __name__ == '__main__':
     which = sys.argv[1:] or ['small', 'kat', 'c2']
     for w in which:
-        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve, 'e2e': gen_e2e, 'hsvi': gen_hsvi, 'prune': gen_prune, 'limiter': gen_limiter}[w]()
+        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve, 'e2e': gen_e2e, 'hsvi': gen_hsvi, 'prune': gen_prune, 'limiter': gen_limiter, 'c5': gen_c5}[w]()

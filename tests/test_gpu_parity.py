@@ -1279,3 +1279,59 @@ def test_sharded_backup_on_the_engine_two_ranks():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
     assert 'sharded engine backup ok' in out.stdout
+
+
+def _c5_fixture():
+    path = os.path.join(GOLDEN, 'olfactory_c5_B8192.npz')
+    if not os.path.exists(path):
+        pytest.skip('C5 fixture missing (make_golden.py c5)')
+    return np.load(path, allow_pickle=False)
+
+
+def test_c5_8192_beliefs_on_one_engine_against_reference():
+    """BASELINE config 5's workload (|S|=30000, V=1024, B=8192) on ONE engine -- the strong-scaling baseline of
+    ``bench.py --scaling strong --beliefs-total 8192`` -- against the reference's outputs for all 8192 beliefs
+    (olfactory_c5_B8192.npz: the reference run in 8 blocks of 1024, make_golden.py c5)."""
+    z = _c5_fixture()
+    B, V = int(z['B']), int(z['V'])
+    m = synth.olfactory_model(R=1)
+    alpha, _ = synth.alpha_set(m, V)
+    beliefs = synth.belief_points(m, B)
+    import hashlib
+    h = hashlib.sha256()
+    for a in (m.reachable_states, m.rto, m.expected_rewards, alpha, beliefs):
+        h.update(np.ascontiguousarray(a).tobytes())
+    if h.hexdigest() != str(z['inputs_sha256']):
+        pytest.skip('host regenerated different input bits than the fixture machine (exp/libm); parity unpinned here')
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32')
+    res = eng.backup_full(alpha, beliefs, m.gamma)
+    mism = int(np.sum(res.best_alpha_ind != z['core_best']))
+    assert mism == 0, f'{mism} of {res.best_alpha_ind.size} best_alpha_ind differ'
+    assert np.array_equal(res.actions, z['core_actions'])
+    u64 = res.unique_alpha.astype(np.float64)
+    np.testing.assert_allclose(u64.sum(axis=1)[res.index], z['row_sum'], rtol=F32_RTOL)
+    np.testing.assert_allclose(u64[res.index[z['sample_b']], z['sample_s']], z['sample_val'], rtol=F32_RTOL, atol=1e-12)
+    assert len(orc.dedup_rows(*res.value_function_rows())[1]) == int(z['n_unique'])
+    val, _ = eng.max_value_resident()
+    np.testing.assert_allclose(val, z['value_max'], rtol=1e-12)
+    print(f"C5 on one engine: {res.stats['ms_total']:.2f} ms for {B} beliefs, {res.stats['n_unique']} distinct keys")
+    eng.close()
+
+
+def test_c5_sharded_over_two_ranks_against_reference():
+    """The same workload sharded: two ranks of 4096 beliefs, one HIP engine each, the product step of the multi-GPU path
+    (local backup, one all-gather of integers, global dedup, append to every replica's alpha store), merged result against
+    the reference's outputs for all 8192 beliefs.  (tests/dist_c5_check.py holds the ranks' code.)"""
+    _c5_fixture()
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dist_c5_check.py')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), script],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    assert 'c5 sharded ok' in out.stdout
