@@ -94,8 +94,12 @@ def gemm_roofline(stats, dtype: str, mode: str):
     f32_gemm = dtype == 'f32' or bool(stats[0].get('screened'))      # an fp64 engine's scores come from its fp32 screen
     peak = PEAK_F32_MFMA_TFLOPS if f32_gemm else PEAK_F64_MFMA_TFLOPS
     ach = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': ('k_gemm_nt_f32_streamk' if f32_gemm else 'k_gemm_nt_f64_mfma') +
+    fused = bool(stats[0].get('fused_projection'))
+    return {'bound': 'mfma', 'kernel': (('k_gemm_nt_f32_streamk_fused' if fused else 'k_gemm_nt_f32_streamk') if f32_gemm
+                                        else 'k_gemm_nt_f64_mfma') +
                                        ' (belief x Gamma score GEMM, non-zero tiles' +
+                                       ('; Gamma tiles generated in the operand staging instead of read from HBM: the kernel '
+                                        'also does the work of the projection kernel it replaces' if fused else '') +
                                        (', fp32 screen of an fp64 engine)' if f32_gemm and dtype != 'f32' else ')'),
             'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
             'flops_per_launch': flops, 'ms_per_launch': ms, 'dense_flops_per_launch': dense,
@@ -136,7 +140,7 @@ def timed_steps(step, steps: int, warmup: int, fence):
     return np.asarray(per), time.perf_counter() - t0, outs
 
 
-def measure_config(name, m, alpha, beliefs, dtype, mode, steps, warmup, fence, true_dense=False, screen=None):
+def measure_config(name, m, alpha, beliefs, dtype, mode, steps, warmup, fence, true_dense=False, screen=None, fused=None):
     """One single-GPU configuration measured like the headline one (run + results to pinned host, median)."""
     from pomdp_pbvi_exploration_amd.engine import Engine, debug_gemm_dense
     prev = debug_gemm_dense(True) if true_dense else None
@@ -144,6 +148,8 @@ def measure_config(name, m, alpha, beliefs, dtype, mode, steps, warmup, fence, t
         eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype, mode=mode)
         if screen is not None:
             eng.set_f64_screen(screen)
+        if fused is not None:
+            eng.set_fused_projection(fused)
         eng.set_alpha(alpha)
         eng.set_beliefs(beliefs)
         B = beliefs.shape[0]
@@ -295,6 +301,10 @@ def main():
             'value_mean_over_region': n_total * K / elapsed, 'ms_per_step_mean': elapsed / K * 1e3,
             'ms_per_step_min': float(per_step.min()) * 1e3, 'ms_per_step_max': float(per_step.max()) * 1e3,
             'roofline': gemm_roofline(stats, args.dtype, args.mode) if stats and stats[0] else None,
+            # the executed MFMA work of the step at the fp32 peak / the device time of the whole step (all kernels)
+            'step_frac_of_mfma_bound': (stats[0]['score_flops_executed'] / (PEAK_F32_MFMA_TFLOPS * 1e12)
+                                        / (float(np.mean([s['ms_total'] for s in stats])) * 1e-3))
+            if stats and stats[0] and args.dtype == 'f32' else None,
             'stage_ms': {k: float(np.mean([s[k] for s in stats])) for k in STAGES} if stats and stats[0] else None,
         }
         if stats and stats[-1]:
@@ -342,6 +352,9 @@ def main():
     if rank == 0 and args.secondary == 'auto' and default_workload:
         sec = {}
         try:
+            sec['c4_unfused'] = measure_config('the headline workload with the Gamma projection as a kernel of its own (round 1\'s '
+                                               'pipeline: k_project writes Gamma, the stream-K GEMM reads it)', m, alpha, beliefs,
+                                               'f32', 'sparse', 20, 5, fence, fused=False)
             sec['c4_f64'] = measure_config('olfactory-30000 reachable-sparse R=1, fp64 engine (the reference\'s precision; scores '
                                            'screened in fp32, near-ties re-decided from the fp64 operands)',
                                            m, alpha, beliefs, 'f64', 'sparse', 10, 3, fence)

@@ -87,7 +87,8 @@ typedef struct pbvi_stats {
                                 clears and the scale/copy pass around it); 0 in sparse mode */
     int32_t screened;        /* fp64 engines: 1 when the scores came from the fp32 screen (fp32 stream-K GEMM on rounded
                                 copies of the operands, near-ties re-decided from the fp64 originals), 0 = pure fp64 */
-    int32_t reserved_;
+    int32_t fused_projection; /* 1 when the score GEMM generated its Gamma tiles in the operand staging (R = 1, fp32
+                                scoring, alpha-side formulation): ms_project then covers only the few projected rows */
 } pbvi_stats_t;
 
 /* Library / device queries. */
@@ -353,6 +354,14 @@ int pbvi_set_formulation(pbvi_engine_t* e, int formulation);
  * PBVI_F64_SCREEN=off|auto|always in the environment sets the initial mode.
  */
 int pbvi_set_f64_screen(pbvi_engine_t* e, int mode);
+
+/*
+ * fp32 scoring with one reachable state per (s, a) (every large model of the reference): 1 (default) = the score GEMM
+ * generates the Gamma tiles (src/pomdp.py:1485-1491) on the way into LDS instead of reading a projected copy from HBM;
+ * 0 = project first (k_project), then multiply -- the same scores bit for bit, kept for A/B measurements.  No effect
+ * where the fused path does not apply (R > 1, fp64 scoring, belief-side formulation, dense mode).
+ */
+int pbvi_set_fused_projection(pbvi_engine_t* e, int enable);
 
 /* Tuning knob for f32 engines: relative half-width of the near-tie window that sends an
  * argmax to fp64 refinement (<= 0 restores the default derived from |S|). */

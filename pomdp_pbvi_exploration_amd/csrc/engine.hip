@@ -345,6 +345,7 @@ struct ScoreStage {
     double tol_rel;
     const int* chain;
     int64_t rd_col0, extra_row0, f64_pairs;
+    bool fused;                       // the GEMM generated its Gamma tiles itself (gemm.hip, scheduler 2b)
 };
 
 class EngineBase {
@@ -372,6 +373,7 @@ class EngineBase {
     virtual int set_value_max_exact(int exact) = 0;
     virtual int set_formulation(int f) = 0;
     virtual int set_screen(int mode) = 0;
+    virtual int set_fused(int enable) = 0;
     virtual int64_t device_bytes() const = 0;
     virtual int64_t store_append(int which, const void* rows, int64_t n) = 0;
     virtual int64_t store_append_unique(const int32_t* unique_idx, int64_t n) = 0;
@@ -1666,6 +1668,11 @@ class EngineT : public EngineBase {
         return !simple && m_rows * n_rows >= 64 * 64;
     }
 
+    int set_fused(int enable) override {
+        fuse_project_ = enable != 0;
+        if (screen_) screen_->fuse_project_ = fuse_project_;
+        return PBVI_OK;
+    }
     int set_screen(int mode) override {
         if (mode < 0 || mode > 2) FAIL(PBVI_EINVAL, "set_f64_screen: 0 = never, 1 = automatic, 2 = always");
         screen_mode_ = mode;
@@ -1877,6 +1884,7 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
     }
     SlabView<T> sv;
     out->extra_row0 = -1;
+    out->fused = false;
     if (use_push) {
         // K1 (belief side): every belief through every (a, o); K2: [B*A*O] x [V]
         if ((rc = build_inverse_lists())) return rc;
@@ -1979,6 +1987,7 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
         // K2: scores
         // (its tile lists and stream-K plan are built on the side stream, beside the projection)
         if ((rc = score_gemm(gam_.as<T>(), N, nzB_.as<uint8_t>(), AO, (int)V_, &sv, nullptr, 0, nullptr, io.side, fused))) return rc;
+        out->fused = fused != nullptr;
     }
     HIPCHK(hipEventRecord(io.ev[2], stream_));
     HIPCHK(hipStreamWaitEvent(stream_, io.join, 0));       // dead flags + rdot ready
@@ -2017,6 +2026,7 @@ int EngineT<T>::ensure_screen() {
             return rc;
         }
         e->formulation_ = formulation_;
+        e->fuse_project_ = fuse_project_;
         screen_ = e;
         return PBVI_OK;
     }
@@ -2337,6 +2347,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
             st->split_k = 1;
         }
         st->screened = screened ? 1 : 0;
+        st->fused_projection = sc.fused ? 1 : 0;
     }
     return PBVI_OK;
 }
@@ -2711,6 +2722,10 @@ int pbvi_belief_update(pbvi_engine_t* e, const int32_t* actions, const int32_t* 
 int pbvi_set_formulation(pbvi_engine_t* e, int formulation) {
     NEED(e);
     return e->impl->set_formulation(formulation);
+}
+int pbvi_set_fused_projection(pbvi_engine_t* e, int enable) {
+    NEED(e);
+    return e->impl->set_fused(enable);
 }
 int pbvi_set_f64_screen(pbvi_engine_t* e, int mode) {
     NEED(e);

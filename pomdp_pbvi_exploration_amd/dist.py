@@ -55,11 +55,14 @@ def _valid_mask(n_total: int, world: int, per: int) -> np.ndarray:
     return m
 
 
-def _carrier_device(dist, group):
-    """Where collective operands must live: CUDA for nccl (= RCCL), host for gloo."""
+def _carrier_device(dist, group, device_index=None):
+    """Where collective operands must live: CUDA for nccl (= RCCL) -- the engine's own device when there is one, else
+    torch's current device -- and host memory for gloo."""
     import torch
     backend = str(dist.get_backend(group)).lower()
-    return torch.device('cuda', torch.cuda.current_device()) if 'nccl' in backend else torch.device('cpu')
+    if 'nccl' not in backend:
+        return torch.device('cpu')
+    return torch.device('cuda', torch.cuda.current_device() if device_index is None else int(device_index))
 
 
 class ShardedBackup:
@@ -362,7 +365,7 @@ def sharded_backup(solver, model, belief_set, value_function, belief_dominance_p
     beliefs = belief_set.belief_list
     n_total = len(beliefs)
     lo, hi, per = shard_bounds(n_total, world, rank)
-    carrier = _carrier_device(dist, group)
+    carrier = _carrier_device(dist, group, value_function.model.engine.device if value_function.is_on_gpu else None)
 
     if not value_function.is_on_gpu:
         # host mirror: the reference's NumPy statements on this rank's block, per-belief rows exchanged

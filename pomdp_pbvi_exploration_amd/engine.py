@@ -33,7 +33,7 @@ EXPORTS = [
     'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact',
     'pbvi_belief_walk_keys', 'pbvi_backup_fetch_value_max',
     'pbvi_backup_fetch_compact', 'pbvi_host_alloc', 'pbvi_host_free', 'pbvi_debug_gemm_dense',
-    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_set_f64_screen',
+    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_set_f64_screen', 'pbvi_set_fused_projection',
 ]
 
 
@@ -50,7 +50,7 @@ class PbviStats(C.Structure):
                 ('score_flops', C.c_int64), ('score_flops_executed', C.c_int64), ('score_tiles_dense', C.c_int64),
                 ('score_tiles_run', C.c_int64), ('project_flops', C.c_int64), ('project_flops_executed', C.c_int64),
                 ('split_k', C.c_int32), ('formulation', C.c_int32), ('n_refine_candidates', C.c_int64),
-                ('ms_project_gemm', C.c_double), ('screened', C.c_int32), ('reserved_', C.c_int32)]
+                ('ms_project_gemm', C.c_double), ('screened', C.c_int32), ('fused_projection', C.c_int32)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -118,6 +118,7 @@ def load_library(path: str = LIB_PATH):
                                                C.c_double, C.c_double, C.c_int32, f64p, f64p, i32p]),
         'pbvi_set_formulation': (C.c_int, [vp, C.c_int]),
         'pbvi_set_f64_screen': (C.c_int, [vp, C.c_int]),
+        'pbvi_set_fused_projection': (C.c_int, [vp, C.c_int]),
         'pbvi_belief_walk': (C.c_int64, [vp, f64p, C.c_int64, i32p, i32p, u8p, f64p]),
         'pbvi_engine_set_rto_f64': (C.c_int, [vp, f64p]),
         'pbvi_backup_fetch_unique_keys': (C.c_int, [vp, vp]),
@@ -898,6 +899,11 @@ class Engine:
         """Operand projected through the model: ``'auto'``, ``'alpha'`` (Gamma, the reference's order) or
         ``'belief'`` (beliefs pushed through every (a, o); cheaper when B << V)."""
         _check(self._lib.pbvi_set_formulation(self._h, {'auto': 0, 'alpha': 1, 'belief': 2}[which]))
+
+    def set_fused_projection(self, enable: bool = True) -> None:
+        """fp32 scoring, R = 1: Gamma tiles generated inside the score GEMM (default) or projected first
+        (``pbvi_set_fused_projection``; same scores bit for bit)."""
+        _check(self._lib.pbvi_set_fused_projection(self._h, 1 if enable else 0))
 
     def set_f64_screen(self, mode: str = 'auto') -> None:
         """fp64 engines: ``'off'`` (pure fp64 arithmetic), ``'auto'`` (fp32 screen + fp64 re-decision of near-ties when the
