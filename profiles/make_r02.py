@@ -54,7 +54,7 @@ def main():
     out += ['## Agreement of `bench.py`\'s live kernel time with rocprofv3 (same profiled run)', '',
             f'`bench.py` brackets the score GEMM with HIP events on the engine\'s stream: **{live:.4f} ms** per launch over its '
             f'{k} timed steps (after {w} warm-up steps).  rocprofv3\'s durations of those same {k} launches of '
-            f'`{bench["roofline"]["kernel"].split(" ")[0]}`_fused (launches {w + 1}..{w + k} of the process): '
+            f'`{bench["roofline"]["kernel"].split(" ")[0]}` (launches {w + 1}..{w + k} of the process): '
             + ', '.join(f'{x:.0f}' for x in timed) + f' us, mean **{sum(timed) / len(timed) / 1e3:.4f} ms**.  '
             f'(The table above averages all {len(launches)} launches of the process: warm-up, timed, the device-resident '
             f'repeat and the 3 PCIe-inclusive steps.)  Unprofiled, the default `python bench.py` run is in '
