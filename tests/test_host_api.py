@@ -281,6 +281,7 @@ class _StubEngine:
         self.rows = {'alpha': [], 'belief': []}
         self._store_epoch = {'alpha': 0, 'belief': 0}
         self._vmax_cache, self._vmax_epochs = [], None
+        self.serial = next(Engine._serials)                  # residency tags name the engine by serial, not by id()
         self.pairs_scored = 0
         # the real bookkeeping methods, bound to this object
         self.dtype = 'f64'
@@ -363,7 +364,7 @@ def test_store_ids_travel_with_the_containers():
     # a backup's result: two new rows and one that repeats an old row's bytes, every vector tagged with its store id
     rows = np.vstack([rng.normal(size=(2, S)), old.alpha_vector_array[3:4]])
     first = eng.store_rows('alpha', rows)
-    tag = (id(eng), 'alpha', eng._store_epoch['alpha'])
+    tag = (eng.serial, 'alpha', eng._store_epoch['alpha'])
     vecs = []
     for k, r in enumerate(rows):
         v = AlphaVector(r, 2)
