@@ -966,6 +966,46 @@ def test_exact_ties_with_hundreds_of_candidates(formulation):
     eng.close()
 
 
+@pytest.mark.parametrize('S,A,O,V,B,regular', [(1000, 2, 2, 512, 70, False), (4097, 3, 1, 300, 300, True), (2500, 1, 3, 777, 40, False),
+                                                (30000, 2, 2, 256, 260, True)])
+def test_fused_projection_gives_the_bits_of_the_projected_pipeline(S, A, O, V, B, regular):
+    """Score GEMM with the Gamma tiles generated in its operand staging (R = 1) against the same engine with the projection
+    as a kernel of its own (``pbvi_set_fused_projection``): same products, same rounding, same summation order, so every
+    output -- indices, actions, alpha' bytes, and the refinement's work -- is identical, and both are the oracle's.  Shapes:
+    groups that end inside a 256-row tile (V not a multiple of 256: straddling tiles stay projected), S not a multiple of 32,
+    successor maps that are shifts (``regular``: 16-byte alpha loads) or random (every K tile takes the gather path)."""
+    rng = np.random.default_rng(S + V)
+    if regular:
+        rs = ((np.arange(S)[:, None] + rng.integers(-5, 6, size=A)[None, :]) % S)[:, :, None].astype(np.int64)
+    else:
+        rs = rng.integers(0, S, size=(S, A, 1))
+    p = rng.random((S, A, O))
+    p[rng.random((S, A, O)) < 0.3] = 0.0
+    p[:, :, 0] += 1e-3
+    rto = (p / p.sum(axis=2, keepdims=True))[:, :, :, None].astype(np.float32).astype(np.float64)
+    er = rng.normal(size=(S, A)).astype(np.float32).astype(np.float64)
+    alpha = rng.normal(scale=4.0, size=(V, S)).astype(np.float32).astype(np.float64)
+    b = rng.random((B, S)) * (rng.random((B, S)) < 0.2)
+    b[:, rng.integers(0, S, size=B)] += 1e-3
+    b = (b / b.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    want_rows, want_a, want_v = orc.backup_core(alpha, b, rs, rto, er, 0.9)
+    eng = Engine(S, A, O, 1, rs, rto, er, dtype='f32')
+    eng.set_formulation('alpha')
+    out = {}
+    for fused in (True, False):
+        eng.set_fused_projection(fused)
+        res = eng.backup_full(alpha, b, 0.9, belief_dominance_prune=True)
+        assert res.stats['fused_projection'] == int(fused)
+        assert np.array_equal(res.best_alpha_ind, want_v) and np.array_equal(res.actions, want_a), fused
+        assert_alpha_close(res.alpha, want_rows, F32_RTOL)
+        out[fused] = res
+    f, u = out[True], out[False]
+    assert np.array_equal(f.alpha, u.alpha) and np.array_equal(f.keep, u.keep)
+    for k in ('n_refined', 'n_refine_candidates', 'n_refined_actions', 'n_dead', 'n_unique', 'score_tiles_run'):
+        assert f.stats[k] == u.stats[k], k
+    eng.close()
+
+
 def test_speculative_refinement_recovers_when_ties_appear():
     """After a backup whose refinement deferred nothing the engine stops reading the deferred-work counts in the middle of
     the pipeline: it enqueues the later stages at once and checks the counts at the end.  Here the first backup has no
