@@ -1006,6 +1006,55 @@ def test_fused_projection_gives_the_bits_of_the_projected_pipeline(S, A, O, V, B
     eng.close()
 
 
+_SEA_ROBIN = {}
+
+
+def _sea_robin_case():
+    if not _SEA_ROBIN:
+        rng = np.random.default_rng(61875)
+        H, W, A, O, V, B = 165, 375, 16, 2, 300, 100
+        S = H * W
+        y, x = np.divmod(np.arange(S), W)
+        moves = [(-1, 0), (0, 1), (1, 0), (0, -1), (-2, 0), (0, 2), (2, 0), (0, -2), (-1, 1), (1, 1), (1, -1), (-1, -1), (0, 0),
+                 (0, 5), (5, 0), (0, -5)]
+        rs = np.stack([((y + dy) % H) * W + (x + dx) % W for dy, dx in moves], axis=1)[:, :, None].astype(np.int64)
+        p = 0.05 + 0.9 * rng.random((S, A))
+        p[rng.random((S, A)) < 0.2] = 0.0                                  # states where one observation is impossible
+        rto = np.stack([p, 1.0 - p], axis=2)[:, :, :, None].astype(np.float32).astype(np.float64)
+        er = (rng.random((S, A)) < 0.01).astype(np.float64)
+        alpha = (rng.random((V, S)) * rng.random((V, 1)) * 10.0).astype(np.float32).astype(np.float64)
+        b = rng.random((B, S)) * (rng.random((B, S)) < 0.1)
+        b[:, 17] += 1e-3
+        b = (b / b.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+        _SEA_ROBIN['case'] = (S, A, O, rs, rto, er, alpha, b, orc.backup_core_tiled(alpha, b, rs, rto, er, 0.99))
+    return _SEA_ROBIN['case']
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_sea_robin_shape_against_oracle(dtype):
+    """The shape of the reference's largest other model family (Sea_Robin_Real.ipynb: S=61875, A=16, O=2, one reachable
+    state; its CuPy run went out of memory at |V|=1386): 32 (a,o) groups, S not a multiple of 32, V not a multiple of 256,
+    successor maps that are grid moves with wrap-around.  Synthetic tables (the notebook's data files are not shipped);
+    fp32 engine (fused GEMM) and fp64 engine (large enough for the screen to engage by itself), both formulations,
+    against the oracle."""
+    S, A, O, rs, rto, er, alpha, b, (want_rows, want_a, want_v) = _sea_robin_case()
+    eng = Engine(S, A, O, 1, rs, rto, er, dtype=dtype)
+    eng.set_formulation('alpha')
+    res = eng.backup_full(alpha, b, 0.99)
+    if dtype == 'f32':
+        assert res.stats['fused_projection'] == 1
+    else:
+        assert res.stats['screened'] == 1
+    assert np.array_equal(res.best_alpha_ind, want_v), int(np.sum(res.best_alpha_ind != want_v))
+    assert np.array_equal(res.actions, want_a)
+    assert_alpha_close(res.alpha, want_rows, F32_RTOL if dtype == 'f32' else F64_RTOL)
+    eng.set_formulation('belief')
+    push = eng.backup_full(alpha, b, 0.99)
+    assert push.stats['formulation'] == 2
+    assert np.array_equal(push.best_alpha_ind, want_v) and np.array_equal(push.actions, want_a)
+    eng.close()
+
+
 def test_speculative_refinement_recovers_when_ties_appear():
     """After a backup whose refinement deferred nothing the engine stops reading the deferred-work counts in the middle of
     the pipeline: it enqueues the later stages at once and checks the counts at the end.  Here the first backup has no
