@@ -2122,6 +2122,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     if ((rc = keep_.ensure((size_t)B_, &bytes_))) return rc;
     int* qcount = counters_.as<int>();
     int* aqcount = counters_.as<int>() + 1;
+    if (windows && (rc = stage_reserve(256))) return rc;      // pinned room for the refinement's counts, while the stream is idle
     HIPCHK(hipMemsetAsync(counters_.p, 0, 8 * sizeof(int), stream_));
 
     HIPCHK(hipEventRecord(ev_[0], stream_));
@@ -2194,9 +2195,8 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     bool speculate = false;
     if (windows) {
         if ((rc = refine_work(pairs, V_, &work))) return rc;
-        // the counts land in the engine's pinned bounce buffer (idle during a backup: results are staged through it only
-        // by the fetch calls that follow)
-        if ((rc = stage_reserve(256))) return rc;
+        // the counts land in the engine's pinned bounce buffer (reserved at the top of the call; idle during a backup:
+        // results are staged through it only by the fetch calls that follow)
         rf_counts_ = reinterpret_cast<int*>(host_stage_);
         rf_counts_[0] = rf_counts_[1] = 0;
         static const bool no_spec = getenv("PBVI_NO_SPECULATION") != nullptr;      // debug / A-B only
