@@ -296,7 +296,11 @@ def main():
                        'step': ('local backup + all-gather of ' + ('alpha rows' if exchange_rows else 'row keys')
                                 + ' + global dedup + append of the distinct rows to every replica\'s alpha store') if distributed
                                else 'pbvi_backup_run + pbvi_backup_fetch_compact (U distinct rows, index, actions) into pinned host memory, synchronised',
-                       'parallelism': f'belief-sharded x{world}' if distributed else 'single GPU'},
+                       'parallelism': f'belief-sharded x{world}' if distributed else 'single GPU',
+                       'resident_inputs': 'alpha set and belief block in HBM before the timed region, with the indexes the engine '
+                                          'builds of a belief block when it becomes resident / is first backed up (sort order, '
+                                          'zero-tile map, dead-triple flags, per-belief tile lists); nothing computed from the '
+                                          'alpha set is kept between steps'},
             'value_statistic': f'beliefs / median of the {K} timed steps (SURVEY 8d)',
             'value_mean_over_region': n_total * K / elapsed, 'ms_per_step_mean': elapsed / K * 1e3,
             'ms_per_step_min': float(per_step.min()) * 1e3, 'ms_per_step_max': float(per_step.max()) * 1e3,

@@ -459,6 +459,8 @@ class EngineT : public EngineBase {
     std::vector<uint8_t> h_mat_;
     std::vector<int> h_vlist_;
     int64_t mat_V_ = -1;
+    uint64_t dead_ver_ = 0;                                  // belief-block version dead_ / btl_ / btc_ describe
+    int64_t dead_pairs_ = 0, dead_count_ = 0;
     int* rf_counts_ = nullptr;                               // [2] in host_stage_: what the refinement's per-entry pass deferred
     bool last_deferred_nothing_ = false;                     // (the first backup of an engine reads the counts mid-pipeline)
     bool owns_streams_ = true;                               // false: a screen running on its fp64 engine's streams
@@ -2140,9 +2142,19 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         if ((rc = btl_.ensure((size_t)B_ * k_tiles * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = btc_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = val_exact_.ensure((size_t)B_ * A_ * (1 + O_) * sizeof(double), &bytes_))) return rc;
-        HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(),
-                              btl_.as<int32_t>(), btc_.as<int32_t>(), counters_.as<int>() + 5, side));
-        btl_valid_ = true;
+        // Dead triples and the per-belief tile lists are a function of the belief block and the model alone: computed on
+        // the first backup of a block, kept for the following ones (a solve backs a block up once; update_passes > 1,
+        // the belief-dominance loops of the notebooks and the benchmark back the same block up again and again).  Like
+        // the block's sort order and zero-tile map they index the INPUT; nothing of a backup's result is kept.
+        static const bool no_cache = getenv("PBVI_NO_DEAD_CACHE") != nullptr;       // debug / A-B only
+        if (dead_ver_ != bel_ver_ || !btl_valid_ || dead_pairs_ != pairs || no_cache) {
+            HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(),
+                                  btl_.as<int32_t>(), btc_.as<int32_t>(), counters_.as<int>() + 5, side));
+            btl_valid_ = true;
+            dead_ver_ = bel_ver_;
+            dead_pairs_ = pairs;
+            dead_count_ = -1;                                // read back with this call's counters
+        }
     }
     if (use_push) {   // b . ER[:,a] in f64 (the alpha-side gets it from Gamma's reward rows)
         if ((rc = prd_.ensure((size_t)B_ * A_ * sizeof(double), &bytes_))) return rc;
@@ -2282,6 +2294,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
             if ((rc = later_stages())) return rc;
         }
     }
+    if (windows && dead_count_ < 0) dead_count_ = h_cnt[5];
     full_valid_ = false;
     res_sorted_ = sorted_;
     have_result_ = true;
@@ -2312,7 +2325,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         st->n_refined_actions = h[1];
         st->n_unique = h_ucount;
         st->formulation = last_formulation_;
-        st->n_dead = windows ? h[5] : 0;                     // counted by k_dead
+        st->n_dead = windows ? dead_count_ : 0;              // counted by k_dead (when the block was first backed up)
         if (mode_ == PBVI_DENSE) {
             if (kF32) {
                 float t = 0.f;
