@@ -181,6 +181,14 @@ int pbvi_backup_fetch_unique(pbvi_engine_t* e, void* out_rows, int32_t* out_inde
 int pbvi_backup_fetch_compact(pbvi_engine_t* e, void* out_rows, int32_t* out_index, int32_t* out_action,
                               int32_t* out_best_alpha, uint8_t* out_keep);
 
+/*
+ * Hashes of the U distinct rows of the last backup, out_hashes [U] uint64: sum_i bits(row, i) * (2 i + 1) mod 2^64 over
+ * the row's fp32 / fp64 bit patterns.  ValueFunction.__init__ keys its dedup dictionary on `values.tobytes()`
+ * (src/mdp.py:667-669) -- 120-240 KB copied and hashed per row; the host mirror keys it on this number instead (equality
+ * is still decided on the bytes), computed where the rows are.
+ */
+int pbvi_backup_fetch_row_hashes(pbvi_engine_t* e, uint64_t* out_hashes);
+
 /* Page-locked host memory for result buffers (hipHostMalloc / hipHostFree); NULL on failure.  The reference's
  * counterpart is CuPy's pinned-memory pool behind `cp.asnumpy` (src/mdp.py:806-831, ValueFunction.to_cpu). */
 void* pbvi_host_alloc(size_t bytes);

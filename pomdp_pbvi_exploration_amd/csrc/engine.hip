@@ -295,6 +295,28 @@ __global__ void k_row_bit_sums(const double* __restrict__ rows, int S, unsigned 
     if (threadIdx.x == 0) key[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// hash[r] = sum_i bits(row r, element i) * (2 i + 1)  (mod 2^64): the key the host's alpha-vector container hashes its
+// rows by (mdp.py::_AlphaKey -- equality is still decided on the bytes).  Position-weighted: a solve's alpha-vectors are
+// largely shifted copies of one another, which a plain sum of bit patterns cannot tell apart.
+template <typename T>
+__global__ void k_row_hash(const T* __restrict__ rows, int ld, int S, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long red[4];
+    const T* p = rows + (int64_t)blockIdx.x * ld;
+    unsigned long long acc = 0;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        unsigned long long bits;
+        if constexpr (sizeof(T) == 4)
+            bits = (unsigned long long)__float_as_uint((float)p[s]);
+        else
+            bits = (unsigned long long)__double_as_longlong((double)p[s]);
+        acc += bits * (2ull * (unsigned long long)s + 1ull);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 // max_v score[row0 + b][v] for the B extra rows of the belief-side GEMM (the beliefs themselves multiplied by the alpha
 // set: b . alpha_v), one wave per row; out[perm ? perm[b] : b]
 template <typename T>
@@ -362,6 +384,7 @@ class EngineBase {
     virtual int fetch_unique(void* out_rows, int32_t* out_index) = 0;
     virtual int fetch_compact(void* out_rows, int32_t* out_index, int32_t* out_action, int32_t* out_best, uint8_t* out_keep) = 0;
     virtual int fetch_unique_keys(int32_t* out_keys) = 0;
+    virtual int fetch_row_hashes(uint64_t* out) = 0;
     virtual int fetch_exchange(int32_t* out, int64_t per) = 0;
     virtual int assemble_keys(double gamma, int64_t n, const int32_t* keys, void* out_rows) = 0;
     virtual int64_t assemble_keys_store(double gamma, int64_t n, const int32_t* keys, void* out_rows) = 0;
@@ -1332,6 +1355,22 @@ class EngineT : public EngineBase {
             host_stage_cap_ = want;
         }
         return PBVI_OK;
+    }
+
+    // position-weighted bit-pattern hashes of the U distinct rows of the last backup (see k_row_hash)
+    int fetch_row_hashes(uint64_t* out) override {
+        if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch_row_hashes: no backup result resident");
+        if (!out) FAIL(PBVI_EINVAL, "backup_fetch_row_hashes: NULL destination");
+        if (res_unique_ <= 0) return PBVI_OK;
+        HIPCHK(hipSetDevice(device_));
+        int rc = keys_tmp_.ensure((size_t)res_unique_ * sizeof(uint64_t), &bytes_);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_row_hash<T>, dim3((unsigned)res_unique_), dim3(256), 0, stream_, out_.as<T>(), S_, S_,
+                           keys_tmp_.as<unsigned long long>());
+        HIPCHK(hipGetLastError());
+        if ((rc = out_begin())) return rc;
+        if ((rc = out_add(out, keys_tmp_.p, (size_t)res_unique_ * sizeof(uint64_t)))) return rc;
+        return out_finish();
     }
 
     // (a*, v*[a*,:]) of every unique row of the last backup: [U][1+O] int32, host or device destination
@@ -2593,6 +2632,10 @@ int64_t pbvi_backup_store_unique(pbvi_engine_t* e, const int32_t* unique_idx, in
     return e->impl->store_append_unique(unique_idx, n);
 }
 
+int pbvi_backup_fetch_row_hashes(pbvi_engine_t* e, uint64_t* out_hashes) {
+    NEED(e);
+    return e->impl->fetch_row_hashes(out_hashes);
+}
 int pbvi_backup_fetch_unique_keys(pbvi_engine_t* e, int32_t* out_keys) {
     NEED(e);
     return e->impl->fetch_unique_keys(out_keys);

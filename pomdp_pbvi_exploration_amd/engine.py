@@ -33,7 +33,7 @@ EXPORTS = [
     'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact',
     'pbvi_belief_walk_keys', 'pbvi_backup_fetch_value_max',
     'pbvi_backup_fetch_compact', 'pbvi_host_alloc', 'pbvi_host_free', 'pbvi_debug_gemm_dense',
-    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_set_f64_screen', 'pbvi_set_fused_projection',
+    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_set_f64_screen', 'pbvi_set_fused_projection', 'pbvi_backup_fetch_row_hashes',
 ]
 
 
@@ -122,6 +122,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_belief_walk': (C.c_int64, [vp, f64p, C.c_int64, i32p, i32p, u8p, f64p]),
         'pbvi_engine_set_rto_f64': (C.c_int, [vp, f64p]),
         'pbvi_backup_fetch_unique_keys': (C.c_int, [vp, vp]),
+        'pbvi_backup_fetch_row_hashes': (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         'pbvi_assemble_rows': (C.c_int, [vp, C.c_double, C.c_int64, vp, vp]),
         'pbvi_backup_fetch_exchange': (C.c_int, [vp, vp]),
         'pbvi_backup_fetch_exchange_padded': (C.c_int, [vp, C.c_int64, vp]),
@@ -707,6 +708,15 @@ class Engine:
         """Copy unique rows [U,S] / index [B] to raw (host or device) addresses."""
         _check(self._lib.pbvi_backup_fetch_unique(self._h, C.c_void_p(rows_ptr) if rows_ptr else None,
                                                   C.cast(index_ptr, C.POINTER(C.c_int32)) if index_ptr else None))
+
+    def fetch_row_hashes(self) -> np.ndarray:
+        """``[U]`` uint64: the position-weighted bit-pattern hashes of the last backup's distinct rows, computed on the
+        device (``pbvi_backup_fetch_row_hashes``); ``mdp._AlphaKey`` is the host's function of the same name."""
+        U = self.unique_count
+        out = np.empty(max(U, 0), dtype=np.uint64)
+        if U > 0:
+            _check(self._lib.pbvi_backup_fetch_row_hashes(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
 
     def fetch_unique_keys(self) -> np.ndarray:
         """``[U, 1+O]`` int32: (a*, v*[a*, :]) of each distinct alpha' row of the last backup."""

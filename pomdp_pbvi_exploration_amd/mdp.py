@@ -284,9 +284,9 @@ class _RowKey(int):
     a megabyte per row: the key IS an integer -- the wrapping sum of the row's bit patterns, one single-threaded pass,
     equal bytes give equal sums -- so dictionaries hash it at C speed, and equality compares the bytes, which only
     happens when two keys carry the same sum, i.e. practically only for equal rows.  Used by the belief containers;
-    the alpha-vector container keeps ``bytes`` keys: the sum is permutation-invariant and a solve's alpha-vectors are
-    largely shifted copies of one another (wrap-around grid), so their sums collide -- 400 byte comparisons per
-    ``extend`` when tried."""
+    the alpha-vector container uses ``_AlphaKey`` (a position-weighted sum): the plain sum is permutation-invariant and
+    a solve's alpha-vectors are largely shifted copies of one another (wrap-around grid), so their sums collide -- 400
+    byte comparisons per ``extend`` when tried."""
 
     def __new__(cls, row):
         if isinstance(row, int):                            # copy / pickle rebuild: the row comes back through __dict__
@@ -317,12 +317,66 @@ class _RowKey(int):
         return not self.__eq__(other)
 
 
+class _AlphaKey(int):
+    """Dictionary key of an alpha-vector row with the semantics of the row's bytes (the reference keys
+    ``ValueFunction._uniqueness_dict`` on ``values.tobytes()``, ``src/mdp.py:660-669``): the key IS an integer -- the
+    position-weighted sum ``sum_i bits_i * (2 i + 1) mod 2^64`` of the row's fp32 / fp64 bit patterns, so equal bytes give
+    equal keys and shifted copies of a row (a solve's alpha-vectors on a wrap-around grid) do not collide as they do under
+    the plain sum of ``_RowKey`` -- and equality compares the bytes, which only happens when two keys carry the same number,
+    i.e. practically only for equal rows.  For rows the engine produced the number comes from the device
+    (``pbvi_backup_fetch_row_hashes``); here it costs one pass instead of a 120-240 KB copy plus a byte hash."""
+
+    _weights = {}
+
+    def __new__(cls, row):
+        if isinstance(row, int):                            # copy / pickle rebuild: the row comes back through __dict__
+            return int.__new__(cls, row)
+        self = int.__new__(cls, cls.hash_of(row))
+        self.row = row
+        return self
+
+    @classmethod
+    def hash_of(cls, row) -> int:
+        a = np.ascontiguousarray(row)
+        if a.dtype.itemsize not in (4, 8) or a.ndim != 1:
+            return hash(a.tobytes()) & 0xFFFFFFFFFFFFFFFF
+        bits = a.view(np.uint32 if a.dtype.itemsize == 4 else np.uint64)
+        w = cls._weights.get(bits.shape[0])
+        if w is None:
+            w = cls._weights[bits.shape[0]] = np.arange(bits.shape[0], dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+        with np.errstate(over='ignore'):
+            return int(np.dot(bits.astype(np.uint64, copy=False), w))      # integer dot: wraps modulo 2^64 like the device sum
+
+    @classmethod
+    def from_hash(cls, h: int, row) -> '_AlphaKey':
+        """Key of ``row`` whose hash is already known (the engine computes it for rows it produced)."""
+        self = int.__new__(cls, int(h))
+        self.row = row
+        return self
+
+    __hash__ = int.__hash__
+
+    def __eq__(self, other) -> bool:
+        return int.__eq__(self, other) is True and (self.row is other.row or self.row.tobytes() == other.row.tobytes())
+
+    def __ne__(self, other) -> bool:
+        return not self.__eq__(other)
+
+
 class AlphaVector:
     """One hyperplane over the state space and its action (``src/mdp.py:593-608``)."""
 
     def __init__(self, values: np.ndarray, action: int) -> None:
         self.values = values
         self.action = int(action)
+
+    @property
+    def key(self) -> _AlphaKey:
+        """Dedup key of the row as it is NOW (the reference computes ``values.tobytes()`` whenever a container is built).
+        Rows the engine produced carry the device's hash (``_hash``, set with the row, which nothing in this package
+        mutates); anything else is hashed here."""
+        h = self.__dict__.get('_hash')
+        return _AlphaKey.from_hash(h, self.values) if h is not None else _AlphaKey(self.values)
 
 
 class ValueFunction:
@@ -350,7 +404,7 @@ class ValueFunction:
             assert alpha_vectors.shape == expected, \
                 f"Alpha vector array does not have the right shape (received: {alpha_vectors.shape}; expected: {expected})"
             vectors = [AlphaVector(row, act) for row, act in zip(alpha_vectors, action_list)]
-        self._uniqueness_dict = {v.values.tobytes(): v for v in vectors}
+        self._uniqueness_dict = {v.key: v for v in vectors}
         self._vector_list = list(self._uniqueness_dict.values())
         self._pruning_level = 1
 
@@ -395,7 +449,7 @@ class ValueFunction:
 
     def append(self, alpha_vector: AlphaVector) -> None:
         assert alpha_vector.values.shape[0] == self.model.state_count, "Vector to add to value function doesn't have the right size"
-        self._uniqueness_dict[alpha_vector.values.tobytes()] = alpha_vector
+        self._uniqueness_dict[alpha_vector.key] = alpha_vector
         self._vector_list = list(self._uniqueness_dict.values())
         self._dev_ids = None
         self._vector_array = None
@@ -485,7 +539,7 @@ class ValueFunction:
                 if len(items) == len(vecs):
                     self._uniqueness_dict = {k: v for (k, v), kp in zip(items, keep) if kp}
                 else:                                        # list holds duplicates the dictionary folded: rebuild
-                    self._uniqueness_dict = {v.values.tobytes(): v for v, kp in zip(vecs, keep) if kp}
+                    self._uniqueness_dict = {v.key: v for v, kp in zip(vecs, keep) if kp}
                 self._vector_list = list(self._uniqueness_dict.values())
                 self._vector_array = None
                 self._actions = None
@@ -496,7 +550,7 @@ class ValueFunction:
                     keep[i] = np.count_nonzero(np.all(arr >= v, axis=1)) == 1
                 self._vector_array = arr[keep]
                 self._actions = self.actions[keep]
-                self._uniqueness_dict = {r.tobytes(): AlphaVector(r, a) for r, a in zip(self._vector_array, self._actions)}
+                self._uniqueness_dict = {_AlphaKey(r): AlphaVector(r, a) for r, a in zip(self._vector_array, self._actions)}
                 self._vector_list = list(self._uniqueness_dict.values())
             self._dev_ids = None
         self._pruning_level = level

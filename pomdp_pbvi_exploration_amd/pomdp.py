@@ -459,12 +459,15 @@ class PBVI_Solver(Solver):
                                         alpha_owner=value_function, belief_owner=belief_set)
                 alpha_new, actions, uidx = eng.fetch().value_function_rows(use_keep=belief_dominance_prune, with_index=True)
                 if len(uidx):
-                    # the new rows join the engine's alpha store device to device: the next call selects them by id
+                    # the new rows join the engine's alpha store device to device: the next call selects them by id;
+                    # their dedup hashes come from the device too (ValueFunction keys its dictionary on them)
                     first, tag = eng.store_unique(uidx), eng.store_tag('alpha')
+                    hashes = eng.fetch_row_hashes()[uidx]
                     vectors = []
                     for k, (row, act) in enumerate(zip(alpha_new, actions)):
                         v = AlphaVector(row, act)
                         v._dev = (tag, first + k)
+                        v._hash = int(hashes[k])
                         vectors.append(v)
                     alpha_new = vectors
             else:   # beliefs are independent: larger sets go through the engine in blocks (it takes 65535 at a time)

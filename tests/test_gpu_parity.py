@@ -1055,6 +1055,32 @@ def test_sea_robin_shape_against_oracle(dtype):
     eng.close()
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_device_row_hashes_equal_the_host_hash(dtype):
+    """pbvi_backup_fetch_row_hashes: the numbers the host's alpha-vector container keys on, computed where the rows are,
+    equal ``_AlphaKey.hash_of`` of the fetched rows -- so a row hashed on the device and the same row hashed on the host
+    meet in one dictionary slot -- and PBVI_Solver.backup hands them to the vectors it creates."""
+    from pomdp_pbvi_exploration_amd.mdp import _AlphaKey
+    from pomdp_pbvi_exploration_amd import Model
+    z, rs, rto, er = small(5)
+    eng = Engine(600, 6, 3, 5, rs, rto, er, dtype=dtype)
+    res = eng.backup_full(z['alpha'], z['beliefs'], float(z['gamma']))
+    h = eng.fetch_row_hashes()
+    assert h.shape == (res.unique_alpha.shape[0],)
+    assert [int(x) for x in h] == [_AlphaKey.hash_of(r) for r in res.unique_alpha]
+    eng.close()
+    m = synth.olfactory_model(H=15, W=40, R=1)
+    gm = Model(states=m.S, actions=m.A, observations=m.O, reachable_states=m.reachable_states,
+               observation_table=m.observation_table, end_states=[m.goal], start_probabilities=list(m.start_belief)).to_gpu(dtype)
+    alpha, acts = synth.alpha_set(m, 40)
+    rows = synth.belief_points(m, 30, max_depth=16)
+    out = PBVI_Solver(gamma=m.gamma).backup(gm, BeliefSet(gm, [Belief(gm, r) for r in rows]), ValueFunction(gm, alpha, acts),
+                                           append=True, belief_dominance_prune=False)
+    new = [v for v in out.alpha_vector_list if '_hash' in v.__dict__]
+    assert len(new) > 0 and all(v._hash == _AlphaKey.hash_of(v.values) for v in new)
+    assert len(out) == len({v.values.tobytes() for v in out.alpha_vector_list})          # byte-dedup semantics intact
+
+
 def test_speculative_refinement_recovers_when_ties_appear():
     """After a backup whose refinement deferred nothing the engine stops reading the deferred-work counts in the middle of
     the pipeline: it enqueues the later stages at once and checks the counts at the end.  Here the first backup has no
