@@ -334,8 +334,8 @@ int pbvi_mdp_value_iteration(int device, int32_t S, int32_t A, int32_t R, const 
 int64_t pbvi_belief_walk(pbvi_engine_t* e, const double* b0, int64_t n, const int32_t* actions, const int32_t* observations,
                          const uint8_t* restart, double* out_beliefs);
 /*
- * Dedup keys of the n beliefs of the last pbvi_belief_walk: out_keys[i] = wrapping sum of the 64-bit patterns of the
- * fp64 row i -- the integer the host's belief containers hash on in place of the row's bytes (BeliefSet.union,
+ * Dedup keys of the n beliefs of the last pbvi_belief_walk: out_keys[i] = sum_s bits(row i, s) * (2 s + 1) mod 2^64 over
+ * the 64-bit patterns of the fp64 row i (the hash of pbvi_backup_fetch_row_hashes) -- the integer the host's belief containers hash on in place of the row's bytes (BeliefSet.union,
  * src/pomdp.py:585-606, keys its dictionaries on values.tobytes()) -- so the host does not pass over the rows again.
  */
 int pbvi_belief_walk_keys(pbvi_engine_t* e, int64_t n, uint64_t* out_keys);

@@ -282,19 +282,6 @@ __global__ void k_gather_rows_ld(const T* __restrict__ src, int ld_src, T* __res
     dst[(int64_t)blockIdx.y * ld_dst + s] = src[(int64_t)perm[blockIdx.y] * ld_src + s];
 }
 
-// key[r] = wrapping sum of the 64-bit patterns of row r (the hash the host's belief containers key on: equal bytes give
-// equal sums; mdp.py::_RowKey)
-__global__ void k_row_bit_sums(const double* __restrict__ rows, int S, unsigned long long* __restrict__ key) {
-    __shared__ unsigned long long red[4];
-    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(rows + (int64_t)blockIdx.x * S);
-    unsigned long long acc = 0;
-    for (int s = threadIdx.x; s < S; s += 256) acc += p[s];
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) key[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
 // hash[r] = sum_i bits(row r, element i) * (2 i + 1)  (mod 2^64): the key the host's alpha-vector container hashes its
 // rows by (mdp.py::_AlphaKey -- equality is still decided on the bytes).  Position-weighted: a solve's alpha-vectors are
 // largely shifted copies of one another, which a plain sum of bit patterns cannot tell apart.
@@ -1141,13 +1128,14 @@ class EngineT : public EngineBase {
         return out_finish();
     }
 
-    // bit-pattern sums of the fp64 rows of the last walk (rows 1..n of walk64_), for the host's dedup keys
+    // position-weighted bit-pattern hashes (k_row_hash) of the fp64 rows of the last walk (rows 1..n of walk64_), for the
+    // host's dedup keys
     int walk_keys(int64_t n, uint64_t* out_keys) override {
         if (n <= 0 || n != walk_rows_ || !out_keys) FAIL(PBVI_EINVAL, "belief_walk_keys: n must be the length of the last walk");
         HIPCHK(hipSetDevice(device_));
         int rc = keys_tmp_.ensure((size_t)n * sizeof(uint64_t), &bytes_);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_row_bit_sums, dim3((unsigned)n), dim3(256), 0, stream_, walk64_.as<double>() + S_, S_,
+        hipLaunchKernelGGL(k_row_hash<double>, dim3((unsigned)n), dim3(256), 0, stream_, walk64_.as<double>() + S_, S_, S_,
                            keys_tmp_.as<unsigned long long>());
         HIPCHK(hipGetLastError());
         if ((rc = out_begin())) return rc;

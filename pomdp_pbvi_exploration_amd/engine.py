@@ -869,7 +869,7 @@ class Engine:
         return out, first
 
     def belief_walk_keys(self, n: int) -> np.ndarray:
-        """``[n]`` uint64: bit-pattern sums of the fp64 rows of the last ``belief_walk`` (what ``_RowKey`` computes on
+        """``[n]`` uint64: position-weighted bit-pattern hashes of the fp64 rows of the last ``belief_walk`` (what ``_RowKey`` computes on
         the host), from the device."""
         keys = np.empty(n, dtype=np.uint64)
         _check(self._lib.pbvi_belief_walk_keys(self._h, n, keys.ctypes.data_as(C.POINTER(C.c_uint64))))

@@ -278,32 +278,46 @@ class Model:
         return self._engine
 
 
+_HASH_WEIGHTS = {}
+
+
+def _row_hash(row) -> int:
+    """``sum_i bits_i * (2 i + 1) mod 2^64`` over the fp32 / fp64 bit patterns of a 1-D row: the number the dedup keys of
+    the belief and alpha-vector containers hash by.  The HIP engine computes the same number for rows it produced
+    (``k_row_hash``: ``pbvi_backup_fetch_row_hashes``, ``pbvi_belief_walk_keys``).  Position-weighted, so shifted copies of
+    a row do not collide."""
+    a = np.ascontiguousarray(row)
+    if a.dtype.itemsize not in (4, 8) or a.ndim != 1:
+        return hash(a.tobytes()) & 0xFFFFFFFFFFFFFFFF
+    bits = a.view(np.uint32 if a.dtype.itemsize == 4 else np.uint64)
+    w = _HASH_WEIGHTS.get(bits.shape[0])
+    if w is None:
+        w = _HASH_WEIGHTS[bits.shape[0]] = np.arange(bits.shape[0], dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    with np.errstate(over='ignore'):
+        return int(np.dot(bits.astype(np.uint64, copy=False), w))          # integer dot: wraps modulo 2^64 like the device sum
+
+
 class _RowKey(int):
     """Dictionary key with the semantics of the row's bytes (the reference keys its dedup dictionaries on
     ``values.tobytes()``, ``src/mdp.py:660-669``, ``src/pomdp.py:562-571``) without copying and hashing a quarter of
-    a megabyte per row: the key IS an integer -- the wrapping sum of the row's bit patterns, one single-threaded pass,
-    equal bytes give equal sums -- so dictionaries hash it at C speed, and equality compares the bytes, which only
-    happens when two keys carry the same sum, i.e. practically only for equal rows.  Used by the belief containers;
-    the alpha-vector container uses ``_AlphaKey`` (a position-weighted sum): the plain sum is permutation-invariant and
-    a solve's alpha-vectors are largely shifted copies of one another (wrap-around grid), so their sums collide -- 400
-    byte comparisons per ``extend`` when tried."""
+    a megabyte per row: the key IS an integer -- ``_row_hash``, one single-threaded pass, equal bytes give equal numbers --
+    so dictionaries hash it at C speed, and equality compares the bytes, which only happens when two keys carry the same
+    number, i.e. practically only for equal rows.  (A plain sum of the bit patterns was used first: a walk's successive
+    beliefs and a solve's alpha-vectors are largely shifted copies of one another on a wrap-around grid, so sums collide --
+    8 000 byte comparisons of 240 KB rows in a 300-expansion solve; the position weights end that.)  Used by the belief
+    containers; ``_AlphaKey`` is the same for alpha-vector rows."""
 
     def __new__(cls, row):
         if isinstance(row, int):                            # copy / pickle rebuild: the row comes back through __dict__
             return int.__new__(cls, row)
-        size = row.dtype.itemsize
-        if size in (4, 8):                                  # one hash function per item size, whatever the strides
-            bits = np.ascontiguousarray(row).view(np.uint64 if size == 8 else np.uint32)
-            h = int(np.add.reduce(bits, dtype=np.uint64))
-        else:
-            h = hash(row.tobytes())
+        h = _row_hash(row)
         self = int.__new__(cls, h)
         self.row = row
         return self
 
     @classmethod
     def from_sum(cls, bit_sum: int, row) -> '_RowKey':
-        """Key of ``row`` whose bit-pattern sum is already known (the engine computes it for rows it produced)."""
+        """Key of ``row`` whose ``_row_hash`` is already known (the engine computes it for rows it produced)."""
         self = int.__new__(cls, bit_sum)
         self.row = row
         return self
@@ -326,26 +340,14 @@ class _AlphaKey(int):
     i.e. practically only for equal rows.  For rows the engine produced the number comes from the device
     (``pbvi_backup_fetch_row_hashes``); here it costs one pass instead of a 120-240 KB copy plus a byte hash."""
 
-    _weights = {}
-
     def __new__(cls, row):
         if isinstance(row, int):                            # copy / pickle rebuild: the row comes back through __dict__
             return int.__new__(cls, row)
-        self = int.__new__(cls, cls.hash_of(row))
+        self = int.__new__(cls, _row_hash(row))
         self.row = row
         return self
 
-    @classmethod
-    def hash_of(cls, row) -> int:
-        a = np.ascontiguousarray(row)
-        if a.dtype.itemsize not in (4, 8) or a.ndim != 1:
-            return hash(a.tobytes()) & 0xFFFFFFFFFFFFFFFF
-        bits = a.view(np.uint32 if a.dtype.itemsize == 4 else np.uint64)
-        w = cls._weights.get(bits.shape[0])
-        if w is None:
-            w = cls._weights[bits.shape[0]] = np.arange(bits.shape[0], dtype=np.uint64) * np.uint64(2) + np.uint64(1)
-        with np.errstate(over='ignore'):
-            return int(np.dot(bits.astype(np.uint64, copy=False), w))      # integer dot: wraps modulo 2^64 like the device sum
+    hash_of = staticmethod(_row_hash)
 
     @classmethod
     def from_hash(cls, h: int, row) -> '_AlphaKey':
