@@ -1758,7 +1758,9 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
         sv->tiles_m = plan_.tiles_m;
         sv->fixed = 0;
     } else {
-        if ((rc = slabs_.ensure((size_t)m_rows * rows_y * sizeof(T), &bytes_))) return rc;
+        const int kt32s = S_pad_ / GEMM_BK;
+        const int split = f64_uses_mfma(m_rows, rows_y) ? gemm_f64_split((int)m_rows, (int)rows_y, kt32s) : 1;
+        if ((rc = slabs_.ensure((size_t)split * m_rows * rows_y * sizeof(T), &bytes_))) return rc;
         f64_pairs_ = 0;
         if (!f64_uses_mfma(m_rows, rows_y)) {
             HIPCHK(launch_gemm_nt_simple<T>(X, S_pad_, Y, S_pad_, slabs_.as<T>(), (int)rows_y, (int)m_rows, (int)rows_y,
@@ -1769,15 +1771,15 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
             if ((rc = kcount_.ensure(gemm_f64_kcount_ints((int)m_rows, (int)rows_y, kt32) * sizeof(int), &bytes_))) return rc;
             HIPCHK(launch_gemm_nt_f64((const double*)X, S_pad_, (int)m_rows, (const double*)Y, S_pad_, (int)rows_y,
                                       slabs_.as<double>(), (int)rows_y, S_pad_, nzX, nzB, G, v_group, klist_.as<int>(),
-                                      kcount_.as<int>(), stream_));
+                                      kcount_.as<int>(), stream_, split, m_rows * rows_y));
             f64_pairs_ = (int64_t)gemm_f64_pairs((int)m_rows, (int)rows_y);
         }
         sv->slabs = slabs_.as<T>();
-        sv->slab_stride = 0;
+        sv->slab_stride = m_rows * rows_y;
         sv->ldc = (int)rows_y;
         sv->nchunks = nullptr;
         sv->tiles_m = 0;
-        sv->fixed = 1;
+        sv->fixed = split;
     }
     return PBVI_OK;
 }

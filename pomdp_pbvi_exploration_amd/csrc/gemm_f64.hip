@@ -4,10 +4,13 @@
 // windows or refinement -- only speed.  Differences from the f32 kernel (gemm.hip), all because the f64 MFMA is
 // four times slower per byte of operand: 128 x 128 x 16 tiles (64 KiB of LDS per block, two blocks per CU),
 // plain global -> register -> LDS staging (LDS bandwidth is nowhere near the bound: 32 ds_read_b64 per 64 MFMAs
-// of 64 cycles each), one block per tile pair with the whole K list (no split-K slabs), zero-tile lists derived
-// from the same 32-state maps the f32 path uses.
+// of 64 cycles each), zero-tile lists derived from the same 32-state maps the f32 path uses.  One block per
+// (tile pair, K split): a grid of fewer pairs than the chip has block slots (the solve loop's skinny GEMMs: 100 new
+// beliefs x 10^4 alpha rows = 79 pairs, each walking several hundred K tiles) is split along K into `split` equal
+// parts of every pair's list, one partial slab per part, summed in fixed order by the readers (SlabView::at).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -26,9 +29,11 @@ constexpr int D_LD = D_BK + 2;          // LDS row stride in doubles: 144 B keep
 //   nzB [G+1][kt32]          per row group of B (rows [g*v_group, (g+1)*v_group)); rows >= G*v_group may touch any
 //                            group or the extra row nzB[G]; nullptr = dense
 __global__ void k_build_klists_f64(const uint8_t* __restrict__ nzA, const uint8_t* __restrict__ nzB, int G, int v_group,
-                                   int n_rows, int tiles_m, int kt32, int* __restrict__ klist, int* __restrict__ kcount) {
-    __shared__ int wcount[4];
-    __shared__ int total;
+                                   int n_rows, int tiles_m, int kt32, int* __restrict__ klist, int* __restrict__ kcount,
+                                   int split, int* __restrict__ kpart /* [pairs][split + 1] list offsets of the K parts */) {
+    __shared__ int wcount[4], wcount_a[4];
+    __shared__ int total, total_a, n_a;
+    __shared__ int part_start[33];
     const int pair = blockIdx.x;
     const int tm = pair % tiles_m, tn = pair / tiles_m;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -45,48 +50,99 @@ __global__ void k_build_klists_f64(const uint8_t* __restrict__ nzA, const uint8_
             g1 = r1 / v_group;
         }
     }
-    if (tid == 0) total = 0;
+    const uint8_t* za = nzA ? nzA + (int64_t)(tm * D_BM / 256) * kt32 : nullptr;
+    // K parts: boundaries from the support of the A ROW BLOCK alone (its non-zero tiles dealt evenly over the parts), so
+    // every column of a row -- whichever column tile it sits in -- is summed in the same association: identical B rows
+    // keep bit-identical scores and ties keep going to the lower index.
+    if (tid == 0) {
+        total = 0;
+        total_a = 0;
+        n_a = 0;
+    }
+    if (tid <= split) part_start[tid] = 0x7fffffff;
     __syncthreads();
+    if (split > 1) {
+        int c = 0;
+        for (int kt = tid; kt < kt32; kt += 256) c += za ? (za[kt] != 0) : 1;
+        atomicAdd(&n_a, c);
+        __syncthreads();
+    }
+    const int na = n_a > 0 ? n_a : 1;
     for (int base = 0; base < kt32; base += 256) {
         const int kt = base + tid;
-        int f = 0;
-        if (kt < kt32 && r0 < n_rows && (nzA == nullptr || nzA[(int64_t)(tm * D_BM / 256) * kt32 + kt])) {
+        int f = 0, fa = 0;
+        if (kt < kt32) fa = za ? (za[kt] != 0) : 1;
+        if (fa && r0 < n_rows) {
             if (nzB == nullptr) {
                 f = 1;
             } else {
                 for (int g = g0; g <= g1; ++g) f |= nzB[(int64_t)g * kt32 + kt];
             }
         }
-        const unsigned long long mask = __ballot(f);
-        if (lane == 0) wcount[wid] = __popcll(mask);
+        const unsigned long long mask = __ballot(f), mask_a = __ballot(fa);
+        if (lane == 0) {
+            wcount[wid] = __popcll(mask);
+            wcount_a[wid] = __popcll(mask_a);
+        }
         __syncthreads();
-        int off = total;
-        for (int w = 0; w < wid; ++w) off += wcount[w];
-        if (f) klist[(int64_t)pair * kt32 + off + __popcll(mask & ((1ull << lane) - 1ull))] = kt;
+        int off = total, off_a = total_a;
+        for (int w = 0; w < wid; ++w) {
+            off += wcount[w];
+            off_a += wcount_a[w];
+        }
+        if (f) {
+            const int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+            klist[(int64_t)pair * kt32 + pos] = kt;
+            if (split > 1) {
+                const int rank_a = off_a + __popcll(mask_a & ((1ull << lane) - 1ull));     // A-non-zero tiles before kt
+                atomicMin(&part_start[(int)((int64_t)rank_a * split / na)], pos);
+            }
+        }
         __syncthreads();
-        if (tid == 0) total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        if (tid == 0) {
+            total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+            total_a += wcount_a[0] + wcount_a[1] + wcount_a[2] + wcount_a[3];
+        }
         __syncthreads();
     }
-    if (tid == 0) kcount[pair] = total;
+    if (tid == 0) {
+        kcount[pair] = total;
+        if (split > 1) {      // empty parts start where the next non-empty one does
+            int nxt = total;
+            kpart[(int64_t)pair * (split + 1) + split] = total;
+            for (int z = split - 1; z >= 0; --z) {
+                if (part_start[z] != 0x7fffffff) nxt = part_start[z];
+                kpart[(int64_t)pair * (split + 1) + z] = nxt;
+            }
+        }
+    }
 }
 
 // Longest lists first: blocks are dispatched in index order, so handing out the heavy tile pairs first leaves the
 // light ones to fill the tail (LPT scheduling).  One block; counting sort by list length (<= kt32), stable.
 __global__ void k_order_pairs_f64(const int* __restrict__ kcount, int pairs, int kt32, int* __restrict__ hist /* [kt32+2] zeroed */,
                                   int* __restrict__ order) {
+    constexpr int LBINS = 4096;
+    __shared__ int lhist[LBINS];
     const int tid = threadIdx.x;
-    for (int p = tid; p < pairs; p += blockDim.x) atomicAdd(&hist[kt32 - kcount[p]], 1);      // bin 0 = longest
+    int* h = hist;
+    if (kt32 + 1 <= LBINS) {                              // the histogram in LDS: the lengths cluster, and global atomics
+        for (int b = tid; b <= kt32; b += blockDim.x) lhist[b] = 0;      // on a handful of addresses serialise
+        h = lhist;
+        __syncthreads();
+    }
+    for (int p = tid; p < pairs; p += blockDim.x) atomicAdd(&h[kt32 - kcount[p]], 1);      // bin 0 = longest
     __syncthreads();
     if (tid == 0) {
         int run = 0;
         for (int b = 0; b <= kt32; ++b) {
-            const int c = hist[b];
-            hist[b] = run;
+            const int c = h[b];
+            h[b] = run;
             run += c;
         }
     }
     __syncthreads();
-    for (int p = tid; p < pairs; p += blockDim.x) order[atomicAdd(&hist[kt32 - kcount[p]], 1)] = p;
+    for (int p = tid; p < pairs; p += blockDim.x) order[atomicAdd(&h[kt32 - kcount[p]], 1)] = p;
 }
 
 // non-zero map of a double matrix at the f32 path's granularity: nz[row block of 256][32-column tile]
@@ -125,17 +181,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64_mfma(const double* __res
                                                              double* __restrict__ C, int ldc, int tiles_m,
                                                              const int* __restrict__ klist,
                                                              const int* __restrict__ kcount, int kt32,
-                                                             const int* __restrict__ order) {
+                                                             const int* __restrict__ order, int split,
+                                                             int64_t slab_stride, const int* __restrict__ kpart) {
     extern __shared__ double lds_f64[];                    // [2][128 * D_LD] A then [2][128 * D_LD] B: 72 KiB (dynamic:
     double (*As)[D_BM * D_LD] = reinterpret_cast<double (*)[D_BM * D_LD]>(lds_f64);                 // above the 64 KiB
     double (*Bs)[D_BN * D_LD] = reinterpret_cast<double (*)[D_BN * D_LD]>(lds_f64 + 2 * D_BM * D_LD);   // static limit)
-    const int pair = order ? order[blockIdx.x] : (int)blockIdx.x;
+    const int pidx = (int)blockIdx.x / split, z = (int)blockIdx.x - pidx * split;
+    const int pair = order ? order[pidx] : pidx;
     const int tm = pair % tiles_m, tn = pair / tiles_m;
     const int m0 = tm * D_BM, n0 = tn * D_BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;                 // 2 x 2 waves, 64 x 64 each
-    const int* kl = klist + (int64_t)pair * kt32;
-    const int nsteps = kcount[pair] * 2;                   // 16-column steps
+    const int k_begin = split > 1 ? kpart[(int64_t)pair * (split + 1) + z] : 0;
+    const int k_end = split > 1 ? kpart[(int64_t)pair * (split + 1) + z + 1] : kcount[pair];
+    const int* kl = klist + (int64_t)pair * kt32 + k_begin;
+    const int nsteps = (k_end - k_begin) * 2;              // 16-column steps (an empty part writes zeros)
+    C += (int64_t)z * slab_stride;
 
     // staging: instruction c of thread t moves 16 bytes of row c*32 + t/8, column chunk t%8 -- a wave instruction
     // covers eight whole 128-byte row segments (full cache lines)
@@ -228,15 +289,26 @@ hipError_t launch_tile_nonzero_f64(const double* X, int ld, int rows, int kt32, 
 size_t gemm_f64_klist_ints(int M, int N, int kt32) {
     return (size_t)((M + D_BM - 1) / D_BM) * ((N + D_BN - 1) / D_BN) * kt32;
 }
-// kcount workspace: [pairs] list lengths, [pairs] dispatch order, [kt32 + 2] histogram
 size_t gemm_f64_pairs(int M, int N) { return (size_t)((M + D_BM - 1) / D_BM) * ((N + D_BN - 1) / D_BN); }
-size_t gemm_f64_kcount_ints(int M, int N, int kt32) { return 2 * gemm_f64_pairs(M, N) + (size_t)kt32 + 2; }
+// kcount workspace: [pairs] list lengths, [pairs] dispatch order, [kt32 + 2] histogram, [pairs][33] K-part offsets
+size_t gemm_f64_kcount_ints(int M, int N, int kt32) { return 35 * gemm_f64_pairs(M, N) + (size_t)kt32 + 2; }
+// K split of a score GEMM: enough blocks for two per CU, parts of at least ~8 listed tiles when the lists are full
+int gemm_f64_split(int M, int N, int kt32) {
+    static const int forced = getenv("PBVI_F64_SPLIT") ? atoi(getenv("PBVI_F64_SPLIT")) : 0;      // debug / A-B only
+    if (forced > 0) return forced;
+    const int64_t pairs = (int64_t)gemm_f64_pairs(M, N);
+    if (pairs <= 0 || pairs >= 384) return 1;
+    int64_t z = (512 + pairs - 1) / pairs;
+    z = std::min<int64_t>(z, std::max(1, kt32 / 8));
+    return (int)std::min<int64_t>(z, 32);
+}
 
 template <typename TB>
 static hipError_t launch_gemm_nt_f64_t(const double* A, int lda, int M, const TB* B, int ldb, int N, double* C, int ldc,
                                        int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
-                                       int* kcount, hipStream_t stream) {
+                                       int* kcount, hipStream_t stream, int split, int64_t slab_stride) {
     if (M <= 0 || N <= 0) return hipSuccess;
+    if (split < 1 || split > 32 || (split > 1 && slab_stride < (int64_t)M * ldc)) return hipErrorInvalidValue;
     if (K_pad % 32 != 0) return hipErrorInvalidValue;
     const int kt32 = K_pad / 32;
     const int tiles_m = (M + D_BM - 1) / D_BM, tiles_n = (N + D_BN - 1) / D_BN;
@@ -244,7 +316,8 @@ static hipError_t launch_gemm_nt_f64_t(const double* A, int lda, int M, const TB
     if (pairs > 0x7fffffff) return hipErrorInvalidValue;
     const int force_dense = gemm_force_dense();          // benchmark / debug: every tile listed
     hipLaunchKernelGGL(k_build_klists_f64, dim3((unsigned)pairs), dim3(256), 0, stream, force_dense ? nullptr : nzA,
-                       force_dense ? nullptr : nzB, G, v_group, N, tiles_m, kt32, klist, kcount);
+                       force_dense ? nullptr : nzB, G, v_group, N, tiles_m, kt32, klist, kcount, split,
+                       kcount + 2 * pairs + kt32 + 2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     constexpr size_t lds_bytes = (size_t)2 * (D_BM + D_BN) * D_LD * sizeof(double);
@@ -259,20 +332,22 @@ static hipError_t launch_gemm_nt_f64_t(const double* A, int lda, int M, const TB
     if ((e = hipMemsetAsync(hist, 0, (size_t)(kt32 + 2) * sizeof(int), stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_order_pairs_f64, dim3(1), dim3(1024), 0, stream, kcount, (int)pairs, kt32, hist, order);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_gemm_nt_f64_mfma<TB>, dim3((unsigned)pairs), dim3(256), lds_bytes, stream, A, lda, M, B, ldb, N, C,
-                       ldc, tiles_m, klist, kcount, kt32, order);
+    if (pairs * split > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_gemm_nt_f64_mfma<TB>, dim3((unsigned)(pairs * split)), dim3(256), lds_bytes, stream, A, lda, M, B, ldb,
+                       N, C, ldc, tiles_m, klist, kcount, kt32, order, split, slab_stride, kcount + 2 * pairs + kt32 + 2);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,
                               int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
-                              int* kcount, hipStream_t stream) {
-    return launch_gemm_nt_f64_t<double>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nzB, G, v_group, klist, kcount, stream);
+                              int* kcount, hipStream_t stream, int split, int64_t slab_stride) {
+    return launch_gemm_nt_f64_t<double>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nzB, G, v_group, klist, kcount, stream, split,
+                                        slab_stride);
 }
 
 hipError_t launch_gemm_nt_f64_bf32(const double* A, int lda, int M, const float* B, int ldb, int N, double* C, int ldc,
                                    int K_pad, const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream) {
-    return launch_gemm_nt_f64_t<float>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nullptr, 1, N, klist, kcount, stream);
+    return launch_gemm_nt_f64_t<float>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nullptr, 1, N, klist, kcount, stream, 1, 0);
 }
 
 }  // namespace pbvi

@@ -472,6 +472,9 @@ def test_value_max_over_the_belief_store_in_place(monkeypatch):
     beliefs = synth.belief_points(m, 700, max_depth=24)
     want = orc.max_value_per_belief(alpha.astype(np.float64), beliefs.astype(np.float64))
     for dtype in ('f32', 'f64'):
+        # f32 engines re-score every belief on its own (bit-identical whatever block it rides in); the fp64 GEMM splits K
+        # by the shape of its grid, so launches of different shapes agree to summation order (a few ulps), indices exactly
+        same = np.array_equal if dtype == 'f32' else (lambda a, b: np.allclose(a, b, rtol=1e-14, atol=0.0))
         eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype)
         eng.store_rows('alpha', alpha)
         eng.select_alpha(np.arange(len(alpha)))
@@ -483,24 +486,24 @@ def test_value_max_over_the_belief_store_in_place(monkeypatch):
             assert len(val) == upto
             eng.select_beliefs(np.arange(upto))
             v2, i2 = eng.max_value_resident()
-            assert np.array_equal(val, v2) and np.array_equal(idx, i2)
+            assert same(val, v2) and np.array_equal(idx, i2)
             np.testing.assert_allclose(val, want[:upto], rtol=1e-12 if dtype == 'f64' else 1e-7)
             assert not np.any(idx == 7)
         v_part, _ = eng.max_value_store(513)
-        assert np.array_equal(v_part, val[:513])
+        assert same(v_part, val[:513])
         # the resident block survives the store scan untouched
         v3, i3 = eng.max_value_resident()
-        assert np.array_equal(v3, v2) and np.array_equal(i3, i2)
+        assert same(v3, v2) and np.array_equal(i3, i2)
         # Engine.max_value_objects takes the store path for large belief sets
         monkeypatch.setattr(Engine, '_STORE_SCAN_MIN', 64)
         ids = np.arange(700, dtype=np.int32)[::2]
         got = eng._vmax_block(np.arange(len(alpha), dtype=np.int32), ids)
-        assert np.array_equal(got, val[ids])
+        assert same(got, val[ids])
         monkeypatch.undo()
         eng.reset_store('belief')
         eng.store_rows('belief', beliefs[5:9])
         v4, _ = eng.max_value_store()
-        assert np.array_equal(v4, val[5:9])
+        assert same(v4, val[5:9])
         with pytest.raises(ValueError):
             eng.max_value_store(5)
         eng.close()
