@@ -460,7 +460,11 @@ class ValueFunction:
     def extend(self, other: 'ValueFunction') -> None:
         mine, theirs = self._uniqueness_dict, other._uniqueness_dict
         # device store ids of the result (Engine.row_ids caches them per container): this set's rows keep their
-        # slots -- an object replaced on equal bytes names an equal row -- then the other's rows that are new
+        # slots, then the other's rows that are new.  A slot whose bytes the other set has too is taken over by the
+        # other's object (dict.update) AND by its store id: the two store rows are equal, and with the older id the id set
+        # of a solve's value function only ever grows -- Engine.max_value_objects extends a cached maximum over a SUBSET
+        # of ids; with the newer id every such repeat sent compute_change back to scoring all beliefs x all rows
+        # (two 0.1 s GEMMs in the 300-expansion run).
         carried = None
         a, b = getattr(self, '_dev_ids', None), getattr(other, '_dev_ids', None)
         if a is None and len(mine) and all(hasattr(v, '_dev') for v in mine.values()):
@@ -469,7 +473,14 @@ class ValueFunction:
                 a = (tag, np.fromiter((v._dev[1] for v in mine.values()), dtype=np.int32, count=len(mine)))
         if a is not None and b is not None and a[0] == b[0] and len(a[1]) == len(mine) and len(b[1]) == len(theirs):
             fresh = np.fromiter((k not in mine for k in theirs), dtype=bool, count=len(theirs))
-            carried = (a[0], np.concatenate([a[1], b[1][fresh]]))
+            ids_mine = a[1]
+            if not fresh.all():
+                slot_of = {k: i for i, k in enumerate(mine)}
+                ids_mine = ids_mine.copy()
+                for j, k in enumerate(theirs):
+                    if not fresh[j]:
+                        ids_mine[slot_of[k]] = b[1][j]
+            carried = (a[0], np.concatenate([ids_mine, b[1][fresh]]))
         mine.update(theirs)
         self._vector_list = list(mine.values())
         self._dev_ids = carried

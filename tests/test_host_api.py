@@ -405,6 +405,8 @@ def test_store_ids_travel_with_the_containers():
     walked = [v._dev[1] for v in new.alpha_vector_list]          # the objects' own tags (old object took the repeated slot)
     assert [eng.rows['alpha'][i].tobytes() for i in new._dev_ids[1]] == [v.values.tobytes() for v in new.alpha_vector_list]
     assert sorted(walked) == sorted(set(walked)) and len(set(new._dev_ids[1].tolist())) == 8
+    assert list(new._dev_ids[1]) == walked                       # the carried array says what the objects say ...
+    assert set(ids_old.tolist()) <= set(new._dev_ids[1].tolist())     # ... and the id set only grows (old id 3 kept, new id 8 unused)
     assert eng.row_ids('alpha', new.alpha_vector_list, lambda v: v.values, owner=new) is new._dev_ids[1]
     new.append(AlphaVector(rng.normal(size=S), 0))               # any other change drops the cache
     assert new._dev_ids is None
