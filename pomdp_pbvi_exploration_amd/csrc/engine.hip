@@ -2380,7 +2380,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         } else if (f64_pairs > 0) {   // fp64 MFMA path: 128 x 128 tiles, lists in 32-column steps
             int64_t kt_sum = 0;
             for (int c : h_kcount) kt_sum += c;
-            st->score_flops_executed = kt_sum * 2LL * 128 * 128 * 32;
+            st->score_flops_executed = kt_sum * 2LL * 128 * gemm_f64_bn((int)std::min<int64_t>(use_push ? V_ : N, 0x7fffffff)) * 32;
             st->score_tiles_dense = f64_pairs * (S_pad_ / GEMM_BK);
             st->score_tiles_run = kt_sum;
             st->split_k = 1;

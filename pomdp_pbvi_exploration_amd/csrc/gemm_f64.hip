@@ -30,15 +30,16 @@ constexpr int D_LD = D_BK + 2;          // LDS row stride in doubles: 144 B keep
 //                            group or the extra row nzB[G]; nullptr = dense
 __global__ void k_build_klists_f64(const uint8_t* __restrict__ nzA, const uint8_t* __restrict__ nzB, int G, int v_group,
                                    int n_rows, int tiles_m, int kt32, int* __restrict__ klist, int* __restrict__ kcount,
-                                   int split, int* __restrict__ kpart /* [pairs][split + 1] list offsets of the K parts */) {
+                                   int split, int* __restrict__ kpart /* [pairs][split + 1] list offsets of the K parts */,
+                                   int bn /* rows of B per column tile */) {
     __shared__ int wcount[4], wcount_a[4];
     __shared__ int total, total_a, n_a;
     __shared__ int part_start[33];
     const int pair = blockIdx.x;
     const int tm = pair % tiles_m, tn = pair / tiles_m;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r0 = tn * D_BN;
-    int r1 = r0 + D_BN - 1;
+    const int r0 = tn * bn;
+    int r1 = r0 + bn - 1;
     if (r1 >= n_rows) r1 = n_rows - 1;
     int g0 = 0, g1 = -1;
     if (nzB != nullptr && G > 0 && r0 < n_rows) {
@@ -174,24 +175,35 @@ __device__ __forceinline__ f64x2 load2(const float* p) {
 }
 
 // TB: element type of B (double, or float widened on the way into LDS -- exact -- for the refinement's re-scoring
-// of fp32 alpha rows against fp64 weights)
-template <typename TB>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_f64_mfma(const double* __restrict__ A, int lda, int M,
-                                                             const TB* __restrict__ B, int ldb, int N,
-                                                             double* __restrict__ C, int ldc, int tiles_m,
-                                                             const int* __restrict__ klist,
-                                                             const int* __restrict__ kcount, int kt32,
-                                                             const int* __restrict__ order, int split,
-                                                             int64_t slab_stride, const int* __restrict__ kpart) {
-    extern __shared__ double lds_f64[];                    // [2][128 * D_LD] A then [2][128 * D_LD] B: 72 KiB (dynamic:
-    double (*As)[D_BM * D_LD] = reinterpret_cast<double (*)[D_BM * D_LD]>(lds_f64);                 // above the 64 KiB
-    double (*Bs)[D_BN * D_LD] = reinterpret_cast<double (*)[D_BN * D_LD]>(lds_f64 + 2 * D_BM * D_LD);   // static limit)
+// of fp32 alpha rows against fp64 weights).
+// BN: rows of B per block.  128 for score GEMMs proper; 64 / 32 for the solve loop's skinny ones (compute_change scores
+// the whole belief store against the few dozen alpha rows an expansion added: with a 128-wide tile three quarters of
+// the MFMA work is padding and the kernel is MFMA-bound on it; with 32 columns the same launch is a streaming read of
+// the store).  Waves: 2 x 2 of 64 x 64 (BN = 128), 4 x 1 of 32 x BN otherwise.
+template <int BN>
+struct F64Tile {
+    static constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN;
+    static constexpr int MI = D_BM / WM / 16, NJ = BN / WN / 16;
+    static constexpr int BCH = BN / 32;                    // staging chunks of B per thread (A: 4)
+    static constexpr size_t lds_bytes = (size_t)2 * (D_BM + BN) * D_LD * sizeof(double);
+    static constexpr int min_blocks = BN == 32 ? 3 : 2;    // per CU: the skinny tile hides load latency with occupancy
+};
+
+template <typename TB, int BN>
+__global__ __launch_bounds__(256, F64Tile<BN>::min_blocks) void k_gemm_nt_f64_mfma(
+    const double* __restrict__ A, int lda, int M, const TB* __restrict__ B, int ldb, int N, double* __restrict__ C, int ldc,
+    int tiles_m, const int* __restrict__ klist, const int* __restrict__ kcount, int kt32, const int* __restrict__ order,
+    int split, int64_t slab_stride, const int* __restrict__ kpart) {
+    using TL = F64Tile<BN>;
+    extern __shared__ double lds_f64[];                    // [2][128 * D_LD] A then [2][BN * D_LD] B: 72 KiB at BN = 128
+    double (*As)[D_BM * D_LD] = reinterpret_cast<double (*)[D_BM * D_LD]>(lds_f64);       // (dynamic: above the 64 KiB
+    double (*Bs)[BN * D_LD] = reinterpret_cast<double (*)[BN * D_LD]>(lds_f64 + 2 * D_BM * D_LD);   // static limit)
     const int pidx = (int)blockIdx.x / split, z = (int)blockIdx.x - pidx * split;
     const int pair = order ? order[pidx] : pidx;
     const int tm = pair % tiles_m, tn = pair / tiles_m;
-    const int m0 = tm * D_BM, n0 = tn * D_BN;
+    const int m0 = tm * D_BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;                 // 2 x 2 waves, 64 x 64 each
+    const int wm = wid / TL::WN, wn = wid % TL::WN;
     const int k_begin = split > 1 ? kpart[(int64_t)pair * (split + 1) + z] : 0;
     const int k_end = split > 1 ? kpart[(int64_t)pair * (split + 1) + z + 1] : kcount[pair];
     const int* kl = klist + (int64_t)pair * kt32 + k_begin;
@@ -202,39 +214,41 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64_mfma(const double* __res
     // covers eight whole 128-byte row segments (full cache lines)
     const int srow = tid >> 3, scol = (tid & 7) * 2;
     const double* ap[4];
-    const TB* bp[4];
-    bool a_ok[4], b_ok[4];
+    const TB* bp[TL::BCH];
+    bool a_ok[4], b_ok[TL::BCH];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int r = c * 32 + srow;
         a_ok[c] = m0 + r < M;
-        b_ok[c] = n0 + r < N;
         ap[c] = A + (int64_t)(a_ok[c] ? m0 + r : 0) * lda + scol;
+    }
+#pragma unroll
+    for (int c = 0; c < TL::BCH; ++c) {
+        const int r = c * 32 + srow;
+        b_ok[c] = n0 + r < N;
         bp[c] = B + (int64_t)(b_ok[c] ? n0 + r : 0) * ldb + scol;
     }
-    f64x2 ra[4], rb[4];
+    f64x2 ra[4], rb[TL::BCH];
     auto fetch = [&](int step) {
         const int k0 = kl[step >> 1] * 32 + (step & 1) * D_BK;
-        const f64x2 z = {0.0, 0.0};
+        const f64x2 zz = {0.0, 0.0};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            ra[c] = a_ok[c] ? *(const f64x2*)(ap[c] + k0) : z;
-            rb[c] = b_ok[c] ? load2(bp[c] + k0) : z;
-        }
+        for (int c = 0; c < 4; ++c) ra[c] = a_ok[c] ? *(const f64x2*)(ap[c] + k0) : zz;
+#pragma unroll
+        for (int c = 0; c < TL::BCH; ++c) rb[c] = b_ok[c] ? load2(bp[c] + k0) : zz;
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            *(f64x2*)(&As[buf][(c * 32 + srow) * D_LD + scol]) = ra[c];
-            *(f64x2*)(&Bs[buf][(c * 32 + srow) * D_LD + scol]) = rb[c];
-        }
+        for (int c = 0; c < 4; ++c) *(f64x2*)(&As[buf][(c * 32 + srow) * D_LD + scol]) = ra[c];
+#pragma unroll
+        for (int c = 0; c < TL::BCH; ++c) *(f64x2*)(&Bs[buf][(c * 32 + srow) * D_LD + scol]) = rb[c];
     };
 
-    f64x4 acc[4][4];
+    f64x4 acc[TL::MI][TL::NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TL::MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < TL::NJ; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     if (nsteps > 0) {
         fetch(0);
@@ -246,20 +260,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64_mfma(const double* __res
         const int buf = step & 1;
         const bool more = step + 1 < nsteps;
         if (more) fetch(step + 1);                         // global loads fly under the MFMAs
-        const double* as = &As[buf][(wm * 64 + fr) * D_LD + fk];
-        const double* bs = &Bs[buf][(wn * 64 + fr) * D_LD + fk];
+        const double* as = &As[buf][(wm * (TL::MI * 16) + fr) * D_LD + fk];
+        const double* bs = &Bs[buf][(wn * (TL::NJ * 16) + fr) * D_LD + fk];
 #pragma unroll
         for (int ks = 0; ks < D_BK / 4; ++ks) {
-            double a[4], b[4];
+            double a[TL::MI], b[TL::NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = as[i * 16 * D_LD + ks * 4];
-                b[i] = bs[i * 16 * D_LD + ks * 4];
-            }
+            for (int i = 0; i < TL::MI; ++i) a[i] = as[i * 16 * D_LD + ks * 4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < TL::NJ; ++j) b[j] = bs[j * 16 * D_LD + ks * 4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < TL::MI; ++i)
+#pragma unroll
+                for (int j = 0; j < TL::NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (more) stash(buf ^ 1);                          // the other buffer was last read one barrier ago
@@ -267,13 +280,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f64_mfma(const double* __res
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TL::MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+        for (int j = 0; j < TL::NJ; ++j) {
+            const int col = n0 + wn * (TL::NJ * 16) + j * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r;
+                const int row = m0 + wm * (TL::MI * 16) + i * 16 + (lane >> 4) + 4 * r;
                 if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[i][j][r];
             }
         }
@@ -286,10 +299,17 @@ hipError_t launch_tile_nonzero_f64(const double* X, int ld, int rows, int kt32, 
     return hipGetLastError();
 }
 
-size_t gemm_f64_klist_ints(int M, int N, int kt32) {
-    return (size_t)((M + D_BM - 1) / D_BM) * ((N + D_BN - 1) / D_BN) * kt32;
+// column-tile width of a GEMM with N rows of B
+int gemm_f64_bn(int N) {
+    static const int forced = getenv("PBVI_F64_BN") ? atoi(getenv("PBVI_F64_BN")) : 0;      // debug / A-B only: 32, 64, 128
+    if (forced == 32 || forced == 64 || forced == 128) return forced;
+    return N <= 32 ? 32 : (N <= 64 ? 64 : D_BN);
 }
-size_t gemm_f64_pairs(int M, int N) { return (size_t)((M + D_BM - 1) / D_BM) * ((N + D_BN - 1) / D_BN); }
+size_t gemm_f64_pairs(int M, int N) {
+    const int bn = gemm_f64_bn(N);
+    return (size_t)((M + D_BM - 1) / D_BM) * ((N + bn - 1) / bn);
+}
+size_t gemm_f64_klist_ints(int M, int N, int kt32) { return gemm_f64_pairs(M, N) * kt32; }
 // kcount workspace: [pairs] list lengths, [pairs] dispatch order, [kt32 + 2] histogram, [pairs][33] K-part offsets
 size_t gemm_f64_kcount_ints(int M, int N, int kt32) { return 35 * gemm_f64_pairs(M, N) + (size_t)kt32 + 2; }
 // K split of a score GEMM: enough blocks for two per CU, parts of at least ~8 listed tiles when the lists are full
@@ -303,6 +323,22 @@ int gemm_f64_split(int M, int N, int kt32) {
     return (int)std::min<int64_t>(z, 32);
 }
 
+template <typename TB, int BN>
+static hipError_t launch_f64_tile(const double* A, int lda, int M, const TB* B, int ldb, int N, double* C, int ldc, int tiles_m,
+                                  int64_t pairs, int* klist, int* kcount, int kt32, int* order, int split, int64_t slab_stride,
+                                  int* kpart, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        const hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nt_f64_mfma<TB, BN>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)F64Tile<BN>::lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_gemm_nt_f64_mfma<TB, BN>), dim3((unsigned)(pairs * split)), dim3(256), F64Tile<BN>::lds_bytes, stream,
+                       A, lda, M, B, ldb, N, C, ldc, tiles_m, klist, kcount, kt32, order, split, slab_stride, kpart);
+    return hipGetLastError();
+}
+
 template <typename TB>
 static hipError_t launch_gemm_nt_f64_t(const double* A, int lda, int M, const TB* B, int ldb, int N, double* C, int ldc,
                                        int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
@@ -311,31 +347,29 @@ static hipError_t launch_gemm_nt_f64_t(const double* A, int lda, int M, const TB
     if (split < 1 || split > 32 || (split > 1 && slab_stride < (int64_t)M * ldc)) return hipErrorInvalidValue;
     if (K_pad % 32 != 0) return hipErrorInvalidValue;
     const int kt32 = K_pad / 32;
-    const int tiles_m = (M + D_BM - 1) / D_BM, tiles_n = (N + D_BN - 1) / D_BN;
+    const int bn = gemm_f64_bn(N);
+    const int tiles_m = (M + D_BM - 1) / D_BM, tiles_n = (N + bn - 1) / bn;
     const int64_t pairs = (int64_t)tiles_m * tiles_n;
-    if (pairs > 0x7fffffff) return hipErrorInvalidValue;
+    if (pairs > 0x7fffffff || pairs * split > 0x7fffffff) return hipErrorInvalidValue;
     const int force_dense = gemm_force_dense();          // benchmark / debug: every tile listed
-    hipLaunchKernelGGL(k_build_klists_f64, dim3((unsigned)pairs), dim3(256), 0, stream, force_dense ? nullptr : nzA,
-                       force_dense ? nullptr : nzB, G, v_group, N, tiles_m, kt32, klist, kcount, split,
-                       kcount + 2 * pairs + kt32 + 2);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    constexpr size_t lds_bytes = (size_t)2 * (D_BM + D_BN) * D_LD * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
-        e = hipFuncSetAttribute((const void*)k_gemm_nt_f64_mfma<TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
     int* order = kcount + pairs;
     int* hist = order + pairs;
+    int* kpart = hist + kt32 + 2;
+    hipLaunchKernelGGL(k_build_klists_f64, dim3((unsigned)pairs), dim3(256), 0, stream, force_dense ? nullptr : nzA,
+                       force_dense ? nullptr : nzB, G, v_group, N, tiles_m, kt32, klist, kcount, split, kpart, bn);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(hist, 0, (size_t)(kt32 + 2) * sizeof(int), stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_order_pairs_f64, dim3(1), dim3(1024), 0, stream, kcount, (int)pairs, kt32, hist, order);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (pairs * split > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_gemm_nt_f64_mfma<TB>, dim3((unsigned)(pairs * split)), dim3(256), lds_bytes, stream, A, lda, M, B, ldb,
-                       N, C, ldc, tiles_m, klist, kcount, kt32, order, split, slab_stride, kcount + 2 * pairs + kt32 + 2);
-    return hipGetLastError();
+    if (bn == 32)
+        return launch_f64_tile<TB, 32>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split, slab_stride,
+                                       kpart, stream);
+    if (bn == 64)
+        return launch_f64_tile<TB, 64>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split, slab_stride,
+                                       kpart, stream);
+    return launch_f64_tile<TB, 128>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split, slab_stride,
+                                    kpart, stream);
 }
 
 hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,

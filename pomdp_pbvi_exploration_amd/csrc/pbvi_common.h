@@ -70,6 +70,7 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
 // first gemm_f64_pairs(M, N) of them are the list lengths).
 size_t gemm_f64_klist_ints(int M, int N, int kt32);
 size_t gemm_f64_pairs(int M, int N);
+int gemm_f64_bn(int N);                      // rows of B per column tile for a GEMM with N rows of B: 32, 64 or 128
 size_t gemm_f64_kcount_ints(int M, int N, int kt32);
 hipError_t launch_tile_nonzero_f64(const double* X, int ld, int rows, int kt32, uint8_t* nz, hipStream_t stream);
 hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,
