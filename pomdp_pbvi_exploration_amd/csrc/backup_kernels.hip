@@ -822,8 +822,8 @@ __global__ void k_refine_weights(int G, const T* __restrict__ bel, int ldb, Mode
 }
 
 // GEMM path, step 3: first maximum of the slot's exact scores over all V alpha rows
-__global__ void k_refine_slot_argmax(RefineWork work, int V, int32_t* __restrict__ best_v, double* __restrict__ best_score,
-                                     double* __restrict__ err) {
+__global__ void k_refine_slot_argmax(RefineWork work, int V, int split, int64_t slab_stride, int32_t* __restrict__ best_v,
+                                     double* __restrict__ best_score, double* __restrict__ err) {
     __shared__ double wv[4];
     __shared__ int wi[4];
     const int sl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -831,7 +831,8 @@ __global__ void k_refine_slot_argmax(RefineWork work, int V, int32_t* __restrict
     double m = -std::numeric_limits<double>::infinity();
     int idx = 0x7fffffff;
     for (int v = tid; v < V; v += 256) {
-        const double x = row[v];
+        double x = row[v];
+        for (int z = 1; z < split; ++z) x += row[v + (int64_t)z * slab_stride];      // K parts of the GEMM, fixed order
         if (x > m) {                                         // ascending v per thread: first maximum
             m = x;
             idx = v;
@@ -910,16 +911,23 @@ hipError_t launch_refine_deferred(bool proj, int V, int G, const T* bel, int ldb
             hipLaunchKernelGGL((k_refine_weights<T, false>), wgrid, dim3(256), 0, st, G, bel, ldb, mv, gamma, work);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = launch_tile_nonzero_f64(work.W, mv.S_pad, n_w, mv.S_pad / 32, work.nzW, st)) != hipSuccess) return e;
+        // a few dozen tie-heavy entries against thousands of alpha rows is a grid of a few dozen tile pairs: split along K
+        // (room for w_slot_cap rows of Cx was reserved; n_w is usually a small part of it)
+        int split = gemm_f64_split(n_w, V, mv.S_pad / 32);
+        if (split > work.w_slot_cap / n_w) split = work.w_slot_cap / n_w;
+        if (split < 1) split = 1;
+        const int64_t slab_stride = (int64_t)n_w * V;
         if constexpr (sizeof(T) == 4) {   // fp32 alpha rows widened exactly on the way into LDS
             if ((e = launch_gemm_nt_f64_bf32(work.W, mv.S_pad, n_w, (const float*)alpha, lda, V, work.Cx, V, mv.S_pad,
-                                             work.nzW, work.klistW, work.kcountW, st)) != hipSuccess)
+                                             work.nzW, work.klistW, work.kcountW, st, split, slab_stride)) != hipSuccess)
                 return e;
         } else {                          // fp64 engine behind an fp32 screen: the fp64 originals
             if ((e = launch_gemm_nt_f64(work.W, mv.S_pad, n_w, (const double*)alpha, lda, V, work.Cx, V, mv.S_pad,
-                                        work.nzW, nullptr, 0, 0, work.klistW, work.kcountW, st)) != hipSuccess)
+                                        work.nzW, nullptr, 0, 0, work.klistW, work.kcountW, st, split, slab_stride)) != hipSuccess)
                 return e;
         }
-        hipLaunchKernelGGL(k_refine_slot_argmax, dim3(n_w), dim3(256), 0, st, work, V, best_v, best_score, err);
+        hipLaunchKernelGGL(k_refine_slot_argmax, dim3(n_w), dim3(256), 0, st, work, V, split, slab_stride, best_v, best_score,
+                           err);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (n_items > 0) {

@@ -380,8 +380,10 @@ hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, 
 }
 
 hipError_t launch_gemm_nt_f64_bf32(const double* A, int lda, int M, const float* B, int ldb, int N, double* C, int ldc,
-                                   int K_pad, const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream) {
-    return launch_gemm_nt_f64_t<float>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nullptr, 1, N, klist, kcount, stream, 1, 0);
+                                   int K_pad, const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream, int split,
+                                   int64_t slab_stride) {
+    return launch_gemm_nt_f64_t<float>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nullptr, 1, N, klist, kcount, stream, split,
+                                       slab_stride);
 }
 
 }  // namespace pbvi

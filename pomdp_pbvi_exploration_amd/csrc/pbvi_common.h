@@ -80,7 +80,8 @@ hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, 
 int gemm_f64_split(int M, int N, int kt32);   // the split a score GEMM of this shape should use (1 once the grid fills the chip)
 // same with an fp32 B operand widened exactly on the way into LDS (fp64 weights x fp32 alpha rows)
 hipError_t launch_gemm_nt_f64_bf32(const double* A, int lda, int M, const float* B, int ldb, int N, double* C, int ldc,
-                                   int K_pad, const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream);
+                                   int K_pad, const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream, int split = 1,
+                                   int64_t slab_stride = 0);
 // Any-size reference GEMM (small f64 problems, A/B checks): C[m][n], no padding requirements.
 template <typename T>
 hipError_t launch_gemm_nt_simple(const T* A, int lda, const T* B, int ldb, T* C, int ldc,
