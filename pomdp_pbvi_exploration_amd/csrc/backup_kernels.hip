@@ -926,8 +926,8 @@ hipError_t launch_refine_deferred(bool proj, int V, int G, const T* bel, int ldb
                                         work.nzW, nullptr, 0, 0, work.klistW, work.kcountW, st, split, slab_stride)) != hipSuccess)
                 return e;
         }
-        hipLaunchKernelGGL(k_refine_slot_argmax, dim3(n_w), dim3(256), 0, st, work, V, split, slab_stride, best_v, best_score,
-                           err);
+        hipLaunchKernelGGL(k_refine_slot_argmax, dim3(n_w), dim3(256), 0, st, work, V, 1, slab_stride, best_v, best_score,
+                           err);                     // (the launcher folded the K parts into the first slab)
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (n_items > 0) {

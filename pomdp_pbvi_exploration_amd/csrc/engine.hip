@@ -1577,7 +1577,7 @@ class EngineT : public EngineBase {
             }
             snz_rows_ = have;
         }
-        if (kF32) {   // per-row tile lists for the f64 refinement
+        if (kF32 && !vmax_skinny()) {   // per-row tile lists for the f64 refinement
             if ((rc = grow_keep(sbtl_, (size_t)have * k_tiles * sizeof(int32_t), (size_t)sbt_rows_ * k_tiles * sizeof(int32_t)))) return rc;
             if ((rc = grow_keep(sbtc_, (size_t)have * sizeof(int32_t), (size_t)sbt_rows_ * sizeof(int32_t)))) return rc;
             for (int64_t r0 = sbt_rows_; r0 < have; r0 += 32768) {
@@ -1604,14 +1604,14 @@ class EngineT : public EngineBase {
             const int64_t cnt = std::min<int64_t>(window, n - r0);
             bel_.p = base + (size_t)r0 * S_pad_;                       bel_.cap = huge;
             nzA_.p = snz_.as<uint8_t>() + (size_t)(r0 / GEMM_BM) * k_tiles;   nzA_.cap = huge;
-            if (kF32) {
+            if (kF32 && !vmax_skinny()) {
                 btl_.p = sbtl_.as<int32_t>() + (size_t)r0 * k_tiles;   btl_.cap = huge;
                 btc_.p = sbtc_.as<int32_t>() + r0;                     btc_.cap = huge;
             }
             B_ = cnt;
             B_pad_ = round_up(cnt, GEMM_BM);
             sorted_ = false;
-            btl_valid_ = kF32;
+            btl_valid_ = kF32 && !vmax_skinny();
             rc = value_max_device();
             if (rc == PBVI_OK) rc = out_begin();
             if (rc == PBVI_OK && out_value) rc = out_add(out_value + r0, bs2_.p, (size_t)cnt * sizeof(double));
@@ -1691,6 +1691,11 @@ class EngineT : public EngineBase {
         return PBVI_OK;
     }
 
+    // fp32 engines: value-max GEMMs against at most 64 alpha rows take the skinny fp64-accumulating tile (value_max_device)
+    bool vmax_skinny() const {
+        static const bool off = getenv("PBVI_NO_SKINNY") != nullptr;      // debug / A-B only
+        return kF32 && !off && V_ > 0 && V_ <= 64 && mode_ == PBVI_SPARSE;
+    }
     // fp64 engines: MFMA GEMM unless the problem is a handful of tiles (the plain kernel is as good there)
     static bool f64_uses_mfma(int64_t m_rows, int64_t n_rows) {
         static const bool simple = getenv("PBVI_F64_SIMPLE") != nullptr;      // debug / A-B only
@@ -1775,11 +1780,11 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
             f64_pairs_ = (int64_t)gemm_f64_pairs((int)m_rows, (int)rows_y);
         }
         sv->slabs = slabs_.as<T>();
-        sv->slab_stride = m_rows * rows_y;
+        sv->slab_stride = 0;                  // the K parts were folded into the first slab by the launcher
         sv->ldc = (int)rows_y;
         sv->nchunks = nullptr;
         sv->tiles_m = 0;
-        sv->fixed = split;
+        sv->fixed = 1;
     }
     return PBVI_OK;
 }
@@ -1836,6 +1841,34 @@ int EngineT<T>::value_max_device() {
     if ((rc = queue2_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
     int* qc = counters_.as<int>() + 2;
     HIPCHK(hipMemsetAsync(qc, 0, sizeof(int), stream_));
+    if constexpr (kF32) {
+        if (vmax_skinny()) {
+            // A few dozen alpha rows (compute_change: every known belief against the rows an expansion added): on the
+            // 256 x 256 tile of the fp32 engine nine tenths of the MFMA work would be padding and the launch MFMA-bound on
+            // it.  The fp64 tile engine's 32- / 64-column variant with both operands widened on the way into LDS streams
+            // the belief block once instead -- and its scores are exact products summed in fp64, so there is no tie window
+            // and nothing to re-score.
+            const int kt32 = S_pad_ / GEMM_BK;
+            const int split = gemm_f64_split((int)B_, (int)V_, kt32);
+            const int64_t slab = B_ * V_;
+            if ((rc = slabs_.ensure((size_t)split * slab * sizeof(double), &bytes_))) return rc;
+            if ((rc = klist_.ensure(gemm_f64_klist_ints((int)B_, (int)V_, kt32) * sizeof(int), &bytes_))) return rc;
+            if ((rc = kcount_.ensure(gemm_f64_kcount_ints((int)B_, (int)V_, kt32) * sizeof(int), &bytes_))) return rc;
+            HIPCHK(launch_gemm_nt_f64_ff32((const float*)bel_.p, S_pad_, (int)B_, (const float*)alpha_.p, S_pad_, (int)V_,
+                                           slabs_.as<double>(), (int)V_, S_pad_, nzA_.as<uint8_t>(), klist_.as<int>(),
+                                           kcount_.as<int>(), stream_, split, slab));
+            SlabView<double> svd;
+            svd.slabs = slabs_.as<double>();
+            svd.slab_stride = 0;              // K parts folded into the first slab by the launcher
+            svd.ldc = (int)V_;
+            svd.nchunks = nullptr;
+            svd.tiles_m = 0;
+            svd.fixed = 1;
+            HIPCHK(launch_argmax<double>(svd, (int)V_, 1, (int)B_, nullptr, 0.0, 0.0, nullptr, 0, bv2_.as<int32_t>(),
+                                         bs2_.as<double>(), err2_.as<double>(), nullptr, qc, stream_));
+            return PBVI_OK;
+        }
+    }
     SlabView<T> sv;
     if ((rc = score_gemm(alpha_.as<T>(), Vt, nullptr, 1, (int)V_, &sv))) return rc;
     const int k_chunk = kF32 ? plan_.chunk_len * GEMM_BK : S_pad_;

@@ -174,8 +174,9 @@ __device__ __forceinline__ f64x2 load2(const float* p) {
     return f64x2{(double)v[0], (double)v[1]};
 }
 
-// TB: element type of B (double, or float widened on the way into LDS -- exact -- for the refinement's re-scoring
-// of fp32 alpha rows against fp64 weights).
+// TA / TB: element types of A and B (double, or float widened on the way into LDS -- exact: fp32 alpha rows against the
+// refinement's fp64 weights, and both operands fp32 for the skinny value-max GEMMs of fp32 engines, whose products are
+// then exact and whose sums are fp64).
 // BN: rows of B per block.  128 for score GEMMs proper; 64 / 32 for the solve loop's skinny ones (compute_change scores
 // the whole belief store against the few dozen alpha rows an expansion added: with a 128-wide tile three quarters of
 // the MFMA work is padding and the kernel is MFMA-bound on it; with 32 columns the same launch is a streaming read of
@@ -184,20 +185,23 @@ template <int BN>
 struct F64Tile {
     static constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN;
     static constexpr int MI = D_BM / WM / 16, NJ = BN / WN / 16;
-    static constexpr int BCH = BN / 32;                    // staging chunks of B per thread (A: 4)
-    static constexpr size_t lds_bytes = (size_t)2 * (D_BM + BN) * D_LD * sizeof(double);
-    static constexpr int min_blocks = BN == 32 ? 3 : 2;    // per CU: the skinny tile hides load latency with occupancy
+    static constexpr int BCH = (BN + 31) / 32;             // staging chunks of B per thread (A: 4); BN = 16, 48: the last
+                                                           // chunk's upper 16 rows land in LDS padding rows, never read
+    static constexpr int BROWS = BCH * 32;                 // rows of B staged (>= BN)
+    static constexpr size_t lds_bytes = (size_t)2 * (D_BM + BROWS) * D_LD * sizeof(double);
+    static constexpr int min_blocks = 2;                   // per CU
+    static constexpr int PD = BN == 128 ? 1 : 4;           // register prefetch depth in K steps (see the kernel)
 };
 
-template <typename TB, int BN>
+template <typename TA, typename TB, int BN>
 __global__ __launch_bounds__(256, F64Tile<BN>::min_blocks) void k_gemm_nt_f64_mfma(
-    const double* __restrict__ A, int lda, int M, const TB* __restrict__ B, int ldb, int N, double* __restrict__ C, int ldc,
+    const TA* __restrict__ A, int lda, int M, const TB* __restrict__ B, int ldb, int N, double* __restrict__ C, int ldc,
     int tiles_m, const int* __restrict__ klist, const int* __restrict__ kcount, int kt32, const int* __restrict__ order,
     int split, int64_t slab_stride, const int* __restrict__ kpart) {
     using TL = F64Tile<BN>;
     extern __shared__ double lds_f64[];                    // [2][128 * D_LD] A then [2][BN * D_LD] B: 72 KiB at BN = 128
     double (*As)[D_BM * D_LD] = reinterpret_cast<double (*)[D_BM * D_LD]>(lds_f64);       // (dynamic: above the 64 KiB
-    double (*Bs)[BN * D_LD] = reinterpret_cast<double (*)[BN * D_LD]>(lds_f64 + 2 * D_BM * D_LD);   // static limit)
+    double (*Bs)[TL::BROWS * D_LD] = reinterpret_cast<double (*)[TL::BROWS * D_LD]>(lds_f64 + 2 * D_BM * D_LD);   // static limit)
     const int pidx = (int)blockIdx.x / split, z = (int)blockIdx.x - pidx * split;
     const int pair = order ? order[pidx] : pidx;
     const int tm = pair % tiles_m, tn = pair / tiles_m;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, F64Tile<BN>::min_blocks) void k_gemm_nt_f64_mf
     // staging: instruction c of thread t moves 16 bytes of row c*32 + t/8, column chunk t%8 -- a wave instruction
     // covers eight whole 128-byte row segments (full cache lines)
     const int srow = tid >> 3, scol = (tid & 7) * 2;
-    const double* ap[4];
+    const TA* ap[4];
     const TB* bp[TL::BCH];
     bool a_ok[4], b_ok[TL::BCH];
 #pragma unroll
@@ -228,20 +232,29 @@ __global__ __launch_bounds__(256, F64Tile<BN>::min_blocks) void k_gemm_nt_f64_mf
         b_ok[c] = n0 + r < N;
         bp[c] = B + (int64_t)(b_ok[c] ? n0 + r : 0) * ldb + scol;
     }
-    f64x2 ra[4], rb[TL::BCH];
-    auto fetch = [&](int step) {
+    // Register prefetch ring, PD steps deep: the loads of step s + PD are issued when step s's operands have moved into
+    // LDS.  One step ahead is enough while a step's MFMAs (BN = 128: 4096 cycles per wave) outlast a global load; the
+    // skinny tiles spend 1024 / 2048 cycles per step against a load latency of several thousand, and their operand is a
+    // column slab of a multi-GB row store (128 rows x 128 bytes per step, one DRAM page each) -- they need several
+    // steps of loads in flight to stream it.
+    constexpr int PD = TL::PD;
+    f64x2 ra[PD][4], rb[PD][TL::BCH];
+    auto fetch = [&](int step, f64x2 (&qa)[4], f64x2 (&qb)[TL::BCH]) {
+        // No predication: rows past M / N read row 0 (their pointers were clamped) and feed accumulator rows / columns that
+        // are never stored, and a step past the end re-reads the last one.  A branch around a load would make the
+        // compiler drain the whole ring (vmcnt(0)) before every LDS write instead of waiting for the oldest slot only.
+        step = step < nsteps ? step : nsteps - 1;
         const int k0 = kl[step >> 1] * 32 + (step & 1) * D_BK;
-        const f64x2 zz = {0.0, 0.0};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ra[c] = a_ok[c] ? *(const f64x2*)(ap[c] + k0) : zz;
+        for (int c = 0; c < 4; ++c) qa[c] = load2(ap[c] + k0);
 #pragma unroll
-        for (int c = 0; c < TL::BCH; ++c) rb[c] = b_ok[c] ? load2(bp[c] + k0) : zz;
+        for (int c = 0; c < TL::BCH; ++c) qb[c] = load2(bp[c] + k0);
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const f64x2 (&qa)[4], const f64x2 (&qb)[TL::BCH]) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) *(f64x2*)(&As[buf][(c * 32 + srow) * D_LD + scol]) = ra[c];
+        for (int c = 0; c < 4; ++c) *(f64x2*)(&As[buf][(c * 32 + srow) * D_LD + scol]) = qa[c];
 #pragma unroll
-        for (int c = 0; c < TL::BCH; ++c) *(f64x2*)(&Bs[buf][(c * 32 + srow) * D_LD + scol]) = rb[c];
+        for (int c = 0; c < TL::BCH; ++c) *(f64x2*)(&Bs[buf][(c * 32 + srow) * D_LD + scol]) = qb[c];
     };
 
     f64x4 acc[TL::MI][TL::NJ];
@@ -250,33 +263,41 @@ __global__ __launch_bounds__(256, F64Tile<BN>::min_blocks) void k_gemm_nt_f64_mf
 #pragma unroll
         for (int j = 0; j < TL::NJ; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
+    // step s lives in ring slot s % PD.  Top of step s: LDS buffer s & 1 holds step s, the ring holds steps s+1 .. s+PD.
     if (nsteps > 0) {
-        fetch(0);
-        stash(0);
+        fetch(0, ra[0], rb[0]);
+        stash(0, ra[0], rb[0]);
+#pragma unroll
+        for (int u = 1; u <= PD; ++u) fetch(u, ra[u % PD], rb[u % PD]);
     }
     __syncthreads();
     const int fr = lane & 15, fk = lane >> 4;              // fragment row / k of this lane
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        const bool more = step + 1 < nsteps;
-        if (more) fetch(step + 1);                         // global loads fly under the MFMAs
-        const double* as = &As[buf][(wm * (TL::MI * 16) + fr) * D_LD + fk];
-        const double* bs = &Bs[buf][(wn * (TL::NJ * 16) + fr) * D_LD + fk];
+    for (int s0 = 0; s0 < nsteps; s0 += PD) {
 #pragma unroll
-        for (int ks = 0; ks < D_BK / 4; ++ks) {
-            double a[TL::MI], b[TL::NJ];
+        for (int u = 0; u < PD; ++u) {
+            const int step = s0 + u;
+            if (step >= nsteps) break;
+            const int buf = step & 1;
+            const double* as = &As[buf][(wm * (TL::MI * 16) + fr) * D_LD + fk];
+            const double* bs = &Bs[buf][(wn * (TL::NJ * 16) + fr) * D_LD + fk];
 #pragma unroll
-            for (int i = 0; i < TL::MI; ++i) a[i] = as[i * 16 * D_LD + ks * 4];
+            for (int ks = 0; ks < D_BK / 4; ++ks) {
+                double a[TL::MI], b[TL::NJ];
 #pragma unroll
-            for (int j = 0; j < TL::NJ; ++j) b[j] = bs[j * 16 * D_LD + ks * 4];
+                for (int i = 0; i < TL::MI; ++i) a[i] = as[i * 16 * D_LD + ks * 4];
 #pragma unroll
-            for (int i = 0; i < TL::MI; ++i)
+                for (int j = 0; j < TL::NJ; ++j) b[j] = bs[j * 16 * D_LD + ks * 4];
 #pragma unroll
-                for (int j = 0; j < TL::NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TL::MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TL::NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            const int nslot = (u + 1) % PD;                // constant after unrolling
+            if (step + 1 < nsteps) stash(buf ^ 1, ra[nslot], rb[nslot]);      // the other buffer was last read one barrier ago
+            fetch(step + 1 + PD, ra[nslot], rb[nslot]);
+            __syncthreads();
         }
-        if (more) stash(buf ^ 1);                          // the other buffer was last read one barrier ago
-        __syncthreads();
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
@@ -302,8 +323,8 @@ hipError_t launch_tile_nonzero_f64(const double* X, int ld, int rows, int kt32, 
 // column-tile width of a GEMM with N rows of B
 int gemm_f64_bn(int N) {
     static const int forced = getenv("PBVI_F64_BN") ? atoi(getenv("PBVI_F64_BN")) : 0;      // debug / A-B only: 32, 64, 128
-    if (forced == 32 || forced == 64 || forced == 128) return forced;
-    return N <= 32 ? 32 : (N <= 64 ? 64 : D_BN);
+    if (forced == 16 || forced == 32 || forced == 48 || forced == 64 || forced == 128) return forced;
+    return N <= 16 ? 16 : N <= 32 ? 32 : N <= 48 ? 48 : N <= 64 ? 64 : D_BN;
 }
 size_t gemm_f64_pairs(int M, int N) {
     const int bn = gemm_f64_bn(N);
@@ -318,29 +339,45 @@ int gemm_f64_split(int M, int N, int kt32) {
     if (forced > 0) return forced;
     const int64_t pairs = (int64_t)gemm_f64_pairs(M, N);
     if (pairs <= 0 || pairs >= 384) return 1;
-    int64_t z = (512 + pairs - 1) / pairs;
+    // ~4 blocks per block slot of the chip (2 per CU): a grid of 1.2 x the slots would run as two rounds, the second one
+    // nearly empty; with short blocks the tail is a small part of the launch
+    int64_t z = (2048 + pairs - 1) / pairs;
     z = std::min<int64_t>(z, std::max(1, kt32 / 8));
+    z = std::min<int64_t>(z, std::max<int64_t>(1, ((int64_t)64 << 20) / ((int64_t)M * N * 8)));      // partial slabs: <= 64 MiB
     return (int)std::min<int64_t>(z, 32);
 }
 
-template <typename TB, int BN>
-static hipError_t launch_f64_tile(const double* A, int lda, int M, const TB* B, int ldb, int N, double* C, int ldc, int tiles_m,
+// C[0] += C[1] + ... in slab order (fixed association): the K parts of a split GEMM folded into the first slab, so the
+// readers see one matrix.  (Left to them, a row-per-wave reader like k_argmax walks split x N values per wave -- for a
+// 100-row product that is the whole chip waiting on 100 waves.)
+__global__ void k_fold_slabs(double* __restrict__ C, int ldc, int M, int N, int split, int64_t slab_stride) {
+    const int64_t n = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t off = (i / N) * ldc + i % N;
+        double acc = C[off];
+        for (int z = 1; z < split; ++z) acc += C[off + z * slab_stride];
+        C[off] = acc;
+    }
+}
+
+template <typename TA, typename TB, int BN>
+static hipError_t launch_f64_tile(const TA* A, int lda, int M, const TB* B, int ldb, int N, double* C, int ldc, int tiles_m,
                                   int64_t pairs, int* klist, int* kcount, int kt32, int* order, int split, int64_t slab_stride,
                                   int* kpart, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nt_f64_mfma<TB, BN>,
+        const hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nt_f64_mfma<TA, TB, BN>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)F64Tile<BN>::lds_bytes);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_gemm_nt_f64_mfma<TB, BN>), dim3((unsigned)(pairs * split)), dim3(256), F64Tile<BN>::lds_bytes, stream,
+    hipLaunchKernelGGL((k_gemm_nt_f64_mfma<TA, TB, BN>), dim3((unsigned)(pairs * split)), dim3(256), F64Tile<BN>::lds_bytes, stream,
                        A, lda, M, B, ldb, N, C, ldc, tiles_m, klist, kcount, kt32, order, split, slab_stride, kpart);
     return hipGetLastError();
 }
 
-template <typename TB>
-static hipError_t launch_gemm_nt_f64_t(const double* A, int lda, int M, const TB* B, int ldb, int N, double* C, int ldc,
+template <typename TA, typename TB>
+static hipError_t launch_gemm_nt_f64_t(const TA* A, int lda, int M, const TB* B, int ldb, int N, double* C, int ldc,
                                        int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
                                        int* kcount, hipStream_t stream, int split, int64_t slab_stride) {
     if (M <= 0 || N <= 0) return hipSuccess;
@@ -362,28 +399,48 @@ static hipError_t launch_gemm_nt_f64_t(const double* A, int lda, int M, const TB
     if ((e = hipMemsetAsync(hist, 0, (size_t)(kt32 + 2) * sizeof(int), stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_order_pairs_f64, dim3(1), dim3(1024), 0, stream, kcount, (int)pairs, kt32, hist, order);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    auto fold = [&](hipError_t e0) -> hipError_t {
+        if (e0 != hipSuccess || split == 1) return e0;
+        const int64_t n = (int64_t)M * N;
+        hipLaunchKernelGGL(k_fold_slabs, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, C, ldc, M, N,
+                           split, slab_stride);
+        return hipGetLastError();
+    };
+    if (bn == 16)
+        return fold(launch_f64_tile<TA, TB, 16>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split,
+                                                slab_stride, kpart, stream));
+    if (bn == 48)
+        return fold(launch_f64_tile<TA, TB, 48>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split, slab_stride,
+                                           kpart, stream));
     if (bn == 32)
-        return launch_f64_tile<TB, 32>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split, slab_stride,
-                                       kpart, stream);
+        return fold(launch_f64_tile<TA, TB, 32>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split, slab_stride,
+                                       kpart, stream));
     if (bn == 64)
-        return launch_f64_tile<TB, 64>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split, slab_stride,
-                                       kpart, stream);
-    return launch_f64_tile<TB, 128>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split, slab_stride,
-                                    kpart, stream);
+        return fold(launch_f64_tile<TA, TB, 64>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split, slab_stride,
+                                       kpart, stream));
+    return fold(launch_f64_tile<TA, TB, 128>(A, lda, M, B, ldb, N, C, ldc, tiles_m, pairs, klist, kcount, kt32, order, split, slab_stride,
+                                    kpart, stream));
 }
 
 hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,
                               int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
                               int* kcount, hipStream_t stream, int split, int64_t slab_stride) {
-    return launch_gemm_nt_f64_t<double>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nzB, G, v_group, klist, kcount, stream, split,
+    return launch_gemm_nt_f64_t<double, double>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nzB, G, v_group, klist, kcount, stream, split,
                                         slab_stride);
 }
 
 hipError_t launch_gemm_nt_f64_bf32(const double* A, int lda, int M, const float* B, int ldb, int N, double* C, int ldc,
                                    int K_pad, const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream, int split,
                                    int64_t slab_stride) {
-    return launch_gemm_nt_f64_t<float>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nullptr, 1, N, klist, kcount, stream, split,
+    return launch_gemm_nt_f64_t<double, float>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nullptr, 1, N, klist, kcount, stream, split,
                                        slab_stride);
+}
+
+hipError_t launch_gemm_nt_f64_ff32(const float* A, int lda, int M, const float* B, int ldb, int N, double* C, int ldc, int K_pad,
+                                   const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream, int split,
+                                   int64_t slab_stride) {
+    return launch_gemm_nt_f64_t<float, float>(A, lda, M, B, ldb, N, C, ldc, K_pad, nzA, nullptr, 1, N, klist, kcount, stream,
+                                              split, slab_stride);
 }
 
 }  // namespace pbvi

@@ -75,12 +75,16 @@ size_t gemm_f64_kcount_ints(int M, int N, int kt32);
 hipError_t launch_tile_nonzero_f64(const double* X, int ld, int rows, int kt32, uint8_t* nz, hipStream_t stream);
 hipError_t launch_gemm_nt_f64(const double* A, int lda, int M, const double* B, int ldb, int N, double* C, int ldc,
                               int K_pad, const uint8_t* nzA, const uint8_t* nzB, int G, int v_group, int* klist,
-                              int* kcount, hipStream_t stream, int split = 1 /* K parts per pair: part z of C at */,
-                              int64_t slab_stride = 0 /* C + z * slab_stride; the product is their sum */);
+                              int* kcount, hipStream_t stream, int split = 1 /* K parts per pair: part z is accumulated at */,
+                              int64_t slab_stride = 0 /* C + z * slab_stride (workspace), then folded into C in slab order */);
 int gemm_f64_split(int M, int N, int kt32);   // the split a score GEMM of this shape should use (1 once the grid fills the chip)
 // same with an fp32 B operand widened exactly on the way into LDS (fp64 weights x fp32 alpha rows)
 hipError_t launch_gemm_nt_f64_bf32(const double* A, int lda, int M, const float* B, int ldb, int N, double* C, int ldc,
                                    int K_pad, const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream, int split = 1,
+                                   int64_t slab_stride = 0);
+// both operands fp32, widened exactly: fp64 scores of fp32 data (skinny value-max GEMMs of fp32 engines)
+hipError_t launch_gemm_nt_f64_ff32(const float* A, int lda, int M, const float* B, int ldb, int N, double* C, int ldc, int K_pad,
+                                   const uint8_t* nzA, int* klist, int* kcount, hipStream_t stream, int split = 1,
                                    int64_t slab_stride = 0);
 // Any-size reference GEMM (small f64 problems, A/B checks): C[m][n], no padding requirements.
 template <typename T>

@@ -467,14 +467,15 @@ def test_value_max_over_the_belief_store_in_place(monkeypatch):
     sort, zero maps and tile lists extended as rows arrive.  Equal to the gathered-block path and to the oracle, across
     appends that leave partial 256-row blocks, for f32 (exact re-scoring) and f64 engines."""
     m = synth.olfactory_model(H=15, W=40, R=5)
-    alpha, _ = synth.alpha_set(m, 40)
-    alpha[7] = alpha[3]                                           # an exact tie: the lower index must win
     beliefs = synth.belief_points(m, 700, max_depth=24)
-    want = orc.max_value_per_belief(alpha.astype(np.float64), beliefs.astype(np.float64))
-    for dtype in ('f32', 'f64'):
-        # f32 engines re-score every belief on its own (bit-identical whatever block it rides in); the fp64 GEMM splits K
-        # by the shape of its grid, so launches of different shapes agree to summation order (a few ulps), indices exactly
-        same = np.array_equal if dtype == 'f32' else (lambda a, b: np.allclose(a, b, rtol=1e-14, atol=0.0))
+    for dtype, n_alpha in (('f32', 80), ('f32', 40), ('f64', 40)):
+        alpha, _ = synth.alpha_set(m, n_alpha)
+        alpha[7] = alpha[3]                                           # an exact tie: the lower index must win
+        want = orc.max_value_per_belief(alpha.astype(np.float64), beliefs.astype(np.float64))
+        # f32 engines against more than 64 alpha rows re-score every belief on its own (bit-identical whatever block it
+        # rides in); the fp64 tile engine -- fp64 engines, and fp32 ones against at most 64 rows -- splits K by the shape of
+        # its grid, so launches of different shapes agree to summation order (a few ulps), indices exactly
+        same = np.array_equal if (dtype, n_alpha) == ('f32', 80) else (lambda a, b: np.allclose(a, b, rtol=1e-14, atol=0.0))
         eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype)
         eng.store_rows('alpha', alpha)
         eng.select_alpha(np.arange(len(alpha)))
@@ -514,13 +515,13 @@ def test_value_max_without_fp64_rescoring_stays_within_the_f32_bar():
     relative of the exact ones; exact mode is back afterwards; max_value_objects keeps exact and inexact results apart."""
     from pomdp_pbvi_exploration_amd.mdp import AlphaVector
     m = synth.olfactory_model(H=15, W=40, R=5)
-    alpha, _ = synth.alpha_set(m, 40)
+    alpha, _ = synth.alpha_set(m, 80)          # more than 64 rows: the fp32 stream-K GEMM (fewer take the fp64-accumulating tile)
     beliefs = synth.belief_points(m, 300, max_depth=24)
     want = orc.max_value_per_belief(alpha.astype(np.float64), beliefs.astype(np.float64))
     eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f32')
     eng.store_rows('alpha', alpha)
     eng.store_rows('belief', beliefs)
-    eng.select_alpha(np.arange(40))
+    eng.select_alpha(np.arange(80))
     eng.select_beliefs(np.arange(300))
     exact, _ = eng.max_value_resident()
     np.testing.assert_allclose(exact, want, rtol=1e-12)
