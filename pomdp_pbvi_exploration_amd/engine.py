@@ -325,9 +325,15 @@ class BackupResult:
             return (self.unique_alpha[:0], act[:0], idx[:0]) if with_index else (self.unique_alpha[:0], act[:0])
         first = np.unique(idx, return_index=True)[1]
         first.sort()
+        sel = idx[first]
+        # the engine already lists the distinct rows in order of first occurrence: unless the belief-dominance mask dropped
+        # some, `sel` is 0 .. U-1 and the rows are handed on as they lie (a fancy-index copy of U rows of 120-240 KB was
+        # 0.7 ms of every backup of a solve loop)
+        whole = len(sel) == len(self.unique_alpha) and bool((sel == np.arange(len(sel))).all())
+        rows = self.unique_alpha if whole else self.unique_alpha[sel]
         if with_index:
-            return self.unique_alpha[idx[first]], act[first], idx[first]
-        return self.unique_alpha[idx[first]], act[first]
+            return rows, act[first], sel
+        return rows, act[first]
 
 
 class Engine:

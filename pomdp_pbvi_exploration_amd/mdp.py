@@ -281,6 +281,19 @@ class Model:
 _HASH_WEIGHTS = {}
 
 
+def _same_bytes(a, b) -> bool:
+    """``a.tobytes() == b.tobytes()`` without materialising the two byte strings (240 KB each at S = 30000: the dedup
+    dictionaries of a solve compare ~17 000 pairs of rows with equal hashes, nearly all of them true repeats)."""
+    if a is b:
+        return True
+    if a.dtype != b.dtype or a.shape != b.shape:
+        return a.tobytes() == b.tobytes()
+    if a.dtype.itemsize in (4, 8) and a.flags.c_contiguous and b.flags.c_contiguous:
+        t = np.uint32 if a.dtype.itemsize == 4 else np.uint64
+        return bool(np.array_equal(a.view(t), b.view(t)))       # bit patterns: -0.0 != 0.0 and NaN == NaN, like bytes
+    return a.tobytes() == b.tobytes()
+
+
 def _row_hash(row) -> int:
     """``sum_i bits_i * (2 i + 1) mod 2^64`` over the fp32 / fp64 bit patterns of a 1-D row: the number the dedup keys of
     the belief and alpha-vector containers hash by.  The HIP engine computes the same number for rows it produced
@@ -325,7 +338,7 @@ class _RowKey(int):
     __hash__ = int.__hash__
 
     def __eq__(self, other) -> bool:
-        return int.__eq__(self, other) is True and (self.row is other.row or self.row.tobytes() == other.row.tobytes())
+        return int.__eq__(self, other) is True and _same_bytes(self.row, other.row)
 
     def __ne__(self, other) -> bool:
         return not self.__eq__(other)
@@ -359,7 +372,7 @@ class _AlphaKey(int):
     __hash__ = int.__hash__
 
     def __eq__(self, other) -> bool:
-        return int.__eq__(self, other) is True and (self.row is other.row or self.row.tobytes() == other.row.tobytes())
+        return int.__eq__(self, other) is True and _same_bytes(self.row, other.row)
 
     def __ne__(self, other) -> bool:
         return not self.__eq__(other)
