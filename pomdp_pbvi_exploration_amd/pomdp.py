@@ -23,7 +23,7 @@ import numpy as np
 from .mdp import AlphaVector, ValueFunction, VI_Solver, log, _log, set_quiet   # noqa: F401
 from .mdp import Model as MDP_Model
 from .mdp import Solver as MDP_Solver
-from .mdp import RewardSet, _RowKey                          # noqa: F401
+from .mdp import RewardSet, _RowKey, _draw_index             # noqa: F401
 from .mdp import SimulationHistory as MDP_SimulationHistory
 from .mdp import Simulation as MDP_Simulation
 from . import dist as _dist
@@ -98,7 +98,7 @@ class Model(MDP_Model):
         return r
 
     def observe(self, s_p: int, a: int) -> int:
-        return int(np.random.choice(a=self.observations, size=1, p=self.observation_table[s_p, a])[0])
+        return int(self.observations[_draw_index(self.observation_table[s_p, a])])
 
 
 class Belief:
@@ -161,7 +161,7 @@ class Belief:
         return [self.update(a, o) for a in self.model.actions for o in self.model.observations]
 
     def random_state(self) -> int:
-        return int(np.random.choice(a=self.model.states, size=1, p=self._values)[0])
+        return int(self.model.states[_draw_index(self._values)])
 
 
 class BeliefSet:
