@@ -510,6 +510,43 @@ def test_value_max_over_the_belief_store_in_place(monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize('n_alpha', [5, 16, 17, 33, 48, 49, 64, 65, 130])
+def test_value_max_column_tile_widths(n_alpha):
+    """The fp64 tile engine's 16 / 32 / 48 / 64 / 128-column variants (fp64 engines: every width; fp32 engines: up to 64
+    rows, both operands widened) on either side of each boundary: values against the oracle, exact ties to the lower
+    index, a belief count that leaves a partial 128-row block."""
+    m = synth.olfactory_model(H=15, W=40, R=5)
+    alpha, _ = synth.alpha_set(m, n_alpha)
+    alpha[n_alpha - 1] = alpha[2]                                     # exact tie across the width of the tile
+    beliefs = synth.belief_points(m, 333, max_depth=24)
+    want = orc.max_value_per_belief(alpha.astype(np.float64), beliefs.astype(np.float64))
+    scores = beliefs.astype(np.float64) @ alpha.astype(np.float64).T
+    for dtype in ('f32', 'f64'):
+        eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype)
+        val, idx = eng.max_value(alpha, beliefs)
+        np.testing.assert_allclose(val, want, rtol=1e-12)
+        assert not np.any(idx == n_alpha - 1)
+        # the index is a maximiser of the fp64 scores (up to their own rounding) and never the later of two equal rows
+        np.testing.assert_allclose(scores[np.arange(len(idx)), idx], want, rtol=1e-12)
+        eng.close()
+
+
+def test_value_max_skinny_at_full_size():
+    """S = 30000: a few hundred beliefs against 40 alpha rows -- the shape compute_change produces -- through the K-split
+    skinny tiles of both engine types (a handful of tile pairs, each split along K); values against NumPy's fp64 dots."""
+    m = synth.olfactory_model(H=75, W=400, R=1)
+    alpha, _ = synth.alpha_set(m, 40)
+    alpha[31] = alpha[7]
+    beliefs = synth.belief_points(m, 300, max_depth=50)
+    want = (beliefs.astype(np.float64) @ alpha.astype(np.float64).T).max(axis=1)
+    for dtype in ('f32', 'f64'):
+        eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype)
+        val, idx = eng.max_value(alpha, beliefs)
+        np.testing.assert_allclose(val, want, rtol=1e-12)
+        assert not np.any(idx == 31)
+        eng.close()
+
+
 def test_value_max_without_fp64_rescoring_stays_within_the_f32_bar():
     """pbvi_set_value_max_exact(0) (what compute_change uses on f32 engines): the fp32 GEMM's maxima, within 1e-6
     relative of the exact ones; exact mode is back afterwards; max_value_objects keeps exact and inexact results apart."""
