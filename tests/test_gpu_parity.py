@@ -20,6 +20,13 @@ F32_RTOL = 1e-6
 F64_RTOL = 1e-12
 
 
+
+# The suite is also run with the engine's debug switches set; assertions about which path a DEFAULT
+# engine takes only hold without them.
+SCREEN_DEFAULT = os.environ.get('PBVI_F64_SCREEN', 'auto') in ('', 'auto', '1')
+FUSION_ALLOWED = os.environ.get('PBVI_NO_FUSED_PROJECT') is None
+DEFAULT_PIPELINE = SCREEN_DEFAULT and os.environ.get('PBVI_FORMULATION', 'auto') in ('', 'auto', '0')
+
 def rel_err(x, ref):
     scale = np.maximum(np.abs(ref), 1e-30)
     return float(np.max(np.abs(np.asarray(x, dtype=np.float64) - ref) / np.maximum(scale, np.max(np.abs(ref)) * 1e-6)))
@@ -776,6 +783,8 @@ def test_f64_engine_screened_equals_pure_at_full_size(R):
     outputs (indices exact, values to 1e-12) and against the pure fp64 pipeline of the same engine (same bits)."""
     z, m, alpha, beliefs = _full_fixture(R)
     eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype='f64')
+    if not SCREEN_DEFAULT:
+        eng.set_f64_screen('auto')
     res = eng.backup_full(alpha, beliefs, m.gamma, belief_dominance_prune=True)
     assert res.stats['screened'] == 1
     assert np.array_equal(res.best_alpha_ind, z['core_best']), int(np.sum(res.best_alpha_ind != z['core_best']))
@@ -1036,7 +1045,7 @@ def test_fused_projection_gives_the_bits_of_the_projected_pipeline(S, A, O, V, B
     for fused in (True, False):
         eng.set_fused_projection(fused)
         res = eng.backup_full(alpha, b, 0.9, belief_dominance_prune=True)
-        assert res.stats['fused_projection'] == int(fused)
+        assert res.stats['fused_projection'] == int(fused and FUSION_ALLOWED)
         assert np.array_equal(res.best_alpha_ind, want_v) and np.array_equal(res.actions, want_a), fused
         assert_alpha_close(res.alpha, want_rows, F32_RTOL)
         out[fused] = res
@@ -1083,8 +1092,8 @@ def test_sea_robin_shape_against_oracle(dtype):
     eng.set_formulation('alpha')
     res = eng.backup_full(alpha, b, 0.99)
     if dtype == 'f32':
-        assert res.stats['fused_projection'] == 1
-    else:
+        assert res.stats['fused_projection'] == int(FUSION_ALLOWED)
+    elif SCREEN_DEFAULT:
         assert res.stats['screened'] == 1
     assert np.array_equal(res.best_alpha_ind, want_v), int(np.sum(res.best_alpha_ind != want_v))
     assert np.array_equal(res.actions, want_a)
@@ -1329,10 +1338,13 @@ def test_end_to_end_fsvi_at_headline_scale_matches_reference():
     assert hist.beliefs_counts == list(z['beliefs'])
     # |V| follows the reference exactly for the first 29 backups; from then on single alpha rows may differ where the
     # reference's argmax is decided by rounding noise between exactly tied candidates.
+    # (The forks are decided by the summation order of one GEMM: with a debug switch that sends the early backups through
+    # another kernel -- the pure fp64 GEMM with its K split, the belief-side formulation -- the first one comes earlier.)
     got, want = np.array(hist.alpha_vector_counts), z['alphas']
-    assert np.array_equal(got[:25], want[:25])
-    assert np.all(np.abs(got - want) <= np.maximum(2, want // 100))
-    np.testing.assert_allclose(hist.value_function_changes[:24], z['changes'][:24], rtol=1e-9, atol=1e-12)
+    strict = 25 if DEFAULT_PIPELINE else 9
+    assert np.array_equal(got[:strict], want[:strict])
+    assert np.all(np.abs(got - want) <= (np.maximum(2, want // 100) if DEFAULT_PIPELINE else np.maximum(3, want // 50)))
+    np.testing.assert_allclose(hist.value_function_changes[:strict - 1], z['changes'][:strict - 1], rtol=1e-9, atol=1e-12)
     alpha = np.asarray(vf.alpha_vector_array, dtype=np.float64)
     v_b0 = float(np.max(alpha @ np.asarray(model.start_probabilities)))
     # On the reference's trajectory the value of the start belief is the reference's; a run that forked at one of those
@@ -1341,8 +1353,7 @@ def test_end_to_end_fsvi_at_headline_scale_matches_reference():
     # (The default pipeline reproduces the reference's value to the last digit although its |V| is off by one row from
     # backup 29 on; with every backup forced into the belief-side formulation -- the debug mode the suite is also run
     # in -- the run forks at backup 31 and ends 3 % lower.)
-    forced = os.environ.get('PBVI_FORMULATION', 'auto') not in ('', 'auto', '0')
-    assert abs(v_b0 - float(z['value_b0'])) <= (0.1 if forced else 1e-9) * abs(float(z['value_b0']))
+    assert abs(v_b0 - float(z['value_b0'])) <= (1e-9 if DEFAULT_PIPELINE else 0.1) * abs(float(z['value_b0']))
     print(f'end to end: |V|={len(vf)} backup mean {np.mean(hist.backup_times) * 1e3:.2f} ms '
           f'(reference on the fixture machine: {float(z["ref_backup_mean_s"]):.2f} s)')
 
