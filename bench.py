@@ -273,13 +273,20 @@ def main():
         _, el2, _ = timed_steps(lambda: eng.run(m.gamma), args.steps, 2, fence)
         resident_ms = el2 / args.steps * 1e3
         # PCIe-inclusive variant: pageable host beliefs in, the expanded [B][S] alpha' matrix out to pageable memory
-        t1 = time.perf_counter()
-        for _ in range(3):
-            eng.set_beliefs(beliefs)
+        # (the caller's arrays as a caller of an f32 engine would hold them: engine dtype, allocated once)
+        b_host = np.ascontiguousarray(beliefs, dtype=eng.np_dtype)
+        full = np.zeros((B, m.S), dtype=eng.np_dtype)
+        def host_step():
+            eng.set_beliefs(b_host)
             eng.run(m.gamma)
             eng.fetch()
-            eng.fetch_full()
+            eng.fetch_full(full)
+        host_step()                                  # the engine's pinned bounce buffer grows to the matrix's size once
+        t1 = time.perf_counter()
+        for _ in range(3):
+            host_step()
         host_ms = (time.perf_counter() - t1) / 3 * 1e3
+        del b_host, full
 
     if rank == 0:
         K = args.steps
@@ -346,7 +353,7 @@ def main():
             pass
         if host_ms is not None:
             out['pcie_inclusive'] = {'ms_per_step': host_ms, 'value': B / (host_ms * 1e-3), 'unit': 'backups/s',
-                                     'what': 'pageable beliefs uploaded + run + unique rows and the expanded [B][S] alpha\' matrix fetched to pageable memory'}
+                                     'what': 'pageable beliefs (engine dtype) uploaded + run + unique rows and the expanded [B][S] alpha\' matrix fetched into a pageable array the caller keeps; mean of 3 after one warm-up'}
     host.close()
     eng.close()
 

@@ -700,11 +700,15 @@ class Engine:
             keep.ctypes.data_as(C.POINTER(C.c_uint8)) if keep is not None else None))
         return U
 
-    def fetch_full(self) -> np.ndarray:
-        """Per-belief alpha' matrix [B,S] expanded on the device (``pbvi_backup_fetch``'s out_alpha)."""
-        alpha = np.empty((self.B, self.S), dtype=self.np_dtype)
-        _check(self._lib.pbvi_backup_fetch(self._h, _ptr(alpha), None, None, None))
-        return alpha
+    def fetch_full(self, out=None) -> np.ndarray:
+        """Per-belief alpha' matrix [B,S] expanded on the device (``pbvi_backup_fetch``'s out_alpha); ``out``: a
+        C-contiguous [B,S] array of the engine's dtype to fill instead of a new one."""
+        if out is None:
+            out = np.empty((self.B, self.S), dtype=self.np_dtype)
+        elif out.shape != (self.B, self.S) or out.dtype != self.np_dtype or not out.flags.c_contiguous:
+            raise ValueError(f'out must be a C-contiguous [{self.B}, {self.S}] {self.dtype} array')
+        _check(self._lib.pbvi_backup_fetch(self._h, _ptr(out), None, None, None))
+        return out
 
     @property
     def unique_count(self) -> int:
