@@ -456,7 +456,7 @@ class EngineT : public EngineBase {
     hipStream_t stream2_ = nullptr;                  // belief-only kernels run beside projection + GEMM
     hipStream_t stream3_ = nullptr;                  // the score GEMM's tile lists / stream-K plan: beside both (a few us of
                                                      // work that the GEMM waits for must not queue behind k_dead's 100 us)
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_lists_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_lists_ = nullptr, ev_xr_[2] = {nullptr, nullptr};
     GemmPlan plan_ = {};
     hipEvent_t ev_[9] = {};
     hipEvent_t ev_pg_[2] = {};                       // around the dense projection's GEMM kernel
@@ -511,6 +511,8 @@ class EngineT : public EngineBase {
         if (ev_fork_) chk(hipEventDestroy(ev_fork_), "hipEventDestroy(fork)");
         if (ev_join_) chk(hipEventDestroy(ev_join_), "hipEventDestroy(join)");
         if (ev_lists_) chk(hipEventDestroy(ev_lists_), "hipEventDestroy(lists)");
+        for (auto& e : ev_xr_)
+            if (e) chk(hipEventDestroy(e), "hipEventDestroy(xr)");
         if (owns_streams_) {
             if (stream3_) chk(hipStreamDestroy(stream3_), "hipStreamDestroy(3)");
             if (stream2_) chk(hipStreamDestroy(stream2_), "hipStreamDestroy(2)");
@@ -579,6 +581,7 @@ class EngineT : public EngineBase {
         HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_lists_, hipEventDisableTiming));
+        for (auto& e : ev_xr_) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 
         // re-tile the reference's [S][A][R] / [S][A][O][R] / [S][A] tables to s-contiguous planes
         const size_t n_rs = (size_t)A * R * S_pad_, n_rto = (size_t)A * O * R * S_pad_, n_er = (size_t)A * S_pad_;
@@ -2243,11 +2246,24 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     if ((rc = scorer.stage_scores(gamma, use_push, io, &sc))) return rc;
     const SlabView<TS>& sv = sc.sv;
     const GemmPlan plan = sc.plan;
+    bool xr_pending = false;
     if (use_push && !screened) {   // max_v b.alpha_v of these beliefs from the GEMM's extra rows (exact engines only)
+        // beside the refinement, on the side stream: a wave per belief row over V scores is 0.1 ms that nothing in this
+        // call waits for (the slabs stay as they are until the next GEMM; K5 is not run with this formulation's extras
+        // pending -- it joins first, below)
         if ((rc = vmax_bk_.ensure((size_t)B_ * sizeof(double), &bytes_))) return rc;
-        hipLaunchKernelGGL(k_extra_rowmax<TS>, dim3((unsigned)((B_ + 3) / 4)), dim3(256), 0, stream_, sv, sc.extra_row0, (int)B_,
+        hipStream_t xs = no_side ? stream_ : stream2_;
+        if (xs != stream_) {
+            HIPCHK(hipEventRecord(ev_xr_[0], stream_));
+            HIPCHK(hipStreamWaitEvent(xs, ev_xr_[0], 0));
+        }
+        hipLaunchKernelGGL(k_extra_rowmax<TS>, dim3((unsigned)((B_ + 3) / 4)), dim3(256), 0, xs, sv, sc.extra_row0, (int)B_,
                            (int)V_, sorted_ ? perm_.as<int32_t>() : nullptr, vmax_bk_.as<double>());
         HIPCHK(hipGetLastError());
+        if (xs != stream_) {
+            HIPCHK(hipEventRecord(ev_xr_[1], xs));
+            xr_pending = true;
+        }
     }
     std::vector<int> h_kcount;
     const int64_t f64_pairs = sc.f64_pairs;
@@ -2326,6 +2342,10 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, mv, gamma, res_action_, res_best_, uniq_.as<int32_t>(), ucount,
                                   (int)B_, out_.as<T>(), S_, stream_));
         HIPCHK(hipEventRecord(ev_[6], stream_));
+        if (xr_pending) {                            // the extra rows' maxima read the slabs K5's GEMM is about to overwrite
+            HIPCHK(hipStreamWaitEvent(stream_, ev_xr_[1], 0));
+            xr_pending = false;
+        }
         // K5: belief dominance (keep is written in caller order)
         if (flags & PBVI_BELIEF_DOMINANCE) {
             int rc2;
