@@ -132,9 +132,19 @@ int pbvi_beliefs_set(pbvi_engine_t* e, const void* beliefs, int64_t B);
  * order matters: argmax ties go to the lowest index, and ValueFunction.extend puts new vectors first
  * (src/mdp.py:773-774), so the selection must follow the host list order, not the upload order.
  * store_reset forgets all stored rows (ids restart at 0).
+ *
+ * pbvi_alpha_select keeps the selected set laid out with free rows in front of it: a later selection that is k new ids
+ * followed by exactly the ids of the resident one -- what `new_value_function.extend(value_function)` produces after every
+ * backup of a solve loop (src/pomdp.py:1521-1522) -- gathers those k rows only; a selection at most a quarter of the
+ * resident one's size (compute_change's score of the rows an expansion added, src/pomdp.py:2141-2169) is placed beside it and
+ * leaves it intact.  Results never depend on which of the paths was taken (same rows in the same order).
+ * pbvi_alpha_layout reports it (tests, diagnostics): returns 1 when the working set is such an extendable selection, 0
+ * otherwise (uploaded with pbvi_alpha_set / _append, or a small selection); *free_rows = rows still free in front of it,
+ * *layouts = how many times a selection had to be gathered afresh so far.  Either pointer may be NULL.
  */
 int64_t pbvi_alpha_store_append(pbvi_engine_t* e, const void* rows /* [n][S] T */, int64_t n);
 int pbvi_alpha_select(pbvi_engine_t* e, const int32_t* ids /* [V] */, int64_t V);
+int pbvi_alpha_layout(pbvi_engine_t* e, int64_t* free_rows, int64_t* layouts);
 int pbvi_alpha_store_reset(pbvi_engine_t* e);
 int64_t pbvi_belief_store_append(pbvi_engine_t* e, const void* rows /* [n][S] T */, int64_t n);
 int pbvi_beliefs_select(pbvi_engine_t* e, const int32_t* ids /* [B] */, int64_t B);

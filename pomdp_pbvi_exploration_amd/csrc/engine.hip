@@ -381,6 +381,7 @@ class EngineBase {
     virtual int64_t store_count(int which) const = 0;
     virtual int set_tie_window(double rel) = 0;
     virtual int set_value_max_exact(int exact) = 0;
+    virtual int alpha_layout(int64_t* free_rows, int64_t* layouts) = 0;
     virtual int set_formulation(int f) = 0;
     virtual int set_screen(int mode) = 0;
     virtual int set_fused(int enable) = 0;
@@ -412,7 +413,24 @@ class EngineT : public EngineBase {
     double tie_rel_user_ = -1.0;
 
     DevBuf rs_, rto_, er_, sup_;
-    DevBuf alpha_;
+    // The working alpha set.  alpha_ is a VIEW (never allocated or released itself) of V_ data rows, the magnitude row and
+    // zero rows up to the next multiple of 256 + 256, inside one of two allocations:
+    //   alpha_buf_   -- the set as uploaded (alpha_set / alpha_append: view at row 0), or the PRIMARY set selected from the
+    //                   alpha store, laid out with free rows in FRONT of it: the solve loop's next set is its new rows followed
+    //                   by the previous set (ValueFunction.extend: new-then-old, and first-max ties go to the lower index, so
+    //                   the order is part of the result) -- those rows are gathered into the free rows just before the
+    //                   view, which then starts k rows earlier; nothing else moves, the magnitude row takes the maximum
+    //                   with the new rows.  (Re-gathering 10^4 rows per backup was 0.1 s of a 300-expansion solve, the fp32
+    //                   copy for the screen of an fp64 engine another 0.09 s.)
+    //   alpha_small_ -- a selection much smaller than the primary set (compute_change scores the rows an expansion added):
+    //                   gathered here so that the primary set is still there for the next backup.
+    DevBuf alpha_, alpha_buf_, alpha_small_;
+    std::vector<int32_t> prim_ids_;                          // store ids of the primary set, view order
+    int64_t prim_off_ = 0;                                   // first data row of the primary set inside alpha_buf_
+    bool prim_valid_ = false, alpha_on_primary_ = false;
+    uint64_t prim_layout_ver_ = 0;                           // a fresh layout of the primary set (the screen mirrors it)
+    uint64_t screen_layout_seen_ = 0;                        // fp64 engines: layout / first row the screen's copy reflects
+    int64_t screen_off_seen_ = 0;
     int64_t V_ = 0;
     DevBuf bel_;
     int64_t B_ = 0, B_pad_ = 0;
@@ -487,7 +505,7 @@ class EngineT : public EngineBase {
             delete screen_;
             screen_ = nullptr;
         }
-        DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
+        DevBuf* all[] = {&rs_, &rto_, &er_, &sup_, &alpha_buf_, &alpha_small_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_,
                          &dead_, &queue_, &counters_, &rdot_, &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_,
                          &err2_, &queue2_, &prune_cnt_, &nzB_, &nzA_, &klist_, &kcount_, &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_,
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
@@ -680,11 +698,23 @@ class EngineT : public EngineBase {
     // ---- alpha set ------------------------------------------------------- //
     size_t alpha_rows_cap(int64_t V) const { return (size_t)round_up(V + 1, GEMM_BN); }
 
+    void alpha_view(const DevBuf& own, int64_t row_off) {
+        const size_t skip = (size_t)row_off * S_pad_ * sizeof(T);
+        alpha_.p = static_cast<char*>(own.p) + skip;
+        alpha_.cap = own.cap - skip;
+    }
+
+    // magnitude row (row V_ of the view) := column-wise max |alpha| of the view's rows
     int refresh_magnitude_row() {
         T* base = alpha_.as<T>();
         HIPCHK(hipMemsetAsync(base + (size_t)V_ * S_pad_, 0, (size_t)S_pad_ * sizeof(T), stream_));
-        hipLaunchKernelGGL(k_col_absmax<T>, dim3((S_pad_ + 255) / 256, (unsigned)((V_ + 127) / 128)), dim3(256), 0, stream_,
-                           base, S_pad_, (int)V_, S_pad_, base + (size_t)V_ * S_pad_);
+        return merge_magnitude_row(base, V_);
+    }
+    // ... := max(itself, column-wise max |.| of `n` rows at `rows`)
+    int merge_magnitude_row(const T* rows, int64_t n) {
+        if (n <= 0) return PBVI_OK;
+        hipLaunchKernelGGL(k_col_absmax<T>, dim3((S_pad_ + 255) / 256, (unsigned)((n + 127) / 128)), dim3(256), 0, stream_,
+                           rows, S_pad_, (int)n, S_pad_, alpha_.as<T>() + (size_t)V_ * S_pad_);
         HIPCHK(hipGetLastError());
         return PBVI_OK;
     }
@@ -693,8 +723,10 @@ class EngineT : public EngineBase {
         if (V <= 0 || alpha == nullptr) FAIL(PBVI_EINVAL, "alpha_set: need V > 0 and a non-null array");
         HIPCHK(hipSetDevice(device_));
         const size_t rows = alpha_rows_cap(V);
-        int rc = alpha_.ensure(rows * S_pad_ * sizeof(T), &bytes_);
+        int rc = alpha_buf_.ensure(rows * S_pad_ * sizeof(T), &bytes_);
         if (rc) return rc;
+        alpha_view(alpha_buf_, 0);
+        prim_valid_ = alpha_on_primary_ = false;
         HIPCHK(hipMemsetAsync(alpha_.p, 0, alpha_.cap, stream_));
         HIPCHK(hipMemcpy2DAsync(alpha_.p, (size_t)S_pad_ * sizeof(T), alpha, (size_t)S_ * sizeof(T),
                                 (size_t)S_ * sizeof(T), (size_t)V, hipMemcpyHostToDevice, stream_));
@@ -713,21 +745,24 @@ class EngineT : public EngineBase {
         HIPCHK(hipSetDevice(device_));
         const int64_t Vn = V_ + n;
         const size_t need = alpha_rows_cap(Vn) * S_pad_ * sizeof(T);
-        if (need > alpha_.cap) {   // grow, preserving the resident rows
+        const bool plain = alpha_.p == alpha_buf_.p;          // the view starts the allocation (no rows kept free in front)
+        if (need > alpha_.cap || !plain) {   // grow (or move to a plain layout), preserving the resident rows
             DevBuf nb;
-            int rc = nb.ensure(std::max(need, alpha_.cap * 2), &bytes_);
+            int rc = nb.ensure(std::max(need, plain ? alpha_buf_.cap * 2 : need), &bytes_);
             if (rc) return rc;
             HIPCHK(hipMemsetAsync(nb.p, 0, nb.cap, stream_));
             if (V_ > 0)
                 HIPCHK(hipMemcpyAsync(nb.p, alpha_.p, (size_t)V_ * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
-            bytes_ -= (int64_t)alpha_.cap;
-            alpha_.release();
-            alpha_ = nb;
+            bytes_ -= (int64_t)alpha_buf_.cap;
+            alpha_buf_.release();
+            alpha_buf_ = nb;
+            alpha_view(alpha_buf_, 0);
         } else {
             // clear the old magnitude row's pad columns / content before it becomes a data row
             HIPCHK(hipMemsetAsync(alpha_.as<T>() + (size_t)V_ * S_pad_, 0, (size_t)S_pad_ * sizeof(T), stream_));
         }
+        prim_valid_ = alpha_on_primary_ = false;
         HIPCHK(hipMemcpy2DAsync(alpha_.as<T>() + (size_t)V_ * S_pad_, (size_t)S_pad_ * sizeof(T), alpha,
                                 (size_t)S_ * sizeof(T), (size_t)S_ * sizeof(T), (size_t)n, hipMemcpyHostToDevice, stream_));
         V_ = Vn;
@@ -1150,6 +1185,10 @@ class EngineT : public EngineBase {
         if (which < 0 || which > 1) FAIL(PBVI_EINVAL, "store_reset: bad store");
         store_rows_[which] = 0;
         if (which == 1) snz_rows_ = sbt_rows_ = 0;
+        if (which == 0) {                                    // the ids of the primary working set name rows that are gone
+            prim_valid_ = false;
+            prim_ids_.clear();
+        }
         return PBVI_OK;
     }
 
@@ -1163,16 +1202,65 @@ class EngineT : public EngineBase {
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(ids_.p, ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
         if (which == 0) {   // working alpha set := stored rows in the caller's order
-            const size_t rows = alpha_rows_cap(n);
-            if ((rc = alpha_.ensure(rows * S_pad_ * sizeof(T), &bytes_))) return rc;
-            HIPCHK(hipMemsetAsync(alpha_.as<T>() + (size_t)n * S_pad_, 0, (rows - (size_t)n) * S_pad_ * sizeof(T), stream_));
-            for (int64_t r0 = 0; r0 < n; r0 += 65535) {
-                const unsigned cnt = (unsigned)std::min<int64_t>(65535, n - r0);
-                hipLaunchKernelGGL(k_gather_rows<T>, dim3((S_pad_ + 255) / 256, cnt), dim3(256), 0, stream_,
-                                   store_[0].as<T>(), alpha_.as<T>() + (size_t)r0 * S_pad_, S_pad_, ids_.as<int32_t>() + r0);
-                HIPCHK(hipGetLastError());
+            static const bool no_prepend = getenv("PBVI_NO_ALPHA_PREPEND") != nullptr;      // debug / A-B only
+            auto gather = [&](T* dst, int64_t first, int64_t cnt) -> int {             // ids [first, first + cnt) -> dst rows
+                for (int64_t r0 = 0; r0 < cnt; r0 += 65535) {
+                    const unsigned c = (unsigned)std::min<int64_t>(65535, cnt - r0);
+                    hipLaunchKernelGGL(k_gather_rows<T>, dim3((S_pad_ + 255) / 256, c), dim3(256), 0, stream_, store_[0].as<T>(),
+                                       dst + (size_t)r0 * S_pad_, S_pad_, ids_.as<int32_t>() + first + r0);
+                    HIPCHK(hipGetLastError());
+                }
+                return PBVI_OK;
+            };
+            const int64_t pv = (int64_t)prim_ids_.size();
+            // (1) the primary set with k new rows in front of it (k = 0: the primary set again, after a small selection)
+            if (!no_prepend && prim_valid_ && n >= pv && n - pv <= prim_off_ &&
+                std::equal(prim_ids_.begin(), prim_ids_.end(), ids + (n - pv))) {
+                const int64_t k = n - pv;
+                prim_off_ -= k;
+                alpha_view(alpha_buf_, prim_off_);
+                V_ = n;                                           // the magnitude row stays where it is: row n of the new view
+                if (k > 0) {
+                    if ((rc = gather(alpha_.as<T>(), 0, k))) return rc;
+                    if ((rc = merge_magnitude_row(alpha_.as<T>(), k))) return rc;
+                    prim_ids_.insert(prim_ids_.begin(), ids, ids + k);
+                }
+                alpha_on_primary_ = true;
+                ++alpha_ver_;
+                HIPCHK(hipStreamSynchronize(stream_));
+                have_result_ = false;
+                return PBVI_OK;
             }
+            // (2) a selection much smaller than the primary set: beside it
+            if (!no_prepend && prim_valid_ && n <= 4096 && 4 * n <= pv) {
+                const size_t rows = alpha_rows_cap(n);
+                if ((rc = alpha_small_.ensure(rows * S_pad_ * sizeof(T), &bytes_))) return rc;
+                alpha_view(alpha_small_, 0);
+                alpha_on_primary_ = false;
+                HIPCHK(hipMemsetAsync(alpha_.as<T>() + (size_t)n * S_pad_, 0, (rows - (size_t)n) * S_pad_ * sizeof(T), stream_));
+                if ((rc = gather(alpha_.as<T>(), 0, n))) return rc;
+                V_ = n;
+                ++alpha_ver_;
+                if ((rc = refresh_magnitude_row())) return rc;
+                HIPCHK(hipStreamSynchronize(stream_));
+                have_result_ = false;
+                return PBVI_OK;
+            }
+            // (3) a new primary set: free rows in front (half its size again, for the sets that will extend it), the data,
+            // the magnitude row, and 256 + padding zero rows behind (the view's 256-row padding reaches further back as the
+            // view starts earlier)
+            const int64_t front = no_prepend ? 0 : std::max<int64_t>(512, n / 2);
+            const size_t rows = (size_t)front + alpha_rows_cap(n) + (no_prepend ? 0 : GEMM_BN);
+            if ((rc = alpha_buf_.ensure(rows * S_pad_ * sizeof(T), &bytes_))) return rc;
+            prim_off_ = front;
+            alpha_view(alpha_buf_, prim_off_);
+            HIPCHK(hipMemsetAsync(alpha_.as<T>() + (size_t)n * S_pad_, 0, (rows - (size_t)front - (size_t)n) * S_pad_ * sizeof(T), stream_));
+            if ((rc = gather(alpha_.as<T>(), 0, n))) return rc;
             V_ = n;
+            prim_ids_.assign(ids, ids + n);
+            prim_valid_ = !no_prepend;
+            alpha_on_primary_ = !no_prepend;
+            ++prim_layout_ver_;
             ++alpha_ver_;
             if ((rc = refresh_magnitude_row())) return rc;
             HIPCHK(hipStreamSynchronize(stream_));
@@ -1727,6 +1815,11 @@ class EngineT : public EngineBase {
         vmax_exact_ = exact != 0;
         return PBVI_OK;
     }
+    int alpha_layout(int64_t* free_rows, int64_t* layouts) override {
+        if (free_rows) *free_rows = alpha_on_primary_ ? prim_off_ : 0;
+        if (layouts) *layouts = (int64_t)prim_layout_ver_;
+        return alpha_on_primary_ ? 1 : 0;
+    }
 
     int set_tie_window(double rel) override {
         tie_rel_user_ = rel;
@@ -2107,15 +2200,36 @@ int EngineT<T>::sync_screen() {
         EngineT<float>* sc = screen_;
         int rc;
         if (screen_alpha_seen_ != alpha_ver_) {
-            const size_t rows = alpha_rows_cap(V_);
-            if ((rc = sc->alpha_.ensure(rows * S_pad_ * sizeof(float), &sc->bytes_))) return rc;
-            const int64_t n = (int64_t)V_ * S_pad_;
-            hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, alpha_.as<double>(),
-                               sc->alpha_.template as<float>(), n);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemsetAsync(sc->alpha_.template as<float>() + n, 0, (rows - (size_t)V_) * S_pad_ * sizeof(float), stream_));
-            sc->V_ = V_;
-            if ((rc = sc->refresh_magnitude_row())) return rc;
+            auto narrow = [&](const double* src, float* dst, int64_t rows) -> int {
+                const int64_t n = rows * S_pad_;
+                if (n <= 0) return PBVI_OK;
+                hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, src, dst, n);
+                HIPCHK(hipGetLastError());
+                return PBVI_OK;
+            };
+            // The screen's copy mirrors this engine's layout row for row (same free rows in front of a primary set), so a
+            // set that grew at the front costs the fp32 copy its new rows only.
+            const int64_t off = alpha_on_primary_ ? prim_off_ : 0;
+            const size_t rows_total = alpha_on_primary_ ? alpha_buf_.cap / ((size_t)S_pad_ * sizeof(double)) : alpha_rows_cap(V_);
+            if (alpha_on_primary_ && screen_layout_seen_ == prim_layout_ver_ && screen_off_seen_ >= off &&
+                sc->alpha_buf_.cap >= rows_total * S_pad_ * sizeof(float)) {
+                const int64_t k = screen_off_seen_ - off;
+                sc->alpha_view(sc->alpha_buf_, off);
+                sc->V_ = V_;
+                if ((rc = narrow(alpha_.as<double>(), sc->alpha_.template as<float>(), k))) return rc;
+                if ((rc = sc->merge_magnitude_row(sc->alpha_.template as<float>(), k))) return rc;
+            } else {
+                if ((rc = sc->alpha_buf_.ensure(rows_total * S_pad_ * sizeof(float), &sc->bytes_))) return rc;
+                sc->alpha_view(sc->alpha_buf_, off);
+                sc->V_ = V_;
+                if ((rc = narrow(alpha_.as<double>(), sc->alpha_.template as<float>(), V_))) return rc;
+                HIPCHK(hipMemsetAsync(sc->alpha_.template as<float>() + (size_t)V_ * S_pad_, 0,
+                                      (rows_total - (size_t)off - (size_t)V_) * S_pad_ * sizeof(float), stream_));
+                if ((rc = sc->refresh_magnitude_row())) return rc;
+            }
+            screen_layout_seen_ = alpha_on_primary_ ? prim_layout_ver_ : 0;      // 0: no primary layout is mirrored
+            screen_off_seen_ = off;
+            sc->prim_valid_ = sc->alpha_on_primary_ = false;                     // (the screen never selects by itself)
             sc->have_result_ = false;
             screen_alpha_seen_ = alpha_ver_;
         }
@@ -2833,6 +2947,10 @@ int pbvi_set_f64_screen(pbvi_engine_t* e, int mode) {
 int pbvi_set_value_max_exact(pbvi_engine_t* e, int exact) {
     NEED(e);
     return e->impl->set_value_max_exact(exact);
+}
+int pbvi_alpha_layout(pbvi_engine_t* e, int64_t* free_rows, int64_t* layouts) {
+    NEED(e);
+    return e->impl->alpha_layout(free_rows, layouts);
 }
 int pbvi_set_tie_window(pbvi_engine_t* e, double rel) {
     NEED(e);

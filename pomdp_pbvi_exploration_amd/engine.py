@@ -30,7 +30,7 @@ EXPORTS = [
     'pbvi_belief_update', 'pbvi_beliefs_advance', 'pbvi_beliefs_fetch', 'pbvi_beliefs_count',
     'pbvi_mdp_value_iteration', 'pbvi_set_formulation', 'pbvi_belief_walk', 'pbvi_engine_set_rto_f64', 'pbvi_backup_fetch_unique_keys', 'pbvi_assemble_rows',
     'pbvi_backup_fetch_exchange', 'pbvi_backup_store_unique',
-    'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact',
+    'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact', 'pbvi_alpha_layout',
     'pbvi_belief_walk_keys', 'pbvi_backup_fetch_value_max',
     'pbvi_backup_fetch_compact', 'pbvi_host_alloc', 'pbvi_host_free', 'pbvi_debug_gemm_dense',
     'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_set_f64_screen', 'pbvi_set_fused_projection', 'pbvi_backup_fetch_row_hashes',
@@ -102,6 +102,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_backup_fetch_value_max': (C.c_int, [vp, f64p]),
         'pbvi_belief_walk_keys': (C.c_int, [vp, C.c_int64, C.POINTER(C.c_uint64)]),
         'pbvi_set_value_max_exact': (C.c_int, [vp, C.c_int]),
+        'pbvi_alpha_layout': (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         'pbvi_alpha_store_count': (C.c_int64, [vp]),
         'pbvi_alpha_store_append': (C.c_int64, [vp, vp, C.c_int64]),
         'pbvi_alpha_select': (C.c_int, [vp, i32p, C.c_int64]),
@@ -469,6 +470,16 @@ class Engine:
         _check(self._lib.pbvi_beliefs_select(self._h, i.ctypes.data_as(C.POINTER(C.c_int32)), i.shape[0]))
         self.B = i.shape[0]
         self._resident['belief'] = i.copy()
+
+    def alpha_layout(self):
+        """``(extendable, free_rows, layouts)`` of the working alpha set (``pbvi_alpha_layout``): whether it is a store
+        selection that a new-then-old extension can grow at the front, the rows still free there, and how many times a
+        selection was gathered afresh so far."""
+        free, lay = C.c_int64(0), C.c_int64(0)
+        rc = self._lib.pbvi_alpha_layout(self._h, C.byref(free), C.byref(lay))
+        if rc < 0:
+            _check(rc)
+        return bool(rc), int(free.value), int(lay.value)
 
     def reset_store(self, which: str) -> None:
         self._resident[which] = None

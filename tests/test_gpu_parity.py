@@ -517,6 +517,67 @@ def test_value_max_over_the_belief_store_in_place(monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_working_alpha_set_grown_at_the_front_equals_an_uploaded_one(dtype):
+    """pbvi_alpha_select: a selection that is k new store rows followed by the previous selection (the solve loop's
+    new-then-old value function) is gathered into free rows in front of the resident set instead of re-gathering
+    everything; a much smaller selection in between (compute_change's fresh rows) goes beside it.  After every step the
+    engine must behave exactly as one that was handed the same rows with pbvi_alpha_set: same indices, actions and rows,
+    same value-max -- through several prepends, a small selection, exhausted free rows (fresh layout) and, for fp64
+    engines, the fp32 screen's incremental copy."""
+    m = synth.olfactory_model(H=15, W=40, R=5)
+    pool, _ = synth.alpha_set(m, 2100)
+    pool[1700] = pool[3]                                             # a tie across the old / new boundary: lower index wins
+    beliefs = synth.belief_points(m, 300, max_depth=24)
+    eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype)
+    ref = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype)
+    if dtype == 'f64':
+        eng.set_f64_screen('always')
+        ref.set_f64_screen('always')
+    eng.store_rows('alpha', pool)
+    eng.set_beliefs(beliefs)
+    ids = np.arange(0, 300, dtype=np.int32)
+
+    def check(ids):
+        eng.select_alpha(ids)
+        st = eng.run(m.gamma, True)
+        got = eng.fetch()
+        want = ref.backup_full(pool[ids], beliefs, m.gamma, belief_dominance_prune=True)
+        assert np.array_equal(got.best_alpha_ind, want.best_alpha_ind) and np.array_equal(got.actions, want.actions)
+        assert np.array_equal(got.keep, want.keep) and np.array_equal(got.index, want.index)
+        assert np.array_equal(got.unique_alpha, want.unique_alpha)
+        v1, i1 = eng.max_value_resident()
+        v2, i2 = ref.max_value_resident()
+        assert np.array_equal(v1, v2) and np.array_equal(i1, i2)
+        return st
+
+    check(ids)
+    layouts_taken = []
+    assert eng.alpha_layout() == (True, 512, 1)                      # free rows: max(512, V / 2)
+    nxt = 300
+    for k in (40, 1, 200, 300, 0, 500, 700):                         # 300 + ... : the free rows (512) run out on the way
+        if k == 200:                                                 # a small selection in between leaves the big one alone
+            small = np.array([5, 1700, 3, 77], dtype=np.int32)
+            eng.select_alpha(small)
+            v, i = eng.max_value_resident()
+            vr, ir = ref.max_value(pool[small], beliefs)
+            assert np.array_equal(v, vr) and np.array_equal(i, ir)
+            assert not np.any(i == 2)                                # rows 1 and 2 of the small set are equal: the later never wins
+            assert eng.alpha_layout()[0] is False                    # beside the big selection, which is untouched:
+        ids = np.concatenate([np.arange(nxt, nxt + k, dtype=np.int32), ids])
+        nxt += k
+        check(ids)
+        layouts_taken.append(eng.alpha_layout())
+    # 40, 1, 200 fit the 512 free rows (271 left); 300 does not: fresh layout (841 rows: 512 free... max(512, 420)); 0 and
+    # 500 fit; 700 does not
+    assert layouts_taken == [(True, 472, 1), (True, 471, 1), (True, 271, 1), (True, 512, 2), (True, 512, 2), (True, 12, 2),
+                             (True, 1020, 3)]
+    # any other selection (not an extension) starts a fresh layout
+    check(ids[::-1].copy())
+    eng.close()
+    ref.close()
+
+
 @pytest.mark.parametrize('n_alpha', [5, 16, 17, 33, 48, 49, 64, 65, 130])
 def test_value_max_column_tile_widths(n_alpha):
     """The fp64 tile engine's 16 / 32 / 48 / 64 / 128-column variants (fp64 engines: every width; fp32 engines: up to 64
