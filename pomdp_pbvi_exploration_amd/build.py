@@ -30,7 +30,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', 'hipcc')
     cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared',
-           '-Wall', '-Wno-unused-function',
+           '-Wall', '-Wno-unused-function', '-pthread',
            *[os.path.join(CSRC, s) for s in SOURCES], '-o', LIB_PATH]
     if verbose:
         print('[build]', ' '.join(cmd), flush=True)

@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "backup_kernels.h"
@@ -44,6 +46,33 @@ void set_error(const std::string& msg) { g_err = msg; }
         set_error(msg);        \
         return (code);         \
     } while (0)
+
+// Host-to-host copy of a result out of the pinned bounce buffer into the caller's (pageable) memory.  One thread moves
+// ~12-15 GB/s into cold pages -- for the 123 MB of an expanded alpha' matrix that, not the
+// PCIe transfer (50 GB/s into pinned memory), was the time of the call -- so large copies are split over a few threads.
+// Threads are started per call (~0.1 ms): below 32 MB that costs more than it saves (measured on the solve loop's 6-8 MB
+// copies: 2.68 -> 2.84 s per 300 expansions), so only the bulk fetches take this path (123 MB: 6.2 -> 4.0 ms).
+static void host_copy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t kMinPerThread = (size_t)16 << 20;
+    static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    static const unsigned cap = getenv("PBVI_COPY_THREADS") ? (unsigned)std::max(1, atoi(getenv("PBVI_COPY_THREADS"))) : 4u;
+    const unsigned ways = (unsigned)std::min<size_t>(std::min(cap, hw), bytes / kMinPerThread);
+    if (ways <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t part = ((bytes / ways) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    th.reserve(ways - 1);
+    for (unsigned w = 1; w < ways; ++w) {
+        const size_t o = (size_t)w * part;
+        if (o >= bytes) break;
+        const size_t n = std::min(part, bytes - o);
+        th.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, n); });
+    }
+    std::memcpy(dst, src, std::min(part, bytes));
+    for (auto& t : th) t.join();
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -1139,7 +1168,7 @@ class EngineT : public EngineBase {
             for (int c = 0; c < n_chunks; ++c) {
                 const int64_t r0 = c ? chunk_end[c - 1] : 0;
                 HIPCHK(hipEventSynchronize(walk_ev_[2 * c + 1]));
-                std::memcpy((char*)out + (size_t)r0 * S_ * sizeof(double), (const char*)host_stage_ + (size_t)r0 * S_ * sizeof(double),
+                host_copy((char*)out + (size_t)r0 * S_ * sizeof(double), (const char*)host_stage_ + (size_t)r0 * S_ * sizeof(double),
                             (size_t)(chunk_end[c] - r0) * S_ * sizeof(double));
             }
             HIPCHK(hipStreamSynchronize(stream_));
@@ -1378,7 +1407,7 @@ class EngineT : public EngineBase {
     }
     int out_flush() {
         HIPCHK(hipStreamSynchronize(stream_));
-        for (const OutItem& it : out_items_) std::memcpy(it.dst, (const char*)host_stage_ + it.off, it.bytes);
+        for (const OutItem& it : out_items_) host_copy(it.dst, (const char*)host_stage_ + it.off, it.bytes);
         out_items_.clear();
         out_used_ = 0;
         return PBVI_OK;
