@@ -14,9 +14,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "backup_kernels.h"
@@ -48,31 +51,80 @@ void set_error(const std::string& msg) { g_err = msg; }
     } while (0)
 
 // Host-to-host copy of a result out of the pinned bounce buffer into the caller's (pageable) memory.  One thread moves
-// ~12-15 GB/s into cold pages -- for the 123 MB of an expanded alpha' matrix that, not the
-// PCIe transfer (50 GB/s into pinned memory), was the time of the call -- so large copies are split over a few threads.
-// Threads are started per call (~0.1 ms): below 32 MB that costs more than it saves (measured on the solve loop's 6-8 MB
-// copies: 2.68 -> 2.84 s per 300 expansions), so only the bulk fetches take this path (123 MB: 6.2 -> 4.0 ms).
-static void host_copy(void* dst, const void* src, size_t bytes) {
-    constexpr size_t kMinPerThread = (size_t)16 << 20;
-    static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    static const unsigned cap = getenv("PBVI_COPY_THREADS") ? (unsigned)std::max(1, atoi(getenv("PBVI_COPY_THREADS"))) : 4u;
-    const unsigned ways = (unsigned)std::min<size_t>(std::min(cap, hw), bytes / kMinPerThread);
-    if (ways <= 1) {
-        std::memcpy(dst, src, bytes);
-        return;
+// ~12-15 GB/s into cold pages -- for the 24 MB of a belief walk or the 123 MB of an expanded alpha' matrix that, not the
+// PCIe transfer (50 GB/s into pinned memory), was the time of the call -- so copies of a few MB and more are split over a
+// small pool of worker threads that lives as long as the process (started on first use, parked on a condition variable;
+// starting threads per call cost ~0.1 ms each, more than the solve loop's 6-8 MB copies gain).
+class CopyPool {
+public:
+    static CopyPool& get() {
+        static CopyPool* pool = new CopyPool();              // leaked on purpose: no destructor order to get wrong at exit
+        return *pool;
     }
-    const size_t part = ((bytes / ways) + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    th.reserve(ways - 1);
-    for (unsigned w = 1; w < ways; ++w) {
-        const size_t o = (size_t)w * part;
-        if (o >= bytes) break;
-        const size_t n = std::min(part, bytes - o);
-        th.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, n); });
+    void copy(void* dst, const void* src, size_t bytes) {
+        constexpr size_t kMinPart = (size_t)2 << 20;
+        const unsigned ways = (unsigned)std::min<size_t>(workers_.size() + 1, bytes / kMinPart);
+        if (ways <= 1 || getpid() != pid_) {                 // (a forked child has the object but not its threads)
+            std::memcpy(dst, src, bytes);
+            return;
+        }
+        const size_t part = ((bytes / ways) + 4095) & ~(size_t)4095;
+        unsigned posted = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (unsigned w = 1; w < ways; ++w) {
+                const size_t o = (size_t)w * part;
+                if (o >= bytes) break;
+                tasks_.push_back(Task{static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, std::min(part, bytes - o)});
+                ++posted;
+            }
+            pending_ += posted;
+        }
+        cv_.notify_all();
+        std::memcpy(dst, src, std::min(part, bytes));
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
     }
-    std::memcpy(dst, src, std::min(part, bytes));
-    for (auto& t : th) t.join();
-}
+
+private:
+    struct Task {
+        char* dst;
+        const char* src;
+        size_t n;
+    };
+    CopyPool() {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        unsigned n = getenv("PBVI_COPY_THREADS") ? (unsigned)std::max(1, atoi(getenv("PBVI_COPY_THREADS"))) : 4u;
+        n = std::min(n, hw);
+        for (unsigned i = 1; i < n; ++i) {
+            workers_.emplace_back([this] { run(); });
+            workers_.back().detach();
+        }
+    }
+    void run() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return !tasks_.empty(); });
+                t = tasks_.back();
+                tasks_.pop_back();
+            }
+            std::memcpy(t.dst, t.src, t.n);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    const pid_t pid_ = getpid();
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::vector<Task> tasks_;
+    size_t pending_ = 0;
+    std::vector<std::thread> workers_;
+};
+static void host_copy(void* dst, const void* src, size_t bytes) { CopyPool::get().copy(dst, src, bytes); }
 
 struct DevBuf {
     void* p = nullptr;
