@@ -120,7 +120,8 @@ __global__ void k_build_klists_f64(const uint8_t* __restrict__ nzA, const uint8_
 }
 
 // Longest lists first: blocks are dispatched in index order, so handing out the heavy tile pairs first leaves the
-// light ones to fill the tail (LPT scheduling).  One block; counting sort by list length (<= kt32), stable.
+// light ones to fill the tail (LPT scheduling).  One block; counting sort by list length (<= kt32); the order inside a
+// bin is whatever the atomics give -- it only decides which of two equally long pairs is dispatched first.
 __global__ void k_order_pairs_f64(const int* __restrict__ kcount, int pairs, int kt32, int* __restrict__ hist /* [kt32+2] zeroed */,
                                   int* __restrict__ order) {
     constexpr int LBINS = 4096;
