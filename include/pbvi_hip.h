@@ -376,8 +376,12 @@ int pbvi_set_f64_screen(pbvi_engine_t* e, int mode);
 /*
  * fp32 scoring with one reachable state per (s, a) (every large model of the reference): 1 (default) = the score GEMM
  * generates the Gamma tiles (src/pomdp.py:1485-1491) on the way into LDS instead of reading a projected copy from HBM;
- * 0 = project first (k_project), then multiply -- the same scores bit for bit, kept for A/B measurements.  No effect
- * where the fused path does not apply (R > 1, fp64 scoring, belief-side formulation, dense mode).
+ * 0 = project first (k_project), then multiply -- the same scores bit for bit, kept for A/B measurements.
+ * 2 = also with 2..7 reachable states per (s, a) (the padded-ELL SpMM inside the operand staging; bit-identical again, but
+ * measured SLOWER than projecting first at |S| = 30000, R = 5 -- five shifted alpha windows per K step cost more L2 /
+ * Infinity-Cache traffic than reading the projected tile once -- so it is never chosen automatically).  No effect where
+ * the fused path does not apply (R > 7, successor maps without grid structure, fp64 scoring, belief-side formulation,
+ * dense mode).
  */
 int pbvi_set_fused_projection(pbvi_engine_t* e, int enable);
 

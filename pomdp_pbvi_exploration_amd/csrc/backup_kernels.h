@@ -81,7 +81,9 @@ hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gam
                           const uint8_t* need /* [A*O][k_tiles] or nullptr = all */, int k_tiles, hipStream_t st,
                           const uint8_t* mat = nullptr /* [ceil(rows/256)]: 1 = write this 256-row tile of Gamma; the
                                                           others are generated inside the fused score GEMM */,
-                          const int* vlist = nullptr, int n_vlist = 0 /* device list of the 4-row alpha blocks to visit */);
+                          const int* vlist = nullptr, int n_vlist = 0 /* device list of the 4-row alpha blocks to visit */,
+                          const int32_t* irr = nullptr /* [A][k_tiles]: K tiles written whatever `mat` says (the fused GEMM
+                                                          for R > 1 reads the tiles it does not generate) */);
 hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB /* [AO+1][k_tiles] */, int AO, int V,
                              int k_tiles, uint8_t* need, hipStream_t st);
 
@@ -139,6 +141,13 @@ struct RefineWork {
     int* kcountW = nullptr;
     const int32_t* in_ptr = nullptr;     // inverse transition lists (engine.hip::build_inverse_lists)
     const int32_t* in_src = nullptr;
+    // Level-1 screen of the per-entry pass (PROJ, fp32 engines whose Gamma rows are in HBM): the candidates' scores
+    // are first re-summed in fp64 from the PROJECTED fp32 rows the GEMM read -- |Gamma_f32 - Gamma| <= l1_rel * Gamma(max|alpha|)
+    // element-wise, so b . Gamma_f32 is within l1_rel * magnitude of the exact score -- and only candidates that this
+    // ~100x tighter bound cannot separate are re-scored from alpha, RTO and the successor lists (R gathers per state).
+    const float* gam = nullptr;          // [A*O*V + ...][ldg] projected rows, group-major (row g * V + v); nullptr = off
+    int ldg = 0;
+    double l1_rel = 0.0;                 // (R + 4) * 2^-24: R products, R adds, the scale, gamma's own rounding, slack
 };
 
 // fp64 re-decision of queued near-ties.  PROJ: scores are b . Gamma[a,o,v,:]; else b . alpha[v,:]
@@ -178,11 +187,12 @@ template <typename T>
 hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, const int* chain_steps,
                          const double* best_score, const double* err, double* rdot, double* rdot_err, int32_t* action,
                          int32_t* aqueue, int* aqcount, hipStream_t st, double tol_extra = 0.0);
+constexpr int ACTION_SPLIT = 8;          // parts each exact dot of the action refinement is cut into (val_exact: [B][A][1+O][ACTION_SPLIT])
 template <typename T>
 hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv, double gamma,
                                 const int32_t* btl, const int32_t* btc, const int32_t* aqueue, const int* aqcount,
                                 const double* rdot, const double* rdot_err, const int32_t* best_v,
-                                const double* best_score, const double* err, double* val_exact /* [B][A][1+O] scratch */,
+                                const double* best_score, const double* err, double* val_exact /* [B][A][1+O][ACTION_SPLIT] scratch */,
                                 int32_t* action, hipStream_t st);
 
 // K3: out[u][s] = ER[s,a*] + sum_o gamma * sum_r rto[a*][o][r][s] * alpha[v*[b,a*,o]][rs[a*][r][s]], b = rows[u]

@@ -8,6 +8,7 @@
 // results are deterministic run to run.
 #include "backup_kernels.h"
 
+#include <cstdlib>
 #include <limits>
 
 namespace pbvi {
@@ -35,7 +36,8 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 struct TileList {
     const int32_t* list;
     int count;
-    __device__ __forceinline__ int at(int i) const { return list ? list[i] : i; }
+    int first = 0;                       // list == nullptr: the tiles are first, first + 1, ...
+    __device__ __forceinline__ int at(int i) const { return list ? list[i] : first + i; }
 };
 
 // Partial (this thread's share) of  sum_s b[s] * gamma * sum_r rto[a][o][r][s] * alpha_v[rs[a][r][s]]  in f64,
@@ -91,6 +93,34 @@ __device__ __forceinline__ double plain_dot_partial(const T* __restrict__ brow, 
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
+// Level-1 screen: fp64 sums of  b[s] * G_c[s]  for up to 4 projected fp32 rows at once over a tile list (the belief is
+// read once); blockDim.x = 256 = 8 half-waves, half-wave q takes list entries q, q+8, ...; every thread gets the 4 sums.
+template <typename T>
+__device__ __forceinline__ void gamma_dots4(const T* __restrict__ brow, const float* const (&grow)[4], TileList tl,
+                                            double (&out)[4], double* sh /* >= 16 doubles */) {
+    const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = q; i0 < tl.count; i0 += 16) {            // two list entries per half-wave in flight
+        const int i1 = i0 + 8;
+        const bool ok1 = i1 < tl.count;
+        const int s0 = tl.at(i0) * 32 + l, s1 = tl.at(ok1 ? i1 : i0) * 32 + l;
+        const double b0 = (double)brow[s0], b1 = ok1 ? (double)brow[s1] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += b0 * (double)grow[c][s0] + b1 * (double)grow[c][s1];
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = wave_sum(acc[c]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sh[wid * 4 + c] = acc[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = ((sh[c] + sh[4 + c]) + sh[8 + c]) + sh[12 + c];
+}
+
 // ------------------------------------------------------------------------- //
 // support mask of RTO (engine creation)
 // ------------------------------------------------------------------------- //
@@ -116,11 +146,14 @@ hipError_t launch_support(ModelView<T> mv, uint8_t* sup, hipStream_t st) {
 // One thread per state s (coalesced), 4 alpha-vectors x 4 observations per pass so
 // every gathered alpha value and every table load is reused from registers.
 // ------------------------------------------------------------------------- //
-template <typename T>
+template <typename T, int OB /* observations per pass: min(O, 4) */>
 __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView<T> mv, T gamma,
                           T* __restrict__ gam, int ldg, const uint8_t* __restrict__ need, int k_tiles,
                           const uint8_t* __restrict__ mat /* per 256-row tile of Gamma: write it? (nullptr = all) */,
-                          const int* __restrict__ vlist /* blocks of 4 alpha rows to visit (nullptr = blockIdx.y) */) {
+                          const int* __restrict__ vlist /* blocks of 4 alpha rows to visit (nullptr = blockIdx.y) */,
+                          const int32_t* __restrict__ irr /* [A][k_tiles]: K tiles written whatever `mat` says (fused GEMM, R > 1:
+                                                             it reads the tiles it cannot generate), or nullptr */,
+                          int nx, int ny, int tile_x, int tile_y /* 1-D grid in L2-tiled order (see below); tile_x <= 0: 3-D grid */) {
 #pragma clang fp contract(off)   // einsum then scale: sum_r (rto*alpha), one rounding per op, as the reference
     // NS consecutive states per thread = 16 bytes of every table load and Gamma store (float: 4, double: 2; S_pad is a
     // multiple of 32), 4 alpha-vectors x up to 4 observations per pass: 16 NS-wide accumulators.  (With 4 doubles per
@@ -129,24 +162,70 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
     constexpr int NS = 16 / (int)sizeof(T);
     typedef T TN __attribute__((ext_vector_type(NS)));
     typedef int IN __attribute__((ext_vector_type(NS)));
-    const int s = (blockIdx.x * 256 + threadIdx.x) * NS;
+    // Block -> (state chunk x, alpha block y, action a).  With a list of alpha blocks (the fused GEMM's leftovers) the grid
+    // is (x, list entry, a).  Otherwise the grid is one-dimensional and walked in an L2-TILED order: an XCD (blocks are
+    // dealt round-robin over the 8 XCDs, each with its own 4 MiB L2) takes a contiguous eighth of the sequence
+    //   for x-group (tile_x state chunks) / for y-group (tile_y alpha blocks) / for y / for x / for a
+    // so that the alpha segments it gathers from -- the chunk's own states and the +-W rows a grid move reaches, for
+    // every successor slot and every action -- and the tables of those state chunks stay in ITS L2 while they are
+    // re-used: with (x, y, a) dealt out in launch order the kernel fetched 1.97 GB to write 1.45 GB at |S| = 30000,
+    // R = 5 (16 passes over the alpha set instead of 1; PMC, profiles/r03_*).
+    int xb, yb, a;
+    if (vlist != nullptr || tile_x <= 0) {
+        xb = blockIdx.x;
+        yb = vlist != nullptr ? vlist[blockIdx.y] : (int)blockIdx.y;
+        a = blockIdx.z;
+    } else {
+        const int nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qq = nb >> 3, rr = nb & 7;
+        int L = ((xcd < rr) ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+        const int A = mv.A;
+        const int nxg = (nx + tile_x - 1) / tile_x, nyg = (ny + tile_y - 1) / tile_y;
+        const int full_x = (nxg - 1) * tile_x * ny * A;
+        int xg, xw;
+        if (L < full_x) {
+            xg = L / (tile_x * ny * A);
+            L -= xg * (tile_x * ny * A);
+            xw = tile_x;
+        } else {
+            xg = nxg - 1;
+            L -= full_x;
+            xw = nx - tile_x * (nxg - 1);
+        }
+        const int full_y = (nyg - 1) * tile_y * xw * A;
+        int yg;
+        if (L < full_y) {
+            yg = L / (tile_y * xw * A);
+            L -= yg * (tile_y * xw * A);
+        } else {
+            yg = nyg - 1;
+            L -= full_y;
+        }
+        const int y_in = L / (xw * A);
+        L -= y_in * (xw * A);
+        xb = xg * tile_x + L / A;
+        a = L % A;
+        yb = yg * tile_y + y_in;
+    }
+    const int s = (xb * 256 + threadIdx.x) * NS;
     if (s >= mv.S_pad) return;
-    const int v0 = (vlist != nullptr ? vlist[blockIdx.y] : (int)blockIdx.y) * 4;
-    const int a = blockIdx.z;
+    const int v0 = yb * 4;
     const int nv = (V - v0) < 4 ? (V - v0) : 4;
     const int kt = s >> 5;                                  // GEMM K tile of these states (32 states per tile)
+    const bool irr_here = irr != nullptr && irr[(int64_t)a * k_tiles + kt] != 0;
     TN zero;
 #pragma unroll
     for (int j = 0; j < NS; ++j) zero[j] = T(0);
-    for (int o0 = 0; o0 < mv.O; o0 += 4) {
-        const int no = (mv.O - o0) < 4 ? (mv.O - o0) : 4;
+    for (int o0 = 0; o0 < mv.O; o0 += OB) {
+        const int no = (mv.O - o0) < OB ? (mv.O - o0) : OB;
         // Gamma tiles the score GEMM never reads (no RTO support, or no belief mass in any row
         // block) are not computed or written: `need` is exactly the GEMM's tile-list criterion.
-        bool want[4] = {true, true, true, true};
+        bool want[OB];
+#pragma unroll
+        for (int oj = 0; oj < OB; ++oj) want[oj] = true;
         if (need != nullptr && v0 + nv < V) {              // the magnitude row (last of the V rows) is always written:
             bool any = false;                               // the tail tile it lives in is listed for every group's support
 #pragma unroll
-            for (int oj = 0; oj < 4; ++oj) {
+            for (int oj = 0; oj < OB; ++oj) {
                 want[oj] = (oj < no) && need[((int64_t)a * mv.O + o0 + oj) * k_tiles + kt];
                 any |= want[oj];
             }
@@ -155,26 +234,26 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
         if (mat != nullptr && v0 + nv < V) {               // tiles the fused GEMM generates itself are not projected
             bool any = false;
 #pragma unroll
-            for (int oj = 0; oj < 4; ++oj) {
+            for (int oj = 0; oj < OB; ++oj) {
                 const int64_t r0 = ((int64_t)a * mv.O + o0 + oj) * (V - 1) + v0;
-                want[oj] = want[oj] && (oj < no) && (mat[r0 >> 8] | mat[(r0 + nv - 1) >> 8]);
+                want[oj] = want[oj] && (oj < no) && (irr_here || (mat[r0 >> 8] | mat[(r0 + nv - 1) >> 8]));
                 any |= want[oj];
             }
             if (!any) continue;
         }
-        TN acc[4][4];
+        TN acc[4][OB];
 #pragma unroll
         for (int vj = 0; vj < 4; ++vj)
 #pragma unroll
-            for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = zero;
+            for (int oj = 0; oj < OB; ++oj) acc[vj][oj] = zero;
         for (int r = 0; r < mv.R; ++r) {
             const IN idx = *(const IN*)(mv.rs + ((int64_t)a * mv.R + r) * mv.S_pad + s);
             bool contig = true;
 #pragma unroll
             for (int j = 1; j < NS; ++j) contig = contig && (idx[j] == idx[0] + j);
-            TN w[4];
+            TN w[OB];
 #pragma unroll
-            for (int oj = 0; oj < 4; ++oj)
+            for (int oj = 0; oj < OB; ++oj)
                 w[oj] = (oj < no && want[oj]) ? *(const TN*)(mv.rto + (((int64_t)a * mv.O + o0 + oj) * mv.R + r) * mv.S_pad + s)
                                                : zero;
 #pragma unroll
@@ -185,7 +264,11 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
                     // (element-aligned) load instead of NS gathers
                     TN av;
                     if (contig) {
+#if defined(PBVI_PROJ_EXP) && PBVI_PROJ_EXP == 1       // diagnosis: aligned loads only (wrong results, timing only)
+                        const T* p = arow + (idx[0] & ~3);
+#else
                         const T* p = arow + idx[0];
+#endif
 #pragma unroll
                         for (int j = 0; j < NS; ++j) av[j] = p[j];
                     } else {
@@ -193,34 +276,50 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
                         for (int j = 0; j < NS; ++j) av[j] = arow[idx[j]];
                     }
 #pragma unroll
-                    for (int oj = 0; oj < 4; ++oj) acc[vj][oj] = acc[vj][oj] + w[oj] * av;
+                    for (int oj = 0; oj < OB; ++oj) acc[vj][oj] = acc[vj][oj] + w[oj] * av;
                 }
             }
         }
 #pragma unroll
         for (int vj = 0; vj < 4; ++vj)
 #pragma unroll
-            for (int oj = 0; oj < 4; ++oj)
+            for (int oj = 0; oj < OB; ++oj)
                 if (vj < nv && oj < no && want[oj]) {
                     const int64_t ao = (int64_t)a * mv.O + o0 + oj;
                     const int v = v0 + vj;
                     // alpha rows -> group-major rows; the magnitude row (v == V-1 of the Vt rows) -> tail
                     const int64_t row = (v < V - 1) ? ao * (V - 1) + v : (int64_t)mv.A * mv.O * (V - 1) + ao;
-                    if (mat == nullptr || mat[row >> 8]) *(TN*)(gam + row * ldg + s) = gamma * acc[vj][oj];
+                    if (mat == nullptr || irr_here || mat[row >> 8]) *(TN*)(gam + row * ldg + s) = gamma * acc[vj][oj];
                 }
     }
 }
 
 template <typename T>
 hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg,
-                          const uint8_t* need, int k_tiles, hipStream_t st, const uint8_t* mat, const int* vlist, int n_vlist) {
+                          const uint8_t* need, int k_tiles, hipStream_t st, const uint8_t* mat, const int* vlist, int n_vlist,
+                          const int32_t* irr) {
     if (V <= 0) return hipSuccess;
     if (vlist != nullptr && n_vlist <= 0) return hipSuccess;
     constexpr int NS = 16 / (int)sizeof(T);
-    dim3 grid((mv.S_pad / NS + 255) / 256, vlist != nullptr ? n_vlist : (V + 3) / 4, mv.A);
+    const int nx = (mv.S_pad / NS + 255) / 256, ny = (V + 3) / 4;
+    // L2 tiles: 4 state chunks x 6 actions of tables (~0.5 MB each) + 32 alpha blocks x 4 chunks x 16 KiB of alpha
+    static const int tile_x = getenv("PBVI_PROJ_TILE_X") ? atoi(getenv("PBVI_PROJ_TILE_X")) : 4;
+    static const int tile_y = getenv("PBVI_PROJ_TILE_Y") ? atoi(getenv("PBVI_PROJ_TILE_Y")) : 32;
+    const int64_t total = (int64_t)nx * ny * mv.A;
+    // observations per pass = accumulator rows per alpha-vector: exactly O when O < 4 (16 fewer VGPRs per missing one)
+    auto launch = [&](dim3 grid, int tx, int ty) {
+        switch (mv.O < 4 ? mv.O : 4) {
+            case 1: hipLaunchKernelGGL((k_project<T, 1>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty); break;
+            case 2: hipLaunchKernelGGL((k_project<T, 2>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty); break;
+            case 3: hipLaunchKernelGGL((k_project<T, 3>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty); break;
+            default: hipLaunchKernelGGL((k_project<T, 4>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty); break;
+        }
+        return hipGetLastError();
+    };
+    if (vlist == nullptr && tile_x > 0 && tile_y > 0 && total <= 0x7fffffff) return launch(dim3((unsigned)total), tile_x, tile_y);
+    dim3 grid(nx, vlist != nullptr ? n_vlist : ny, mv.A);
     if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_project<T>, grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist);
-    return hipGetLastError();
+    return launch(grid, 0, 0);
 }
 
 // need[g][kt]: must Gamma's rows of group g be computed for K tile kt?  Yes iff some 256-row belief block
@@ -617,7 +716,102 @@ __global__ void k_refine(SlabView<TS> sv, int V, int G, const int32_t* __restric
     int bestidx = 0x7fffffff;
     int slot = -1;                                           // >= 0 once this entry hands candidates to the work list
     if (tid == 0) sh_slot = -1;
-    for (int v0 = 0; v0 < V; v0 += 256) {
+    // exact scores of cand[0 .. ncand): first maximum into (bestval, bestidx), per wave
+    auto score_exact = [&](int ncand) {
+        if (ncand <= 2) {
+            // the common case (a runner-up inside the window): all 256 threads on one dot at a time -- a quarter of
+            // the latency of giving each candidate to a single wave
+            const TileList tl{L, n_tiles};
+            for (int c = 0; c < ncand; ++c) {
+                const int vv = cand[c];
+                const T* arow = alpha + (int64_t)vv * lda;
+                const double part = PROJ ? proj_dot_partial(brow, arow, mv, a, o, gamma, tl)
+                                         : plain_dot_partial(brow, arow, mv.S, tl);
+                const double tot = block_sum(part, red);
+                if (tot > bestval) {                         // every wave tracks the same (value, index)
+                    bestval = tot;
+                    bestidx = vv;
+                }
+            }
+        } else {
+            for (int c = wid; c < ncand; c += 4) {           // one candidate per wave, ascending v within a wave
+                const int vv = cand[c];
+                const double tot = refine_wave_dot<T, PROJ>(brow, alpha + (int64_t)vv * lda, mv, a, o, gamma, L, n_tiles, lane);
+                if (tot > bestval) {
+                    bestval = tot;
+                    bestidx = vv;
+                }
+            }
+        }
+    };
+    bool settled = false;                                    // the level-1 screen took the entry (block-uniform)
+    if constexpr (PROJ && sizeof(T) == 4) {
+        if (work.gam != nullptr && !loverflow) {          // (an overflowed list names tiles nobody projected)
+            // -- collect the entry's candidates over all chunks of V (ascending v); more than L1_CAP: the paths below
+            constexpr int L1_CAP = 32;
+            __shared__ int c1[L1_CAP];
+            __shared__ double s1[L1_CAP];
+            __shared__ double l1red[16];
+            __shared__ int n1_sh, n2_sh;
+            if (tid == 0) n1_sh = 0;
+            __syncthreads();
+            for (int v0 = 0; v0 < V; v0 += 256) {
+                const int v = v0 + tid;
+                int flag = 0;
+                if (v < V) flag = ((double)sv.score(b, g, V, v) >= thr) ? 1 : 0;
+                const unsigned long long mask = __ballot(flag);
+                if (lane == 0) wcount[wid] = __popcll(mask);
+                __syncthreads();
+                int base = n1_sh;
+                for (int w = 0; w < wid; ++w) base += wcount[w];
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                if (flag && pos < L1_CAP) c1[pos] = v;
+                __syncthreads();
+                if (tid == 0) n1_sh += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+                __syncthreads();
+            }
+            const int n1 = n1_sh;
+            if (n1 <= L1_CAP && n1 > 0) {
+                if (tid == 0 && cand_total != nullptr) atomicAdd(cand_total, n1);
+                const TileList tl{L, n_tiles};
+                for (int c0 = 0; c0 < n1; c0 += 4) {
+                    const float* rows[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        rows[j] = work.gam + ((int64_t)g * V + c1[c0 + j < n1 ? c0 + j : c0]) * work.ldg;
+                    double d[4];
+                    gamma_dots4<T>(brow, rows, tl, d, l1red);
+                    if (tid == 0)
+                        for (int j = 0; j < 4 && c0 + j < n1; ++j) s1[c0 + j] = d[j];
+                }
+                __syncthreads();
+                const double mag = fmax(fabs(m), fabs(sv.magnitude(b, g, G, V)));
+                const double E2 = work.l1_rel * mag;
+                if (tid == 0) {
+                    double m1 = s1[0];
+                    for (int c = 1; c < n1; ++c) m1 = s1[c] > m1 ? s1[c] : m1;
+                    int n2 = 0, keep1 = 0;
+                    for (int c = 0; c < n1; ++c)
+                        if (s1[c] >= m1 - 2.0 * E2) {
+                            cand[n2++] = c1[c];
+                            keep1 = c;
+                        }
+                    n2_sh = n2;
+                    if (n2 == 1) {                           // separated: the exact maximum is this one (within E2 of s1)
+                        best_v[e] = c1[keep1];
+                        best_score[e] = s1[keep1];
+                        err[e] = E2;
+                    }
+                }
+                __syncthreads();
+                const int n2 = n2_sh;
+                if (n2 == 1) return;
+                score_exact(n2);                             // what the projected rows cannot separate: from the operands
+                settled = true;
+            }
+        }
+    }
+    for (int v0 = 0; v0 < V && !settled; v0 += 256) {
         const int v = v0 + tid;
         int flag = 0;
         if (v < V) flag = ((double)sv.score(b, g, V, v) >= thr) ? 1 : 0;
@@ -671,31 +865,7 @@ __global__ void k_refine(SlabView<TS> sv, int V, int G, const int32_t* __restric
             }
         }
         __syncthreads();
-        if (ncand <= 2) {
-            // the common case (a runner-up inside the window): all 256 threads on one dot at a time -- a quarter of
-            // the latency of giving each candidate to a single wave
-            const TileList tl{L, n_tiles};
-            for (int c = 0; c < ncand; ++c) {
-                const int vv = cand[c];
-                const T* arow = alpha + (int64_t)vv * lda;
-                const double part = PROJ ? proj_dot_partial(brow, arow, mv, a, o, gamma, tl)
-                                         : plain_dot_partial(brow, arow, mv.S, tl);
-                const double tot = block_sum(part, red);
-                if (tot > bestval) {                         // every wave tracks the same (value, index)
-                    bestval = tot;
-                    bestidx = vv;
-                }
-            }
-        } else {
-            for (int c = wid; c < ncand; c += 4) {           // one candidate per wave, ascending v within a wave
-                const int vv = cand[c];
-                const double tot = refine_wave_dot<T, PROJ>(brow, alpha + (int64_t)vv * lda, mv, a, o, gamma, L, n_tiles, lane);
-                if (tot > bestval) {
-                    bestval = tot;
-                    bestidx = vv;
-                }
-            }
-        }
+        score_exact(ncand);
     }
     // first maximum over the four waves: largest value, then smallest index
     if (lane == 0) {
@@ -1049,9 +1219,11 @@ hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0
     return hipGetLastError();
 }
 
-// Exact (f64) value of every candidate action of a flagged belief.  One block per (queued belief, action, term):
+// Exact (f64) value of every candidate action of a flagged belief.  One block per (queued belief, action, term, part):
 // term 0 is b . ER[:,a], term 1 + o the score of observation o -- the 1 + O dots of an action used to run one after the
-// other in one block (60 us of dependent latency for two dozen beliefs); k_action_final adds them in that same order.
+// other in one block (60 us of dependent latency for two dozen beliefs) -- and each dot is cut into ACTION_SPLIT parts of
+// the belief's tile list (with five successors per state one block per dot was 117 us for 24 beliefs: a chain of ~90
+// dependent gather rounds); k_action_final adds parts, then terms, in a fixed order.
 template <typename T>
 __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
                                 ModelView<T> mv, double gamma, const int32_t* __restrict__ btl,
@@ -1063,7 +1235,7 @@ __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __r
     __shared__ int cand_sh;
     const int n_q = *aqcount;
     const int terms = 1 + mv.O;
-    const int a = blockIdx.y / terms, term = blockIdx.y % terms, tid = threadIdx.x;
+    const int a = blockIdx.y / terms, term = blockIdx.y % terms, tid = threadIdx.x, part_i = blockIdx.z;
     for (int q = blockIdx.x; q < n_q; q += gridDim.x) {
         const int b = aqueue[q];
         __syncthreads();
@@ -1085,23 +1257,27 @@ __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __r
             cand_sh = (va + Ea >= lo) ? 1 : 0;
         }
         __syncthreads();
-        double* part = val_parts + ((int64_t)b * mv.A + a) * terms + term;
+        double* part = val_parts + (((int64_t)b * mv.A + a) * terms + term) * ACTION_SPLIT + part_i;
         if (!cand_sh) {
             if (tid == 0) *part = -std::numeric_limits<double>::infinity();
             continue;
         }
         const T* brow = bel + (int64_t)b * ldb;
         const int k_tiles = mv.S_pad >> 5;
-        const TileList tl{btl ? btl + (int64_t)b * k_tiles : nullptr, btl ? btc[b] : k_tiles};
+        const int n_all = btl ? btc[b] : k_tiles;
+        const int per = (n_all + ACTION_SPLIT - 1) / ACTION_SPLIT;
+        const int t0 = part_i * per < n_all ? part_i * per : n_all, t1 = t0 + per < n_all ? t0 + per : n_all;
+        const TileList tl{btl ? btl + (int64_t)b * k_tiles + t0 : nullptr, t1 - t0, btl ? 0 : t0};
         double v;
         if (term == 0) {
             v = block_sum(plain_dot_partial(brow, mv.er + (int64_t)a * mv.S_pad, mv.S, tl), red);
         } else {
             const int o = term - 1;
             const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
-            v = best_score[e];
             if (err[e] > 0.0)                                       // block-uniform
                 v = block_sum(proj_dot_partial(brow, alpha + (int64_t)best_v[e] * lda, mv, a, o, gamma, tl), red);
+            else
+                v = part_i == 0 ? best_score[e] : 0.0;              // already exact: carried by part 0
         }
         if (tid == 0) *part = v;
     }
@@ -1115,9 +1291,13 @@ __global__ void k_action_final(int A, int terms, const int32_t* __restrict__ aqu
     int best = 0;
     double bv = -std::numeric_limits<double>::infinity();
     for (int a = 0; a < A; ++a) {
-        const double* p = val_parts + ((int64_t)b * A + a) * terms;
-        double v = p[0];                                        // b.ER, then the observations in order: the association
-        for (int j = 1; j < terms; ++j) v += p[j];              // the one-block version used (-inf stays -inf)
+        const double* p = val_parts + ((int64_t)b * A + a) * terms * ACTION_SPLIT;
+        double v = 0.0;                                         // b.ER, then the observations in order (-inf stays -inf)
+        for (int j = 0; j < terms; ++j) {
+            double t = p[j * ACTION_SPLIT];
+            for (int z = 1; z < ACTION_SPLIT; ++z) t += p[j * ACTION_SPLIT + z];
+            v = j == 0 ? t : v + t;
+        }
         if (v > bv) {                                           // first maximum among the candidates
             bv = v;
             best = a;
@@ -1136,7 +1316,7 @@ hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, in
     const int terms = 1 + mv.O;
     if ((int64_t)mv.A * terms > 65535) return hipErrorInvalidValue;
     const int gx = B < 512 ? B : 512;                           // queued beliefs are few: a bounded grid strides over them
-    hipLaunchKernelGGL(k_refine_action<T>, dim3(gx, mv.A * terms), dim3(256), 0, st, bel, ldb, alpha, lda, mv, gamma, btl, btc,
+    hipLaunchKernelGGL(k_refine_action<T>, dim3(gx, mv.A * terms, ACTION_SPLIT), dim3(256), 0, st, bel, ldb, alpha, lda, mv, gamma, btl, btc,
                        aqueue, aqcount, rdot, rdot_err, best_v, best_score, err, val_exact);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1636,7 +1816,7 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
 #define PBVI_INST(T)                                                                                                   \
     template hipError_t launch_support<T>(ModelView<T>, uint8_t*, hipStream_t);                                        \
     template hipError_t launch_project<T>(const T*, int, int, ModelView<T>, T, T*, int, const uint8_t*, int,           \
-                                          hipStream_t, const uint8_t*, const int*, int);                               \
+                                          hipStream_t, const uint8_t*, const int*, int, const int32_t*);               \
     template hipError_t launch_tail_rows<T>(ModelView<T>, T*, int, hipStream_t);                                       \
     template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const uint8_t*, int, uint8_t*, int32_t*,      \
                                        int32_t*, int*, hipStream_t);                                                   \

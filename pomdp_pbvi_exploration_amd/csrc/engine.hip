@@ -562,7 +562,9 @@ class EngineT : public EngineBase {
     bool have_result_ = false, res_sorted_ = false;
     int64_t res_B_ = 0;
     int screen_mode_ = 1;                                    // fp64 engines: 0 never screen, 1 when the GEMM is large, 2 always
-    bool fuse_project_ = true;                               // fp32, R = 1: Gamma tiles generated inside the score GEMM
+    int fuse_project_ = 1;                                   // fp32: Gamma tiles generated inside the score GEMM; 0 never, 1 = where it
+                                                             // is faster (R = 1), 2 = also for R = 2..7 (measured slower)
+    double irr_frac_ = 0.0;                                  // share of (action, K tile) with non-consecutive successors
     DevBuf irr_;                                             // [A][k_tiles] 1 = a 4-state chunk of the K tile has non-consecutive successors
     DevBuf mat_, vlist_;                                     // [n-tiles] 1 = projected (straddles groups / tail), 0 = generated
     std::vector<uint8_t> h_mat_;
@@ -704,7 +706,37 @@ class EngineT : public EngineBase {
                         h_rto[(((size_t)a * O + o) * R + r) * S_pad_ + s] = rto[(((size_t)s * A + a) * O + o) * R + r];
                 }
             }
-        h_rs_ = h_rs;
+        h_rs_ = h_rs;                                        // (the CSC build keeps the caller's successors)
+        // Slots of weight zero for every observation -- the reference pads an (s, a) with fewer than R successors by
+        // low-index states at probability 0 (src/mdp.py:308-335), and the pad states s >= S are such slots too --
+        // contribute exactly 0 whichever state they name.  On the device they name the state that keeps their 4-state
+        // chunk's successors consecutive, so that padded models keep the 16-byte alpha loads of the projection and the
+        // fused score GEMM (gemm.hip) instead of falling to gathers.
+        if (S >= 4)
+            for (int a = 0; a < A; ++a)
+                for (int r = 0; r < R; ++r) {
+                    int32_t* row = h_rs.data() + ((size_t)a * R + r) * S_pad_;
+                    for (int c = 0; c < S_pad_ / 4; ++c) {
+                        bool wild[4];
+                        int j0 = -1, n_wild = 0;
+                        for (int j = 0; j < 4; ++j) {
+                            const int s = c * 4 + j;
+                            bool w = true;
+                            for (int o = 0; o < O && w; ++o) w = h_rto[(((size_t)a * O + o) * R + r) * S_pad_ + s] == T(0);
+                            wild[j] = w;
+                            n_wild += w;
+                            if (!w && j0 < 0) j0 = j;
+                        }
+                        if (n_wild == 0) continue;
+                        const int64_t base = j0 >= 0 ? (int64_t)row[c * 4 + j0] - j0 : 0;
+                        if (base < 0 || base + 3 >= S) continue;
+                        bool ok = true;
+                        for (int j = 0; j < 4 && ok; ++j) ok = wild[j] || row[c * 4 + j] == base + j;
+                        if (!ok) continue;
+                        for (int j = 0; j < 4; ++j)
+                            if (wild[j]) row[c * 4 + j] = (int32_t)(base + j);
+                    }
+                }
         if constexpr (!kF32) {   // reference-layout copies for the fp32 screen (built on the first large backup)
             if (mode == PBVI_SPARSE && (size_t)S * A * O * R <= ((size_t)1 << 28)) {
                 try {
@@ -742,15 +774,29 @@ class EngineT : public EngineBase {
             if ((rc = nzB_.ensure(h_nz.size(), &bytes_))) return rc;
             HIPCHK(hipMemcpyAsync(nzB_.p, h_nz.data(), h_nz.size(), hipMemcpyHostToDevice, stream_));
             std::vector<int32_t> h_irr;
-            if (kF32 && R == 1 && mode == PBVI_SPARSE) {   // for the fused score GEMM: which K tiles need gathers
+            // For the fused score GEMM (gemm.hip, schedulers 2b / 2c): K tiles that hold a 4-state chunk whose successors
+            // (for some r) are not 4 consecutive states.  R = 1: the kernel gathers those itself; R = 2..7: those Gamma tiles
+            // are projected and read, so fusing only pays while they are few (grid edges: ~1 in 8 on the olfactory grids;
+            // on a model without grid structure every tile is one and the projection kernel stays).
+            if (kF32 && R <= 7 && mode == PBVI_SPARSE) {
                 h_irr.assign((size_t)A * k_tiles, 0);
+                size_t n_irr = 0;
                 for (int a = 0; a < A; ++a)
-                    for (int c = 0; c < S_pad_ / 4; ++c) {
-                        const int32_t* q = h_rs.data() + (size_t)a * S_pad_ + (size_t)c * 4;
-                        if (q[1] != q[0] + 1 || q[2] != q[0] + 2 || q[3] != q[0] + 3) h_irr[(size_t)a * k_tiles + c / 8] = 1;
-                    }
-                if ((rc = irr_.ensure(h_irr.size() * sizeof(int32_t), &bytes_))) return rc;
-                HIPCHK(hipMemcpyAsync(irr_.p, h_irr.data(), h_irr.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+                    for (int r = 0; r < R; ++r)
+                        for (int c = 0; c < S_pad_ / 4; ++c) {
+                            const int32_t* q = h_rs.data() + ((size_t)a * R + r) * S_pad_ + (size_t)c * 4;
+                            int32_t& f = h_irr[(size_t)a * k_tiles + c / 8];
+                            if (!f && (q[1] != q[0] + 1 || q[2] != q[0] + 2 || q[3] != q[0] + 3)) {
+                                f = 1;
+                                ++n_irr;
+                            }
+                        }
+                const double max_irr = getenv("PBVI_FUSE_MAX_IRR") ? atof(getenv("PBVI_FUSE_MAX_IRR")) : 0.30;
+                irr_frac_ = (double)n_irr / (double)h_irr.size();
+                if (R == 1 || irr_frac_ <= max_irr) {
+                    if ((rc = irr_.ensure(h_irr.size() * sizeof(int32_t), &bytes_))) return rc;
+                    HIPCHK(hipMemcpyAsync(irr_.p, h_irr.data(), h_irr.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+                }
             }
             HIPCHK(hipStreamSynchronize(stream_));
         }
@@ -1875,7 +1921,7 @@ class EngineT : public EngineBase {
     }
 
     int set_fused(int enable) override {
-        fuse_project_ = enable != 0;
+        fuse_project_ = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
         if (screen_) screen_->fuse_project_ = fuse_project_;
         return PBVI_OK;
     }
@@ -2183,7 +2229,7 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
             // that straddle two groups and the tail tile are projected here.
             if constexpr (kF32) {
                 static const bool no_fuse = getenv("PBVI_NO_FUSED_PROJECT") != nullptr;     // debug / A-B only
-                if (R_ == 1 && !no_fuse && fuse_project_ && irr_.p != nullptr) {
+                if ((R_ == 1 ? fuse_project_ >= 1 : (R_ <= 7 && fuse_project_ >= 2)) && !no_fuse && irr_.p != nullptr) {
                     const int tiles_n = (int)(round_up(N, GEMM_BN) / GEMM_BN);
                     if (mat_V_ != V_ || (int)h_mat_.size() != tiles_n) {
                         h_mat_.assign((size_t)tiles_n, 0);
@@ -2213,6 +2259,7 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
                     fb.S_pad = S_pad_;
                     fb.O = O_;
                     fb.V = (int)V_;
+                    fb.R = R_;
                     fb.gamma = (float)gamma;
                     fb.mat = mat_.as<uint8_t>();
                     fb.irr = irr_.as<int32_t>();
@@ -2220,8 +2267,9 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
                 }
             }
             HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_,
-                                     fused ? mat_.as<uint8_t>() : nullptr, fused ? vlist_.as<int>() : nullptr,
-                                     fused ? (int)h_vlist_.size() : 0));
+                                     fused ? mat_.as<uint8_t>() : nullptr, fused && R_ == 1 ? vlist_.as<int>() : nullptr,
+                                     fused && R_ == 1 ? (int)h_vlist_.size() : 0,
+                                     fused && R_ > 1 ? irr_.as<int32_t>() : nullptr));
         }
         HIPCHK(launch_tail_rows<T>(mv, gam_.as<T>() + (size_t)(AO * Vt) * S_pad_, S_pad_, stream_));
         HIPCHK(hipEventRecord(io.ev[1], stream_));
@@ -2401,7 +2449,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     if (windows) {   // exact, from the supports of the ORIGINAL operands (an fp32 copy may have flushed tiny values to zero)
         if ((rc = btl_.ensure((size_t)B_ * k_tiles * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = btc_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
-        if ((rc = val_exact_.ensure((size_t)B_ * A_ * (1 + O_) * sizeof(double), &bytes_))) return rc;
+        if ((rc = val_exact_.ensure((size_t)B_ * A_ * (1 + O_) * ACTION_SPLIT * sizeof(double), &bytes_))) return rc;
         // Dead triples and the per-belief tile lists are a function of the belief block and the model alone: computed on
         // the first backup of a block, kept for the following ones (a solve backs a block up once; update_passes > 1,
         // the belief-dominance loops of the notebooks and the benchmark back the same block up again and again).  Like
@@ -2480,6 +2528,16 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     bool speculate = false;
     if (windows) {
         if ((rc = refine_work(pairs, V_, &work))) return rc;
+        if constexpr (kF32 && !screened) {
+            // Gamma is in HBM as the GEMM read it (projection kernel, not the fused GEMM): the per-entry pass first
+            // separates candidates by fp64 sums over those fp32 rows (backup_kernels.h, RefineWork::gam)
+            static const bool no_l1 = getenv("PBVI_NO_L1_SCREEN") != nullptr;      // debug / A-B only
+            if (!no_l1 && !use_push && !sc.fused && mode_ == PBVI_SPARSE) {
+                work.gam = (const float*)gam_.p;
+                work.ldg = S_pad_;
+                work.l1_rel = (double)(R_ + 4) * 5.9604644775390625e-08;
+            }
+        }
         // the counts land in the engine's pinned bounce buffer (reserved at the top of the call; idle during a backup:
         // results are staged through it only by the fetch calls that follow)
         rf_counts_ = reinterpret_cast<int*>(host_stage_);

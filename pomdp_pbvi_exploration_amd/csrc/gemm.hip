@@ -498,6 +498,240 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk_fused(
 }
 
 // --------------------------------------------------------------------------- //
+// scheduler 2c: stream-K with the Gamma projection fused for 2..7 reachable states per (s, a)
+// --------------------------------------------------------------------------- //
+// Gamma[(g, v)][s] = gamma * sum_r rto[g][r][s] * alpha[v][rs[a][r][s]]   (src/pomdp.py:1485-1491, the padded-ELL SpMM)
+// With R successors a generated B tile needs R gathered alpha chunks per 16-byte output chunk: 20 16-byte loads per
+// thread and K step at R = 5 against the 128 MFMAs (8192 SIMD cycles) a wave issues in that step.  What does not fit
+// is registers (the tile engine leaves ~24 for the staging), so a K step is cut into 2R UNITS -- (half h of the
+// thread's four rows) x (successor slot r) -- of two alpha loads each, issued at the 16 boundaries between the
+// 8-MFMA sub-groups of the step and consumed two boundaries later: two units (4 loads, 16 VGPRs) in flight, one
+// 2-row accumulator (8 VGPRs), the same footprint as the R = 1 kernel's staging.  The successor indices and RTO
+// weights of the K tile are not held in registers at all: wave 0 copies them (R x 128 B each) into LDS by LDS-DMA
+// one K step ahead, and every thread reads its 16 bytes of them right where it uses them.
+// Arithmetic is k_project's, operation for operation (acc = 0; acc = acc + rto*alpha per r, contraction off; then
+// gamma * acc), so the scores are bit-identical to the unfused pipeline.
+// K tiles in which some 4-state chunk has non-consecutive successors for some r (grid edges; flagged per action in
+// bit KL_IRR_BIT of the list entry) are NOT generated: k_project writes those Gamma tiles (8-16 % of them on the
+// olfactory grids) and the step stages B by LDS-DMA like the unfused kernel.  Both kinds of step share one loop.
+constexpr int FUSED_R_MAX = 7;                       // 2R + 2 <= 16 issue points per K step
+constexpr int TAB_WORDS = 8 * GEMM_BK;               // one table image: [r < 8][32 states]
+constexpr int GEMM_LDS_BYTES_R = GEMM_LDS_BYTES + 2 * 2 * TAB_WORDS * 4;   // + 2 buffers x (indices, weights) = 4 KiB
+
+struct Frag {
+    f32x4 af[4], bf[2];
+};
+__device__ __forceinline__ void frag_load(const TileThread& t, const float* lds, int buf, int g, Frag& f) {
+    const float* la = lds + buf * 2 * TILE_FLOATS;
+    const float* lb = la + TILE_FLOATS;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int pc = (2 * g + t.h) ^ ((t.a_row[mi] >> 1) & 7);
+        f.af[mi] = *(const f32x4*)(la + t.a_row[mi] * GEMM_BK + pc * 4);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int pc = (2 * g + t.h) ^ ((t.b_row[ni] >> 1) & 7);
+        f.bf[ni] = *(const f32x4*)(lb + t.b_row[ni] * GEMM_BK + pc * 4);
+    }
+}
+__device__ __forceinline__ void frag_mfma(const Frag& f, int j, f32x16 (&acc)[4][2]) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.af[mi][j], f.bf[ni][j], acc[mi][ni], 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 proj_add(f32x4 acc, f32x4 w, f32x4 av) {
+#pragma clang fp contract(off)
+    const f32x4 pr = w * av;                 // k_project: acc = acc + w * av, one rounding per operation
+    return acc + pr;
+}
+__device__ __forceinline__ f32x4 proj_scale(float gamma, f32x4 acc) {
+#pragma clang fp contract(off)
+    return gamma * acc;
+}
+
+// Multiply list entries [i0, i1) of one pair whose B rows belong to ONE group (see above).  rs_a / rto_g: the R
+// successor / weight rows of the group's action / of the group, S_pad apart; arow0: alpha row of the tile's first
+// row + this thread's row; Bblk: the projected Gamma rows (read for the flagged K tiles only).
+template <int R>
+__device__ __forceinline__ void tile_run_fused_r(const TileThread& t, float* lds, const float* Ablk, int lda,
+                                                 const float* Bblk, int ldb, const int32_t* __restrict__ rs_a,
+                                                 const float* __restrict__ rto_g, int S_pad,
+                                                 const float* __restrict__ arow0, int64_t a_step /* 64 rows of alpha */,
+                                                 float gamma, const int* __restrict__ kl, int i0, int i1,
+                                                 f32x16 (&acc)[4][2]) {
+    const int tid = threadIdx.x;
+    int32_t* tabi = (int32_t*)(lds + 4 * TILE_FLOATS);      // [2][8][32] successor indices of the K tile
+    float* tabw = (float*)(tabi + 2 * TAB_WORDS);           // [2][8][32] RTO weights
+    constexpr int nunits = 2 * R;
+    static_assert(R >= 2 && R <= FUSED_R_MAX, "2R + 2 issue points must fit the 16 of a K step");
+    const int scol0 = t.scol[0];                            // the thread's 4 states inside the K tile (same for its 4 rows)
+    auto stage_a = [&](int buf, int entry) {
+        const int kt = entry & KL_MASK;
+        float* la = lds + buf * 2 * TILE_FLOATS;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            glds16(Ablk + (int64_t)t.srow[it] * lda + kt * GEMM_BK + t.scol[it], la + (it * 512 + t.wid * 64) * 4);
+    };
+    auto stage_b = [&](int buf, int entry) {
+        const int kt = entry & KL_MASK;
+        float* lb = lds + buf * 2 * TILE_FLOATS + TILE_FLOATS;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            glds16(Bblk + (int64_t)t.srow[it] * ldb + kt * GEMM_BK + t.scol[it], lb + (it * 512 + t.wid * 64) * 4);
+    };
+    auto stage_tab = [&](int tb, int entry) {               // wave 0: lane (r, c) copies chunk c of row r
+        if (t.wid == 0 && t.lane < 8 * R) {
+            const int64_t off = (int64_t)(t.lane >> 3) * S_pad + (entry & KL_MASK) * GEMM_BK + (t.lane & 7) * 4;
+            glds16((const float*)(rs_a + off), (float*)(tabi + tb * TAB_WORDS));
+            glds16(rto_g + off, tabw + tb * TAB_WORDS);
+        }
+    };
+    f32x4 av[2][2];                                          // two units in flight
+    f32x4 pacc[2];
+    auto unit_issue = [&](int u, int slot, int tb) {
+        const int hh = u >= R ? 1 : 0, r = u - hh * R;     // compile-time at the unrolled issue points
+        const i32x4 idx = *(const i32x4*)(tabi + tb * TAB_WORDS + r * GEMM_BK + scol0);
+#if PBVI_FUSED_EXP == 3      // diagnosis: every load from the row's first line (wrong results, timing only)
+        const float* p0 = arow0 + (int64_t)(2 * hh) * a_step + (idx[0] & 3);
+#else
+        const float* p0 = arow0 + (int64_t)(2 * hh) * a_step + idx[0];
+#endif
+        ld16(av[slot][0], p0);
+        ld16(av[slot][1], p0 + a_step);
+    };
+    auto unit_consume = [&](int u, int slot, int tb, int dst_buf, bool last_in_queue) {
+        const int hh = u >= R ? 1 : 0, r = u - hh * R;
+        const f32x4 w = *(const f32x4*)(tabw + tb * TAB_WORDS + r * GEMM_BK + scol0);
+        if (last_in_queue)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[slot][0]), "+v"(av[slot][1])::"memory");
+        else                                                  // the next unit's two loads may still be in flight
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(av[slot][0]), "+v"(av[slot][1])::"memory");
+        if (r == 0) {
+            pacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        pacc[0] = proj_add(pacc[0], w, av[slot][0]);
+        pacc[1] = proj_add(pacc[1], w, av[slot][1]);
+        if (r == R - 1) {
+            float* lb = lds + dst_buf * 2 * TILE_FLOATS + TILE_FLOATS;
+            *(f32x4*)(lb + ((2 * hh) * 512 + tid) * 4) = proj_scale(gamma, pacc[0]);
+            *(f32x4*)(lb + ((2 * hh + 1) * 512 + tid) * 4) = proj_scale(gamma, pacc[1]);
+        }
+    };
+    // first tile of the segment: nothing to overlap with
+    {
+        const int e0 = kl[i0];
+        stage_a(0, e0);
+        if (e0 >> KL_IRR_BIT) {
+            stage_b(0, e0);
+        } else {
+            stage_tab(0, e0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int u = 0; u < nunits; ++u) {
+                unit_issue(u, 0, 0);
+                unit_consume(u, 0, 0, 0, true);
+            }
+        }
+    }
+    int e_next = (i0 + 1 < i1) ? kl[i0 + 1] : 0;            // list entries are read ahead of their use
+    if (i0 + 1 < i1 && !(e_next >> KL_IRR_BIT)) stage_tab(1, e_next);
+    int e_after = (i0 + 2 < i1) ? kl[i0 + 2] : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int it = i0; it < i1; ++it) {
+        const bool more = it + 1 < i1;                       // block-uniform, as everything that branches below
+        const bool gen = more && !(e_next >> KL_IRR_BIT);
+        int e_after2 = 0;
+        if (more) {
+            stage_a(buf ^ 1, e_next);
+            if (!gen) stage_b(buf ^ 1, e_next);
+            if (it + 2 < i1 && !(e_after >> KL_IRR_BIT)) stage_tab(buf, e_after);   // tile it+2's tables; tile it's are done with
+            if (it + 3 < i1) e_after2 = kl[it + 3];
+        }
+        Frag f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            frag_load(t, lds, buf, g, f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = 4 * g + j;                     // issue point p: unit p goes out, unit p-2 comes in
+                if (gen) {
+                    if (p >= 2 && p - 2 < nunits) unit_consume(p - 2, p & 1, buf ^ 1, buf ^ 1, p - 2 == nunits - 1);
+                    if (p < nunits) unit_issue(p, p & 1, buf ^ 1);
+                }
+                frag_mfma(f, j, acc);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+        e_next = e_after;
+        e_after = e_after2;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk_fused_r(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, FusedB fb, float* __restrict__ C, int ldc,
+    int64_t slab_stride, int tiles_m, int pairs, int k_tiles, const int* __restrict__ klist, const int* __restrict__ kcount,
+    const int* __restrict__ prefix, const int* __restrict__ start_pair, const int* __restrict__ first_block,
+    const int* __restrict__ plan, int ovh) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nb = gridDim.x;
+    int L;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, qq = nb >> 3, r = nb & 7;
+        const int base = (xcd < r) ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq;
+        L = base + (bid >> 3);
+    }
+    const int q = plan[0], T = plan[1];
+    int64_t pos = (int64_t)L * q;
+    if (pos >= T) return;
+    const int64_t end = (pos + q < T) ? pos + q : T;
+    int p = start_pair[L];
+    if (p < 0) return;
+    TileThread t;
+    t.init();
+    while (pos < end && p < pairs) {
+        const int cnt = kcount[p];
+        if (cnt == 0) {                                  // block-uniform
+            ++p;
+            continue;
+        }
+        const int u_lo = (int)(pos - prefix[p]);
+        const int64_t room = end - pos;
+        const int u_hi = (u_lo + room < cnt + ovh) ? (int)(u_lo + room) : cnt + ovh;
+        const int lo = u_lo > ovh ? u_lo - ovh : 0;
+        const int hi = u_hi > ovh ? u_hi - ovh : 0;
+        if (hi > lo) {
+            const int tm = p % tiles_m, tn = p / tiles_m;
+            f32x16 acc[4][2];
+            tile_zero(acc);
+            if (fb.mat[tn]) {                            // block-uniform: projected rows, the LDS-DMA path
+                tile_run(t, lds, A + (int64_t)tm * 256 * lda, lda, B + (int64_t)tn * 256 * ldb, ldb,
+                         klist + (int64_t)p * k_tiles, lo, hi, acc);
+            } else {
+                const int r0 = tn * 256;
+                const int g = r0 / fb.V, v0 = r0 - g * fb.V;                 // scalar: all 256 rows belong to group g
+                tile_run_fused_r<R>(t, lds, A + (int64_t)tm * 256 * lda, lda, B + (int64_t)tn * 256 * ldb, ldb,
+                                 fb.rs + (int64_t)(g / fb.O) * R * fb.S_pad, fb.rto + (int64_t)g * R * fb.S_pad,
+                                 fb.S_pad, fb.alpha + (int64_t)(v0 + t.srow[0]) * fb.lda, (int64_t)64 * fb.lda, fb.gamma,
+                                 klist + (int64_t)p * k_tiles, lo, hi, acc);
+            }
+            tile_store(t, C + (int64_t)(L - first_block[p]) * slab_stride, ldc, tm, tn, acc);
+        }
+        pos += u_hi - u_lo;
+        ++p;
+    }
+}
+
+// --------------------------------------------------------------------------- //
 // Zero-tile bookkeeping
 // --------------------------------------------------------------------------- //
 // nz[tile][kt] = 1 iff the 256-row x 32-column block of X has a non-zero entry.
@@ -642,6 +876,12 @@ static hipError_t set_lds_attr() {
     e = hipFuncSetAttribute((const void*)k_gemm_nt_f32_streamk_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
                             GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
+#define PBVI_FUSED_R_ATTR(RR)                                                                                          \
+    e = hipFuncSetAttribute((const void*)k_gemm_nt_f32_streamk_fused_r<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            GEMM_LDS_BYTES_R);                                                                          \
+    if (e != hipSuccess) return e;
+    PBVI_FUSED_R_ATTR(2) PBVI_FUSED_R_ATTR(3) PBVI_FUSED_R_ATTR(4) PBVI_FUSED_R_ATTR(5) PBVI_FUSED_R_ATTR(6) PBVI_FUSED_R_ATTR(7)
+#undef PBVI_FUSED_R_ATTR
     done = true;
     return hipSuccess;
 }
@@ -680,7 +920,20 @@ hipError_t launch_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, 
             if ((e = hipEventRecord(list_event, ls)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(stream, list_event, 0)) != hipSuccess) return e;
         }
-        if (fused != nullptr)
+        if (fused != nullptr && fused->R > 1) {
+            switch (fused->R) {
+#define PBVI_FUSED_R_CASE(RR)                                                                                                   \
+    case RR:                                                                                                                    \
+        hipLaunchKernelGGL(k_gemm_nt_f32_streamk_fused_r<RR>, dim3(pl.nblocks), dim3(512), GEMM_LDS_BYTES_R, stream, A, lda, B, \
+                           ldb, *fused, C, pl.ldc, pl.slab_stride, pl.tiles_m, pairs, pl.k_tiles, klist, kcount, prefix,        \
+                           start_pair, first_block, plan, ovh);                                                                 \
+        break;
+                PBVI_FUSED_R_CASE(2) PBVI_FUSED_R_CASE(3) PBVI_FUSED_R_CASE(4) PBVI_FUSED_R_CASE(5) PBVI_FUSED_R_CASE(6) PBVI_FUSED_R_CASE(7)
+#undef PBVI_FUSED_R_CASE
+                default:
+                    return hipErrorInvalidValue;
+            }
+        } else if (fused != nullptr)
             hipLaunchKernelGGL(k_gemm_nt_f32_streamk_fused, dim3(pl.nblocks), dim3(512), GEMM_LDS_BYTES, stream, A, lda, B, ldb,
                                *fused, C, pl.ldc, pl.slab_stride, pl.tiles_m, pairs, pl.k_tiles, klist, kcount, prefix, start_pair,
                                first_block, plan, ovh);

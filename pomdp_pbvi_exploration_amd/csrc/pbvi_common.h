@@ -40,13 +40,15 @@ size_t streamk_workspace_ints(const GemmPlan& pl);   // ints of device workspace
 struct FusedB {
     const float* alpha;   // [V][lda]
     int lda;
-    const int32_t* rs;    // [A][S_pad]
-    const float* rto;     // [A*O][S_pad]
+    const int32_t* rs;    // [A][R][S_pad]
+    const float* rto;     // [A*O][R][S_pad]
     int S_pad, O, V;      // groups of V rows each
+    int R;                // reachable states per (s, a): 1 -> scheduler 2b, 2..7 -> scheduler 2c (gemm.hip)
     float gamma;
     const uint8_t* mat;   // [tiles_n] device
     const int32_t* irr;   // [A][K_pad/32] device (int32: read with scalar loads): 1 = the K tile holds a 4-state chunk
-                          // with non-consecutive successors
+                          // with non-consecutive successors (R = 1: gathered by the kernel; R > 1: that Gamma tile is
+                          // projected by k_project and read from B)
 };
 // single_chunk: one K chunk per pair, i.e. slab 0 is the finished product (no split-K).
 GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad, bool single_chunk = false);

@@ -931,10 +931,11 @@ class Engine:
         ``'belief'`` (beliefs pushed through every (a, o); cheaper when B << V)."""
         _check(self._lib.pbvi_set_formulation(self._h, {'auto': 0, 'alpha': 1, 'belief': 2}[which]))
 
-    def set_fused_projection(self, enable: bool = True) -> None:
-        """fp32 scoring, R = 1: Gamma tiles generated inside the score GEMM (default) or projected first
-        (``pbvi_set_fused_projection``; same scores bit for bit)."""
-        _check(self._lib.pbvi_set_fused_projection(self._h, 1 if enable else 0))
+    def set_fused_projection(self, enable=True) -> None:
+        """fp32 scoring: Gamma tiles generated inside the score GEMM (``True``: where that is faster, i.e. R = 1; default) or
+        projected first (``False``); ``2`` also fuses R = 2..7 (slower; tests).  Same scores bit for bit
+        (``pbvi_set_fused_projection``)."""
+        _check(self._lib.pbvi_set_fused_projection(self._h, int(enable)))
 
     def set_f64_screen(self, mode: str = 'auto') -> None:
         """fp64 engines: ``'off'`` (pure fp64 arithmetic), ``'auto'`` (fp32 screen + fp64 re-decision of near-ties when the

@@ -245,10 +245,10 @@ def gen_c2():
 
 
 # --------------------------------------------------------------------------- #
-def gen_full():
+def gen_full(cases=((1, 1024, 1024, 'olfactory_full_R1.npz'), (5, 512, 512, 'olfactory_full_R5.npz'))):
     """|S|=30000, V=B=1024 (BASELINE configs 2-3): only OUTPUT summaries are stored;
     both sides regenerate the inputs from synth (checksums pin them)."""
-    for R, V, B in ((1, 1024, 1024), (5, 512, 512)):
+    for R, V, B, fname in cases:
         t0 = time.time()
         m = synth.olfactory_model(R=R)
         alpha, acts = synth.alpha_set(m, V)
@@ -267,7 +267,7 @@ def gen_full():
         idx = synth.splitmix64(99, np.arange(4096, dtype=np.uint64))
         sb = (idx % np.uint64(B)).astype(np.int64)
         ss = ((idx >> np.uint64(20)) % np.uint64(m.S)).astype(np.int64)
-        np.savez_compressed(os.path.join(HERE, f'olfactory_full_R{R}.npz'),
+        np.savez_compressed(os.path.join(HERE, fname),
                             R=R, V=V, B=B, gamma=m.gamma, ref_seconds=t_ref, n_unique=len(ra),
                             inputs_sha256=synth.checksum(m.reachable_states, m.rto, m.expected_rewards, alpha, beliefs),
                             core_actions=a_star.astype(np.int8), core_best=v_star.astype(np.int16), core_keep=keep,
@@ -275,6 +275,12 @@ def gen_full():
                             sample_b=sb, sample_s=ss, sample_val=a_new[sb, ss],
                             value_max=orc.max_value_per_belief(alpha, beliefs))
         print(f'  stored; keep={int(keep.sum())}/{B}', flush=True)
+
+
+def gen_full_r5():
+    """The stochastic R=5 variant at the size the benchmark's ``secondary.c4_r5`` runs at: |S|=30000, V=B=1024 (the
+    reference's ``backup`` needs ~30 GB of temporaries for it; alone in the 62 GB container)."""
+    gen_full(cases=((5, 1024, 1024, 'olfactory_full_R5_1024.npz'),))
 
 
 def gen_c5():
@@ -613,4 +619,4 @@ def gen_limiter():
 if __name__ == '__main__':
     which = sys.argv[1:] or ['small', 'kat', 'c2']
     for w in which:
-        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve, 'e2e': gen_e2e, 'hsvi': gen_hsvi, 'prune': gen_prune, 'limiter': gen_limiter, 'c5': gen_c5}[w]()
+        {'small': gen_small, 'kat': gen_kat, 'c2': gen_c2, 'full': gen_full, 'full_r5': gen_full_r5, 'sim': gen_sim, 'models': gen_models, 'solve': gen_solve, 'e2e': gen_e2e, 'hsvi': gen_hsvi, 'prune': gen_prune, 'limiter': gen_limiter, 'c5': gen_c5}[w]()

@@ -318,11 +318,13 @@ def full_inputs(R, V, B):
     return m, alpha, beliefs
 
 
-@pytest.mark.parametrize('R', [1, 5])
-def test_full_size_against_reference_summary(R):
+@pytest.mark.parametrize('tag', ['R1', 'R5', 'R5_1024'])
+def test_full_size_against_reference_summary(tag):
     """BASELINE configs 2-3 (|S|=30000): the engine against the reference's own backup on the same
-    regenerated inputs.  Indices exact; row sums, b.alpha' and 4096 sampled values within 1e-6."""
-    path = os.path.join(GOLDEN, f'olfactory_full_R{R}.npz')
+    regenerated inputs (R = 1 at V = B = 1024; the stochastic R = 5 variant at V = B = 512 and at the benchmark's
+    V = B = 1024).  Indices exact; row sums, b.alpha' and 4096 sampled values within 1e-6."""
+    R = int(tag[1])
+    path = os.path.join(GOLDEN, f'olfactory_full_{tag}.npz')
     if not os.path.exists(path):
         pytest.skip('full-size fixture missing')
     z = np.load(path, allow_pickle=False)
@@ -380,11 +382,12 @@ def _check_against_full_fixture(res, z, beliefs):
 
 
 def _full_fixture(R):
+    """R: 1, 5 or a tag such as '5_1024' (olfactory_full_R5_1024.npz)."""
     path = os.path.join(GOLDEN, f'olfactory_full_R{R}.npz')
     if not os.path.exists(path):
         pytest.skip('full-size fixture missing')
     z = np.load(path, allow_pickle=False)
-    m, alpha, beliefs = full_inputs(R, int(z['V']), int(z['B']))
+    m, alpha, beliefs = full_inputs(int(z['R']), int(z['V']), int(z['B']))
     if synth.checksum(m.reachable_states, m.rto, m.expected_rewards, alpha, beliefs) != str(z['inputs_sha256']):
         pytest.skip('host regenerated different input bits than the fixture machine (exp/libm); parity unpinned here')
     return z, m, alpha, beliefs
@@ -1115,6 +1118,74 @@ def test_fused_projection_gives_the_bits_of_the_projected_pipeline(S, A, O, V, B
     for k in ('n_refined', 'n_refine_candidates', 'n_refined_actions', 'n_dead', 'n_unique', 'score_tiles_run'):
         assert f.stats[k] == u.stats[k], k
     eng.close()
+
+
+@pytest.mark.parametrize('S,A,O,R,V,B', [(4100, 2, 2, 2, 512, 70), (3000, 3, 1, 3, 300, 300), (9000, 1, 3, 5, 777, 40),
+                                          (30000, 2, 2, 5, 256, 260), (5000, 2, 2, 7, 256, 64), (2048, 2, 2, 4, 256, 300)])
+def test_fused_projection_with_several_reachable_states(S, A, O, R, V, B):
+    """Score GEMM that generates its Gamma tiles from R = 2..7 successors per (s, a) (gemm.hip, scheduler 2c: the padded-ELL
+    SpMM of src/pomdp.py:1485-1491 inside the B-operand staging) against the same engine with the projection as a kernel of
+    its own: k_project's arithmetic operation for operation, so every output is identical, and both are the oracle's.
+    Successor maps are shifts per (action, slot) with a sprinkle of random successors -- K tiles with such a chunk are
+    projected and read, so generated and read K steps alternate inside one tile list -- and zero-probability pad slots as
+    the reference's Model pads them (src/mdp.py:308-335)."""
+    rng = np.random.default_rng(S + V + R)
+    shifts = rng.integers(-40, 41, size=(A, R))
+    rs = (np.arange(S)[:, None, None] + shifts[None]) % S
+    odd = rng.random((S // 4 + 1, A, R)) < 0.003                      # some 4-state chunks lose their regularity
+    odd = np.repeat(odd, 4, axis=0)[:S]
+    rs = np.where(odd, rng.integers(0, S, size=(S, A, R)), rs).astype(np.int64)
+    p = rng.random((S, A, O, R))
+    p[rng.random((S, A, O, R)) < 0.3] = 0.0
+    p[:, :, 0, 0] += 1e-3
+    pad = rng.random((S, A)) < 0.1                                      # (s, a) with fewer than R successors
+    p[pad, :, R - 1] = 0.0
+    rs[pad, R - 1] = 0
+    rto = (p / p.sum(axis=(2, 3), keepdims=True)).astype(np.float32).astype(np.float64)
+    er = rng.normal(size=(S, A)).astype(np.float32).astype(np.float64)
+    alpha = rng.normal(scale=4.0, size=(V, S)).astype(np.float32).astype(np.float64)
+    b = rng.random((B, S)) * (rng.random((B, S)) < 0.2)
+    b[:, rng.integers(0, S, size=B)] += 1e-3
+    b = (b / b.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    want_rows, want_a, want_v = orc.backup_core(alpha, b, rs, rto, er, 0.9)
+    eng = Engine(S, A, O, R, rs, rto, er, dtype='f32')
+    eng.set_formulation('alpha')
+    out = {}
+    for fused in (2, 1, 0):                                             # 1: "where it is faster" is R = 1 only
+        eng.set_fused_projection(fused)
+        res = eng.backup_full(alpha, b, 0.9, belief_dominance_prune=True)
+        assert res.stats['fused_projection'] == int(fused == 2 and FUSION_ALLOWED)
+        assert np.array_equal(res.best_alpha_ind, want_v) and np.array_equal(res.actions, want_a), fused
+        assert_alpha_close(res.alpha, want_rows, F32_RTOL)
+        out[fused] = res
+    f, u = out[2], out[0]
+    assert np.array_equal(f.alpha, u.alpha) and np.array_equal(f.keep, u.keep)
+    for k in ('n_refined', 'n_refine_candidates', 'n_refined_actions', 'n_dead', 'n_unique', 'score_tiles_run'):
+        assert f.stats[k] == u.stats[k], k
+    eng.close()
+
+
+def test_fused_projection_is_not_chosen_without_grid_structure():
+    """R > 1 with random successors: every K tile would have to be projected AND read, so the engine keeps the projection
+    kernel; R = 8 exceeds the 16 issue points of a K step."""
+    rng = np.random.default_rng(5)
+    for S, A, O, R in ((1200, 2, 2, 3), (1200, 1, 2, 8)):
+        if R == 3:
+            rs = rng.integers(0, S, size=(S, A, R))
+        else:
+            rs = (np.arange(S)[:, None, None] + rng.integers(-9, 10, size=(A, R))[None]) % S
+        rs, rto, er = rs.astype(np.int64), *random_model(rng, S, A, O, R)[1:]
+        alpha = rng.normal(size=(260, S)).astype(np.float32).astype(np.float64)
+        b = rng.random((40, S))
+        b = (b / b.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+        want_rows, want_a, want_v = orc.backup_core(alpha, b, rs, rto, er, 0.9)
+        eng = Engine(S, A, O, R, rs, rto, er, dtype='f32')
+        eng.set_formulation('alpha')
+        eng.set_fused_projection(2)
+        res = eng.backup_full(alpha, b, 0.9)
+        assert res.stats['fused_projection'] == 0
+        assert np.array_equal(res.best_alpha_ind, want_v) and np.array_equal(res.actions, want_a)
+        eng.close()
 
 
 _SEA_ROBIN = {}

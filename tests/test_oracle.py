@@ -112,7 +112,7 @@ def test_dedup_first_position_last_action():
     assert rows.tolist() == [[9., 9.], [3., 4.], [1., 2.]] and acts.tolist() == [5, 1, 0]
 
 
-@pytest.mark.parametrize('R', [1, 5])
+@pytest.mark.parametrize('R', [1, 5, '5_1024'])
 def test_full_size_summary_consistent(R):
     """The |S|=30000 fixtures hold only output summaries; here they are checked for internal
     consistency (the heavy comparison against them is the GPU test)."""
