@@ -3,14 +3,17 @@
     python bench.py --gpus N --steps K --warmup W          (N=1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1)
 
-A step is ONE point-based backup of SURVEY 8d's metric: ``pbvi_backup_run`` (Gamma projection, score GEMM, argmax +
-fp64 tie refinement, action selection, dedup, alpha' assembly) of the resident belief block against the resident
-alpha set, THEN its results -- the U distinct alpha' rows, the per-belief index into them and the actions -- copied
-into page-locked host buffers (``pbvi_backup_fetch_compact``), synchronised.  That is what the reference's own
-``backup_times`` contain: ``ValueFunction.__init__``'s ``tobytes()`` forces the device-to-host copy
-(src/mdp.py:667-669).  Inputs are in HBM when the timed region starts.  ``value`` = beliefs / MEDIAN step time
-(median of the timed calls); the mean over the whole timed region and the device-resident figure (results
-left in HBM) are reported beside it.
+A step is ONE point-based backup of SURVEY 8d's metric, of a belief block the engine has NOT seen as a block before:
+``pbvi_beliefs_select`` of the next block of B rows of the device belief store (rotating id ranges: the rows are in
+HBM, no PCIe, but everything the engine derives from a belief block -- sort order, zero-tile map, per-belief tile lists,
+dead-triple flags -- is built inside the step, as in a solve, which backs each new block up exactly once), then
+``pbvi_backup_run`` (Gamma projection, score GEMM, argmax + fp64 tie refinement, action selection, dedup, alpha'
+assembly) against the resident alpha set, THEN its results -- the U distinct alpha' rows, the per-belief index into them
+and the actions -- copied into page-locked host buffers (``pbvi_backup_fetch_compact``), synchronised.  That is what the
+reference's own ``backup_times`` contain: ``ValueFunction.__init__``'s ``tobytes()`` forces the device-to-host copy
+(src/mdp.py:667-669).  ``value`` = beliefs / MEDIAN step time (median of the timed calls).  Beside it:
+``value_reused_block`` (round 2's ``value``: the same block backed up again and again, its indexes kept), the mean over
+the whole timed region and the device-resident figure (results left in HBM).
 
 With N>1 the beliefs are sharded and each step is the product path of ``dist.sharded_engine_step``: local backup, ONE
 all-gather of integers (per-belief index / action / keep + the keys of the distinct rows), global dedup, and every
@@ -90,7 +93,8 @@ def gemm_roofline(stats, dtype: str, mode: str):
                 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
                 'traffic': None, 'flops_per_launch': pfe, 'ms_per_launch': ms, 'dense_flops_per_launch': pf}
     ms = float(np.mean([s['ms_score'] for s in stats]))
-    flops, dense = stats[0]['score_flops_executed'], stats[0]['score_flops']
+    # (steps may back different belief blocks up: the executed tile-steps are averaged like the launch times)
+    flops, dense = float(np.mean([s['score_flops_executed'] for s in stats])), stats[0]['score_flops']
     f32_gemm = dtype == 'f32' or bool(stats[0].get('screened'))      # an fp64 engine's scores come from its fp32 screen
     peak = PEAK_F32_MFMA_TFLOPS if f32_gemm else PEAK_F64_MFMA_TFLOPS
     ach = flops / (ms * 1e-3) / 1e12
@@ -104,7 +108,7 @@ def gemm_roofline(stats, dtype: str, mode: str):
             'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
             'flops_per_launch': flops, 'ms_per_launch': ms, 'dense_flops_per_launch': dense,
             'dense_equivalent_tflops': dense / (ms * 1e-3) / 1e12,
-            'tiles_run_over_dense': stats[0]['score_tiles_run'] / max(1, stats[0]['score_tiles_dense'])}
+            'tiles_run_over_dense': float(np.mean([s['score_tiles_run'] for s in stats])) / max(1, stats[0]['score_tiles_dense'])}
 
 
 class stdout_to_stderr:
@@ -193,6 +197,7 @@ def main():
     ap.add_argument('--mode', type=str, default='sparse', choices=['sparse', 'dense'],
                     help="projection: reachable-sparse ELL SpMM (BASELINE config 3, the reference's path) or dense "
                          "|A||O| MFMA GEMMs over densified T.O (config 2; 65 GB of matrices at S=30000)")
+    ap.add_argument('--blocks', type=int, default=3, help='belief blocks in the device store the timed steps rotate over')
     ap.add_argument('--secondary', type=str, default='auto', choices=['auto', 'none'],
                     help="'auto': on one GPU with the default workload also measure c3_dense, c4_f64, c4_r5")
     args = ap.parse_args()
@@ -237,6 +242,15 @@ def main():
                  mode=args.mode)
     eng.set_formulation(args.formulation)
     eng.set_alpha(alpha)
+    # the belief store: `blocks` blocks of B rows (block 0 = `beliefs`); a timed step selects the next one by id
+    rotate = not distributed and args.blocks > 1
+    block_ids = []
+    if rotate:
+        for k in range(args.blocks):
+            rows = beliefs if k == 0 else synth.belief_points(m, B, start=(rank * args.blocks + k) * B if args.scaling == 'weak' else n_total * world + k * B)
+            first = eng.store_rows('belief', rows)
+            block_ids.append(np.arange(first, first + B, dtype=np.int32))
+            del rows
     eng.set_beliefs(beliefs)
     shard = EngineShard(eng, m.gamma)
     host = HostResults(eng, B)
@@ -256,9 +270,13 @@ def main():
             # local backup -> one all-gather of integers -> global dedup -> every replica appends the distinct rows
             eng.reset_store('alpha')                                # same store contents every step
             return sharded_engine_step(shard, dist, None, n_total)[5]
+        if rotate:                                                    # a block the engine has no indexes of
+            eng.select_beliefs(block_ids[step.n % len(block_ids)])
+            step.n += 1
         st = eng.run(m.gamma)
         eng.fetch_compact_into(host.rows, host.index, host.actions)   # U rows + index + actions -> pinned host, synchronised
         return st
+    step.n = 0
 
     per_step, elapsed, stats = timed_steps(step, args.steps, args.warmup, fence)
     if distributed:
@@ -269,7 +287,16 @@ def main():
     # device-resident variant: the same backups with the results left in HBM
     resident_ms = None
     host_ms = None
+    reused = None
     if not distributed:
+        if rotate:                                    # round 2's metric: one block backed up again and again
+            eng.set_beliefs(beliefs)
+
+            def reused_step():
+                eng.run(m.gamma)
+                eng.fetch_compact_into(host.rows, host.index, host.actions)
+            per_r, _, _ = timed_steps(reused_step, args.steps, 3, fence)
+            reused = float(np.median(per_r))
         _, el2, _ = timed_steps(lambda: eng.run(m.gamma), args.steps, 2, fence)
         resident_ms = el2 / args.steps * 1e3
         # PCIe-inclusive variant: pageable host beliefs in, the expanded [B][S] alpha' matrix out to pageable memory
@@ -302,9 +329,14 @@ def main():
                        'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': args.alphas, 'B_per_gpu': B, 'B_total': n_total,
                        'step': ('local backup + all-gather of ' + ('alpha rows' if exchange_rows else 'row keys')
                                 + ' + global dedup + append of the distinct rows to every replica\'s alpha store') if distributed
-                               else 'pbvi_backup_run + pbvi_backup_fetch_compact (U distinct rows, index, actions) into pinned host memory, synchronised',
+                               else ('pbvi_beliefs_select (next block of the device belief store) + ' if rotate else '') +
+                                    'pbvi_backup_run + pbvi_backup_fetch_compact (U distinct rows, index, actions) into pinned host memory, synchronised',
                        'parallelism': f'belief-sharded x{world}' if distributed else 'single GPU',
-                       'resident_inputs': 'alpha set and belief block in HBM before the timed region, with the indexes the engine '
+                       'resident_inputs': ('alpha set and the rows of the belief store in HBM before the timed region; every step '
+                                           f'selects a block of {B} store rows it has not indexed (rotation over {len(block_ids)} blocks: '
+                                           'sort order, zero-tile map, per-belief tile lists and dead-triple flags are rebuilt inside the '
+                                           'step); nothing computed from the alpha set is kept between steps') if rotate else
+                                          'alpha set and belief block in HBM before the timed region, with the indexes the engine '
                                           'builds of a belief block when it becomes resident / is first backed up (sort order, '
                                           'zero-tile map, dead-triple flags, per-belief tile lists); nothing computed from the '
                                           'alpha set is kept between steps'},
@@ -313,7 +345,7 @@ def main():
             'ms_per_step_min': float(per_step.min()) * 1e3, 'ms_per_step_max': float(per_step.max()) * 1e3,
             'roofline': gemm_roofline(stats, args.dtype, args.mode) if stats and stats[0] else None,
             # the executed MFMA work of the step at the fp32 peak / the device time of the whole step (all kernels)
-            'step_frac_of_mfma_bound': (stats[0]['score_flops_executed'] / (PEAK_F32_MFMA_TFLOPS * 1e12)
+            'step_frac_of_mfma_bound': (float(np.mean([s['score_flops_executed'] for s in stats])) / (PEAK_F32_MFMA_TFLOPS * 1e12)
                                         / (float(np.mean([s['ms_total'] for s in stats])) * 1e-3))
             if stats and stats[0] and args.dtype == 'f32' else None,
             'stage_ms': {k: float(np.mean([s[k] for s in stats])) for k in STAGES} if stats and stats[0] else None,
@@ -322,6 +354,9 @@ def main():
             st = stats[-1]
             out.update({'unique_rows': int(st['n_unique']), 'refined_pairs': int(st['n_refined']), 'dead_pairs': int(st['n_dead']),
                         'refined_actions': int(st['n_refined_actions']), 'pairs': int(st['n_pairs']), 'split_k': int(st['split_k'])})
+        if reused is not None:
+            out['value_reused_block'] = B / reused
+            out['ms_per_step_reused_block'] = reused * 1e3
         if resident_ms is not None:
             out['value_device_resident'] = B / (resident_ms * 1e-3)
             out['ms_per_step_device_resident'] = resident_ms

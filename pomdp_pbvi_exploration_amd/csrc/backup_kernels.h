@@ -89,10 +89,12 @@ hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB
 
 // dead[b][ao] = 1 iff supp(b) and supp(RTO[:,a,o,:]) are disjoint (P(o|b,a) == 0 exactly)
 template <typename T>
-hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const uint8_t* nzB /* [A*O][k_tiles] */,
+hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv,
+                       const unsigned long long* nzBw /* [A*O][ceil(k_tiles/64)]: support tiles of RTO as bit words */,
                        int k_tiles, uint8_t* dead, int32_t* btl /* out: [B][k_tiles] non-zero tile lists */,
                        int32_t* btc /* out: [B] list lengths */, int* dead_count /* += dead triples, or nullptr */,
-                       hipStream_t st);
+                       hipStream_t st, const uint8_t* rowflags = nullptr /* [.][k_tiles] per-row tile flags, if known */,
+                       const int32_t* perm = nullptr /* belief b's row of rowflags (nullptr: b) */);
 
 // Belief-side projection: bp[((o*A + a)*B + b)][s'] = gamma * sum_{(s,r): rs[s,a,r] = s'} b[b][s] * RTO[s,a,o,r]  (g = a*O+o), so
 // that bp[g,b,:] . alpha[v,:] == b . Gamma[a,o,v,:] re-associated; accumulated in f64, rounded once to T.

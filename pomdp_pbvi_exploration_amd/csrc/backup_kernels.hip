@@ -365,27 +365,36 @@ hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB
 // supp(RTO[:,a,o,:]) is then checked only in tiles where both the belief and the (a,o) support tile map
 // nzB are non-zero -- for the "goal" observation that is one tile instead of |S| states.
 template <typename T>
-__global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, const uint8_t* __restrict__ nzB,
+__global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv,
+                       const unsigned long long* __restrict__ nzBw /* [A*O][ceil(k_tiles/64)] support tiles as bit words */,
                        int k_tiles, uint8_t* __restrict__ dead, int32_t* __restrict__ btl, int32_t* __restrict__ btc,
-                       int* __restrict__ dead_count) {
+                       int* __restrict__ dead_count, const uint8_t* __restrict__ rowflags /* [.][k_tiles] or nullptr */,
+                       const int32_t* __restrict__ perm /* row of rowflags = perm[b], or nullptr = b */) {
     extern __shared__ uint8_t dsm[];
+    __shared__ int dead_w[4];
     uint8_t* tz = dsm;                                  // [k_tiles] belief has a non-zero in tile
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int AO = mv.A * mv.O;
     const T* brow = bel + (int64_t)b * ldb;
-    // tile flags: 8 lanes x 4 states per tile
-    for (int kt0 = 0; kt0 < k_tiles; kt0 += 32) {
-        const int kt = kt0 + (tid >> 3);
-        int f = 0;
-        if (kt < k_tiles) {
-            const int s = kt * 32 + (tid & 7) * 4;
+    int n_dead = 0;
+    if (rowflags != nullptr) {                          // the block's indexing pass left them (engine.hip, k_row_flags)
+        const uint8_t* f = rowflags + (int64_t)(perm ? perm[b] : b) * k_tiles;
+        for (int kt = tid; kt < k_tiles; kt += 256) tz[kt] = f[kt];
+    } else {
+        // tile flags: 8 lanes x 4 states per tile
+        for (int kt0 = 0; kt0 < k_tiles; kt0 += 32) {
+            const int kt = kt0 + (tid >> 3);
+            int f = 0;
+            if (kt < k_tiles) {
+                const int s = kt * 32 + (tid & 7) * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) f |= (s + j < mv.S && brow[s + j] != T(0)) ? 1 : 0;
+                for (int j = 0; j < 4; ++j) f |= (s + j < mv.S && brow[s + j] != T(0)) ? 1 : 0;
+            }
+            f |= __shfl_xor(f, 1, 64);
+            f |= __shfl_xor(f, 2, 64);
+            f |= __shfl_xor(f, 4, 64);
+            if (kt < k_tiles && (tid & 7) == 0) tz[kt] = (uint8_t)f;
         }
-        f |= __shfl_xor(f, 1, 64);
-        f |= __shfl_xor(f, 2, 64);
-        f |= __shfl_xor(f, 4, 64);
-        if (kt < k_tiles && (tid & 7) == 0) tz[kt] = (uint8_t)f;
     }
     __syncthreads();
     if (wid == 0) {   // compact list of this belief's non-zero tiles, kept for the refinement dots
@@ -399,23 +408,62 @@ __global__ void k_dead(const T* __restrict__ bel, int ldb, ModelView<T> mv, cons
         }
         if (lane == 0) btc[b] = base;
     }
+    // the belief's tile flags as bit words (bit t of word w = tile 64 w + t), so that a wave sees the candidate tiles of an
+    // (a, o) -- belief mass AND support, nzBw holds the supports in the same form -- after ONE load instead of one
+    // dependent load per 64 tiles
+    const int kw = (k_tiles + 63) >> 6;
+    unsigned long long* tzw = (unsigned long long*)(dsm + ((k_tiles + 7) & ~7));
+    for (int w = wid; w < kw; w += 4) {
+        const int kt = w * 64 + lane;
+        const unsigned long long m = __ballot(kt < k_tiles && tz[kt]);
+        if (lane == 0) tzw[w] = m;
+    }
+    __syncthreads();
     for (int ao = wid; ao < AO; ao += 4) {                // one wave per (a,o)
-        const uint8_t* zb = nzB + (int64_t)ao * k_tiles;
         const uint8_t* sp = mv.sup + (int64_t)ao * mv.S_pad;
         int found = 0;
-        for (int kt0 = 0; kt0 < k_tiles && !found; kt0 += 64) {
-            const int kt = kt0 + lane;
-            int f = 0;
-            if (kt < k_tiles && tz[kt] && zb[kt]) {      // candidate tile: check its 32 states
-                const int s0 = kt * 32;
-                for (int j = 0; j < 32 && !f; ++j)
-                    f = (s0 + j < mv.S && sp[s0 + j] && brow[s0 + j] != T(0)) ? 1 : 0;
+        for (int w0 = 0; w0 < kw && !found; w0 += 64) {
+            const int wi = w0 + lane;
+            const unsigned long long cw = wi < kw ? (tzw[wi] & nzBw[(int64_t)ao * kw + wi]) : 0ull;
+            unsigned long long lanes = __ballot(cw != 0ull);
+            while (lanes != 0ull && !found) {
+                const int src = __ffsll((long long)lanes) - 1;
+                lanes &= lanes - 1ull;
+                unsigned long long cand = ((unsigned long long)(unsigned)__shfl((int)(cw >> 32), src, 64) << 32) |
+                                          (unsigned long long)(unsigned)__shfl((int)(cw & 0xffffffffull), src, 64);
+                const int kt0 = (w0 + src) * 64;
+                // the wave checks the candidates' states two tiles at a time, one state per lane, and stops at the first
+                // overlap -- which for a live triple is the first or second candidate
+                while (cand != 0ull && !found) {
+                    const int t0 = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1ull;
+                    int t1 = -1;
+                    if (cand != 0ull) {
+                        t1 = __ffsll((long long)cand) - 1;
+                        cand &= cand - 1ull;
+                    }
+                    const int t = lane < 32 ? t0 : t1;
+                    int f = 0;
+                    if (t >= 0) {
+                        const int s = (kt0 + t) * 32 + (lane & 31);
+                        f = (s < mv.S && sp[s] && brow[s] != T(0)) ? 1 : 0;
+                    }
+                    found = __any(f);
+                }
             }
-            found = __any(f);
         }
         if (lane == 0) {
             dead[(int64_t)b * AO + ao] = found ? 0 : 1;
-            if (!found && dead_count != nullptr) atomicAdd(dead_count, 1);
+            if (!found) ++n_dead;
+        }
+    }
+    // one atomic per block: 4830 dead triples adding to one word one by one were 63 us of the kernel's 67
+    if (dead_count != nullptr) {
+        if (lane == 0) dead_w[wid] = n_dead;
+        __syncthreads();
+        if (tid == 0) {
+            const int n = dead_w[0] + dead_w[1] + dead_w[2] + dead_w[3];
+            if (n > 0) atomicAdd(dead_count, n);
         }
     }
 }
@@ -464,11 +512,13 @@ hipError_t launch_belief_tiles(const T* bel, int ldb, int B, int S, int k_tiles,
 }
 
 template <typename T>
-hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const uint8_t* nzB, int k_tiles, uint8_t* dead,
-                       int32_t* btl, int32_t* btc, int* dead_count, hipStream_t st) {
+hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv, const unsigned long long* nzBw, int k_tiles, uint8_t* dead,
+                       int32_t* btl, int32_t* btc, int* dead_count, hipStream_t st, const uint8_t* rowflags,
+                       const int32_t* perm) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dead<T>, dim3(B), dim3(256), (size_t)k_tiles, st, bel, ldb, mv, nzB, k_tiles, dead, btl, btc,
-                       dead_count);
+    const size_t lds = (size_t)((k_tiles + 7) & ~7) + (size_t)((k_tiles + 63) / 64) * 8;      // byte flags + bit words
+    hipLaunchKernelGGL(k_dead<T>, dim3(B), dim3(256), lds, st, bel, ldb, mv, nzBw, k_tiles, dead, btl, btc,
+                       dead_count, rowflags, perm);
     return hipGetLastError();
 }
 
@@ -1154,52 +1204,59 @@ hipError_t launch_tail_rows(ModelView<T> mv, T* gam_tail, int ldg, hipStream_t s
     return hipGetLastError();
 }
 
-// K4, one thread per belief: val[a] = b.ER[:,a] + sum_o best_score[b][a][o]; first max; near-ties queued.
+// K4: val[a] = b.ER[:,a] + sum_o best_score[b][a][o]; first max; near-ties queued.  One thread per (belief, action)
+// gathers the terms (one thread per belief walking its A actions was 22 us of dependent loads for 1024 beliefs), the
+// belief's first thread then takes the first maximum over the A values in order.
 // rdot comes from the score matrix (column rd_col0 + a, f32 engines: with error bound tol * b.|ER_a|).
 template <typename T>
-__global__ void k_action_select(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, double tol_extra,
+__global__ void k_action_select(int B, int per_block, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, double tol_extra,
                                 const int* __restrict__ chain_steps, const double* __restrict__ best_score,
                                 const double* __restrict__ err, double* __restrict__ rdot, double* __restrict__ rdot_err,
                                 int32_t* __restrict__ action, int32_t* __restrict__ aqueue, int* __restrict__ aqcount) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
-    double tr = tol_rel;
-    if (chain_steps != nullptr && tol_rel < 0.0) tr = 8.0 * 5.9604644775390625e-08 * (sqrt((double)chain_steps[0] * 32.0) + 1.0);
-    tr += tol_extra;
-    int best = 0;
-    double bv = -std::numeric_limits<double>::infinity(), lo = bv;
-    for (int a = 0; a < mv.A; ++a) {
+    __shared__ double sv_[256], se_[256];
+    const int A = mv.A;
+    const int lb = threadIdx.x / A, a = threadIdx.x - lb * A;
+    const int b = blockIdx.x * per_block + lb;
+    const bool live = lb < per_block && b < B;
+    if (live) {
+        double tr = tol_rel;
+        if (chain_steps != nullptr && tol_rel < 0.0) tr = 8.0 * 5.9604644775390625e-08 * (sqrt((double)chain_steps[0] * 32.0) + 1.0);
+        tr += tol_extra;
         double rd, E = 0.0;
         if (sv.push) {
-            rd = sv.aux_rd[(int64_t)b * mv.A + a];          // f64 dot: exact to 1e-16, no window needed
+            rd = sv.aux_rd[(int64_t)b * A + a];               // f64 dot: exact to 1e-16, no window needed
         } else {
             rd = (double)sv.at(b, rd_col0 + a);
-            if (aqueue != nullptr) E = tr * fmax(fabs(rd), fabs((double)sv.at(b, rd_col0 + mv.A + a)));
+            if (aqueue != nullptr) E = tr * fmax(fabs(rd), fabs((double)sv.at(b, rd_col0 + A + a)));
         }
-        rdot[(int64_t)b * mv.A + a] = rd;
-        rdot_err[(int64_t)b * mv.A + a] = E;
+        rdot[(int64_t)b * A + a] = rd;
+        rdot_err[(int64_t)b * A + a] = E;
         double v = rd;
         for (int o = 0; o < mv.O; ++o) {
-            const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
+            const int64_t e = ((int64_t)b * A + a) * mv.O + o;
             v += best_score[e];
             E += err[e];
         }
+        sv_[threadIdx.x] = v;
+        se_[threadIdx.x] = E;
+    }
+    __syncthreads();
+    if (!live || a != 0) return;
+    int best = 0;
+    double bv = -std::numeric_limits<double>::infinity(), lo = bv;
+    for (int x = 0; x < A; ++x) {
+        const double v = sv_[threadIdx.x + x], E = se_[threadIdx.x + x];
         if (v > bv) {
             bv = v;
-            best = a;
+            best = x;
         }
         lo = fmax(lo, v - E);
     }
     action[b] = best;
     if (aqueue != nullptr) {
         int ncand = 0, anyerr = 0;
-        for (int a = 0; a < mv.A; ++a) {
-            double v = rdot[(int64_t)b * mv.A + a], E = rdot_err[(int64_t)b * mv.A + a];
-            for (int o = 0; o < mv.O; ++o) {
-                const int64_t e = ((int64_t)b * mv.A + a) * mv.O + o;
-                v += best_score[e];
-                E += err[e];
-            }
+        for (int x = 0; x < A; ++x) {
+            const double v = sv_[threadIdx.x + x], E = se_[threadIdx.x + x];
             if (v + E >= lo) {
                 ++ncand;
                 anyerr |= (E > 0.0);
@@ -1214,8 +1271,10 @@ hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0
                          const double* best_score, const double* err, double* rdot, double* rdot_err, int32_t* action,
                          int32_t* aqueue, int* aqcount, hipStream_t st, double tol_extra) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_action_select<T>, dim3((B + 255) / 256), dim3(256), 0, st, B, mv, sv, rd_col0, tol_rel, tol_extra,
-                       chain_steps, best_score, err, rdot, rdot_err, action, aqueue, aqcount);
+    if (mv.A > 256) return hipErrorInvalidValue;
+    const int per_block = 256 / mv.A;
+    hipLaunchKernelGGL(k_action_select<T>, dim3((B + per_block - 1) / per_block), dim3(256), 0, st, B, per_block, mv, sv, rd_col0,
+                       tol_rel, tol_extra, chain_steps, best_score, err, rdot, rdot_err, action, aqueue, aqcount);
     return hipGetLastError();
 }
 
@@ -1818,8 +1877,8 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
     template hipError_t launch_project<T>(const T*, int, int, ModelView<T>, T, T*, int, const uint8_t*, int,           \
                                           hipStream_t, const uint8_t*, const int*, int, const int32_t*);               \
     template hipError_t launch_tail_rows<T>(ModelView<T>, T*, int, hipStream_t);                                       \
-    template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const uint8_t*, int, uint8_t*, int32_t*,      \
-                                       int32_t*, int*, hipStream_t);                                                   \
+    template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const unsigned long long*, int, uint8_t*, int32_t*, \
+                                       int32_t*, int*, hipStream_t, const uint8_t*, const int32_t*);                                                   \
     template hipError_t launch_belief_tiles<T>(const T*, int, int, int, int, int32_t*, int32_t*, hipStream_t);         \
     template hipError_t launch_argmax<T>(SlabView<T>, int, int, int, const uint8_t*, double, double, const int*, int,  \
                                          int32_t*, double*, double*, int32_t*, int*, hipStream_t, double);             \

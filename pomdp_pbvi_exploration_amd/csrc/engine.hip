@@ -320,19 +320,49 @@ __global__ void k_project_mag(const T* __restrict__ amax, ModelView<T> mv, T gam
     gam_tail[(int64_t)ao * ldg + s] = gamma * acc;
 }
 
-// Belief reordering (f32 engines): rows are sorted by the first K tile that holds belief mass, so the
-// 256-row blocks of the score GEMM have tighter joint supports and more zero tiles to skip.
+// Indexing of a belief block (pbvi_beliefs_set / pbvi_beliefs_select), all on the device and stream-ordered -- a solve
+// backs every new block up exactly once, so this is part of every backup:
+//   k_row_flags  one pass over the source rows: flags[b][kt] = row b has mass in K tile kt (32 states), key[b] = its
+//                first such tile
+//   k_rank_sort  rows ordered by key (stable): the 256-row blocks of the score GEMM get tighter joint supports and more
+//                zero tiles to skip (33.8 % -> 29.1 % of the tile steps at |S| = 30000)
+//   k_gather_rows_v  the block in that order, 16 bytes per lane, straight from the store rows (no staging copy)
+//   k_tile_or    the GEMM's zero map of the block from the row flags
+// The per-belief tile lists and the dead-triple test (backup_kernels.hip) read the same flags.
 template <typename T>
-__global__ void k_first_tile(const T* __restrict__ bel, int ldb, int S, int32_t* __restrict__ key) {
+__global__ void k_row_flags(const T* __restrict__ src, int ld, const int32_t* __restrict__ ids, int S_pad, int k_tiles,
+                            uint8_t* __restrict__ flags, int32_t* __restrict__ key) {
+    constexpr int NS = 16 / (int)sizeof(T);              // states per 16-byte chunk
+    constexpr int LP = GEMM_BK / NS;                     // lanes per K tile (8 or 16)
+    typedef T TN __attribute__((ext_vector_type(NS)));
     __shared__ int red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const T* row = bel + (int64_t)b * ldb;
+    const T* row = src + (int64_t)(ids ? ids[b] : b) * ld;
+    const int chunks = S_pad / NS;                       // rows are padded with zeros to S_pad (a multiple of 32)
     int first = 0x7fffffff;
-    for (int s = tid; s < S; s += 256)
-        if (row[s] != T(0)) {
-            first = s;
-            break;
+    for (int c0 = 0; c0 < chunks; c0 += 1024) {          // four 16-byte loads per lane in flight
+        TN v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j * 256 + tid;
+            TN z;
+#pragma unroll
+            for (int e = 0; e < NS; ++e) z[e] = T(0);
+            v[j] = c < chunks ? *(const TN*)(row + (int64_t)c * NS) : z;
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j * 256 + tid;
+            int f = 0;
+#pragma unroll
+            for (int e = 0; e < NS; ++e) f |= (v[j][e] != T(0)) ? 1 : 0;
+#pragma unroll
+            for (int off = 1; off < LP; off <<= 1) f |= __shfl_xor(f, off, 64);
+            const int kt = c / LP;
+            if (c < chunks && (tid & (LP - 1)) == 0) flags[(int64_t)b * k_tiles + kt] = (uint8_t)f;
+            if (f && c < chunks && kt < first) first = kt;
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const int o = __shfl_xor(first, off, 64);
@@ -343,7 +373,69 @@ __global__ void k_first_tile(const T* __restrict__ bel, int ldb, int S, int32_t*
     if (tid == 0) {
         int m = red[0];
         for (int w = 1; w < 4; ++w) m = red[w] < m ? red[w] : m;
-        key[b] = (m == 0x7fffffff) ? 0x7fffffff : m / GEMM_BK;
+        key[b] = m == 0x7fffffff ? k_tiles : m;          // an empty row sorts behind every other
+    }
+}
+
+// perm[rank of row i] = i, rank = rows with a smaller (key, index): a stable sort as a rank computation -- no atomics,
+// deterministic.  One wave per row (64 lanes share the B comparisons), so 1024 rows keep every CU busy for ~3 us
+// (one thread per row was 23 us on four CUs).
+__global__ void k_rank_sort(const int32_t* __restrict__ key, int B, int32_t* __restrict__ perm) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    const int ki = key[i];
+    int rank = 0;
+    for (int j = lane; j < B; j += 64) {
+        const int kj = key[j];
+        rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rank += __shfl_xor(rank, off, 64);
+    if (lane == 0) perm[rank] = i;
+}
+
+// dst row y = src row ids[perm[y]] (either map may be null), 16 bytes per lane; ld is a multiple of 32 elements
+template <typename T>
+__global__ void k_gather_rows_v(const T* __restrict__ src, T* __restrict__ dst, int ld, const int32_t* __restrict__ perm,
+                                const int32_t* __restrict__ ids) {
+    constexpr int NS = 16 / (int)sizeof(T);
+    typedef T TN __attribute__((ext_vector_type(NS)));
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c * NS >= ld) return;
+    int r = blockIdx.y;
+    if (perm) r = perm[r];
+    if (ids) r = ids[r];
+    *(TN*)(dst + (int64_t)blockIdx.y * ld + (int64_t)c * NS) = *(const TN*)(src + (int64_t)r * ld + (int64_t)c * NS);
+}
+
+// nz[tile][kt] = OR of flags[perm[r]][kt] over the rows r of the 256-row tile (rows >= B are padding).  Block =
+// 16 row slices x 16 words of 4 K tiles: 16 rows per thread, then an OR over the slices in LDS (one thread per K tile
+// looping over 256 rows was a 76 us chain of dependent byte loads in front of the GEMM's tile lists).
+__global__ void k_tile_or(const uint8_t* __restrict__ flags, const int32_t* __restrict__ perm, int B, int k_tiles,
+                          uint8_t* __restrict__ nz) {
+    __shared__ uint32_t part[16][17];
+    const int cw = threadIdx.x & 15, rs = threadIdx.x >> 4, tile = blockIdx.y;
+    const int kt0 = (blockIdx.x * 16 + cw) * 4;                  // this thread's 4 K tiles
+    const int r1 = (tile + 1) * 256 < B ? (tile + 1) * 256 : B;
+    uint32_t f = 0;
+    if (kt0 < k_tiles) {
+        const bool whole = kt0 + 4 <= k_tiles && (k_tiles & 3) == 0;   // aligned 4-byte loads
+#pragma unroll 4
+        for (int r = tile * 256 + rs; r < r1; r += 16) {
+            const uint8_t* p = flags + (int64_t)(perm ? perm[r] : r) * k_tiles + kt0;
+            if (whole) {
+                f |= *(const uint32_t*)p;
+            } else {
+                for (int e = 0; e < 4 && kt0 + e < k_tiles; ++e) f |= (uint32_t)p[e] << (8 * e);
+            }
+        }
+    }
+    part[rs][cw] = f;
+    __syncthreads();
+    if (rs == 0 && kt0 < k_tiles) {
+        for (int x = 1; x < 16; ++x) f |= part[x][cw];
+        for (int e = 0; e < 4 && kt0 + e < k_tiles; ++e) nz[(int64_t)tile * k_tiles + kt0 + e] = ((f >> (8 * e)) & 0xffu) ? 1 : 0;
     }
 }
 
@@ -547,7 +639,18 @@ class EngineT : public EngineBase {
     int64_t res_unique_ = 0;
     bool full_valid_ = false;
     std::vector<int32_t> h_perm_;
+    bool h_perm_valid_ = false;                              // h_perm_ mirrors perm_ (fetched on demand, see host_perm)
     bool sorted_ = false;
+    const void* gam_pad_ptr_ = nullptr;                      // Gamma buffer / row count whose pad rows are zero
+    int64_t gam_pad_N_ = -1;
+    DevBuf rowflags_;                                        // [B][k_tiles] 1 = caller's belief row b has mass in K tile kt
+    uint64_t rowflags_ver_ = 0;                              // belief-block version rowflags_ describes
+    uint64_t nzA_ver_ = 0;                                   // belief-block version ev_nzA_ was recorded for
+    void* ids_pin_ = nullptr;                                // pinned staging of the ids of a store selection
+    size_t ids_pin_cap_ = 0;
+    hipEvent_t ev_ids_ = nullptr;
+    hipEvent_t ev_nzA_ = nullptr;                            // the resident block's zero map (nzA_) is complete
+    DevBuf nzBw_;                                            // [A*O][ceil(k_tiles/64)] support tiles of RTO as bit words
     DevBuf nzB_, nzA_, klist_, kcount_, nchunks_, need_, skws_;   // zero-tile bookkeeping of the f32 score GEMM
     DevBuf dense_, nzD_, nzAlpha_, prod_, klistD_, kcountD_, nchunksD_;   // dense projection mode
     int64_t rows_pad_s_ = 0, dense_pairs_ = 0;
@@ -594,7 +697,7 @@ class EngineT : public EngineBase {
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &snz_, &sbtl_, &sbtc_, &vmax_bk_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
-                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_};
+                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_};
         // every call is checked only to name a failure when PBVI_DEBUG is set; the thread's sticky last-error is cleared at
         // the end either way, so that a later launch check does not report a stale error of this teardown
         static const bool dbg = getenv("PBVI_DEBUG") != nullptr;
@@ -605,6 +708,9 @@ class EngineT : public EngineBase {
             if (e) chk(hipEventDestroy(e), "hipEventDestroy(walk)");
         for (DevBuf* b : all) b->release();
         if (host_stage_) chk(hipHostFree(host_stage_), "hipHostFree(stage)");
+        if (ids_pin_) chk(hipHostFree(ids_pin_), "hipHostFree(ids)");
+        if (ev_ids_) chk(hipEventDestroy(ev_ids_), "hipEventDestroy(ids)");
+        if (ev_nzA_) chk(hipEventDestroy(ev_nzA_), "hipEventDestroy(nzA)");
         for (auto& e : ev_)
             if (e) chk(hipEventDestroy(e), "hipEventDestroy(ev)");
         for (auto& e : ev_pg_)
@@ -773,6 +879,14 @@ class EngineT : public EngineBase {
                     if (h_er[(size_t)a * S_pad_ + s] != T(0)) h_nz[(size_t)A * O * k_tiles + s / GEMM_BK] = 1;
             if ((rc = nzB_.ensure(h_nz.size(), &bytes_))) return rc;
             HIPCHK(hipMemcpyAsync(nzB_.p, h_nz.data(), h_nz.size(), hipMemcpyHostToDevice, stream_));
+            // the same supports as bit words (bit t of word w = K tile 64 w + t), for the dead-triple test
+            const int kw = (k_tiles + 63) / 64;
+            std::vector<unsigned long long> h_nzw((size_t)A * O * kw, 0ull);
+            for (int ao = 0; ao < A * O; ++ao)
+                for (int kt = 0; kt < k_tiles; ++kt)
+                    if (h_nz[(size_t)ao * k_tiles + kt]) h_nzw[(size_t)ao * kw + kt / 64] |= 1ull << (kt & 63);
+            if ((rc = nzBw_.ensure(h_nzw.size() * sizeof(unsigned long long), &bytes_))) return rc;
+            HIPCHK(hipMemcpyAsync(nzBw_.p, h_nzw.data(), h_nzw.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream_));
             std::vector<int32_t> h_irr;
             // For the fused score GEMM (gemm.hip, schedulers 2b / 2c): K tiles that hold a 4-state chunk whose successors
             // (for some r) are not 4 consecutive states.  R = 1: the kernel gathers those itself; R = 2..7: those Gamma tiles
@@ -903,48 +1017,59 @@ class EngineT : public EngineBase {
 
     int64_t alpha_count() const override { return V_; }
 
-    // Belief block from rows staged on the device (stage_ [B][S_pad]): optional reordering, padding to the
-    // GEMM's 256-row blocks, non-zero tile map.
-    int beliefs_finish(int64_t B) {
+    // Belief block from rows on the device -- `src` [.][S_pad], row b of the block = src row (src_ids ? src_ids[b] : b) --
+    // reordered, padded to the GEMM's 256-row blocks, with its zero-tile map.  Stream-ordered, no host synchronisation:
+    // the host's copy of the order (h_perm_) is fetched when a host-side consumer asks for it (host_perm).
+    int beliefs_finish(int64_t B, const T* src, const int32_t* src_ids) {
         const int64_t Bp = round_up(B, GEMM_BM);
+        const int k_tiles = S_pad_ / GEMM_BK;
         int rc = bel_.ensure((size_t)Bp * S_pad_ * sizeof(T), &bytes_);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(bel_.p, 0, (size_t)Bp * S_pad_ * sizeof(T), stream_));
+        if ((rc = rowflags_.ensure((size_t)B * k_tiles, &bytes_))) return rc;
+        if ((rc = keys_.ensure((size_t)B * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = perm_.ensure((size_t)B * sizeof(int32_t), &bytes_))) return rc;
+        if ((rc = nzA_.ensure((size_t)(Bp / GEMM_BM) * k_tiles, &bytes_))) return rc;
+        if (Bp > B) HIPCHK(hipMemsetAsync(bel_.as<T>() + (size_t)B * S_pad_, 0, (size_t)(Bp - B) * S_pad_ * sizeof(T), stream_));
         static const bool no_sort = getenv("PBVI_NO_BELIEF_SORT") != nullptr;     // debug / A-B only
         sorted_ = B > (kF32 ? GEMM_BM : 128) && !no_sort;     // more than one row block of the score GEMM
+        hipLaunchKernelGGL(k_row_flags<T>, dim3((unsigned)B), dim3(256), 0, stream_, src, S_pad_, src_ids, S_pad_, k_tiles,
+                           rowflags_.as<uint8_t>(), keys_.as<int32_t>());
+        HIPCHK(hipGetLastError());
+        const int32_t* perm = nullptr;
         if (sorted_) {
-            if ((rc = keys_.ensure((size_t)B * sizeof(int32_t), &bytes_))) return rc;
-            if ((rc = perm_.ensure((size_t)B * sizeof(int32_t), &bytes_))) return rc;
-            hipLaunchKernelGGL(k_first_tile<T>, dim3((unsigned)B), dim3(256), 0, stream_, stage_.as<T>(), S_pad_, S_,
-                               keys_.as<int32_t>());
+            hipLaunchKernelGGL(k_rank_sort, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream_, keys_.as<int32_t>(), (int)B,
+                               perm_.as<int32_t>());
             HIPCHK(hipGetLastError());
-            std::vector<int32_t> key((size_t)B);
-            HIPCHK(hipMemcpyAsync(key.data(), keys_.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-            HIPCHK(hipStreamSynchronize(stream_));
-            h_perm_.resize((size_t)B);
-            for (int64_t i = 0; i < B; ++i) h_perm_[(size_t)i] = (int32_t)i;
-            std::stable_sort(h_perm_.begin(), h_perm_.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
-            HIPCHK(hipMemcpyAsync(perm_.p, h_perm_.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
-            hipLaunchKernelGGL(k_gather_rows<T>, dim3((S_pad_ + 255) / 256, (unsigned)B), dim3(256), 0, stream_,
-                               stage_.as<T>(), bel_.as<T>(), S_pad_, perm_.as<int32_t>());
-            HIPCHK(hipGetLastError());
-        } else {
-            HIPCHK(hipMemcpyAsync(bel_.p, stage_.p, (size_t)B * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+            perm = perm_.as<int32_t>();
         }
-        {   // which 256x32 belief tiles hold a non-zero (A-operand side of zero-tile skipping)
-            const int k_tiles = S_pad_ / GEMM_BK;
-            if ((rc = nzA_.ensure((size_t)(Bp / GEMM_BM) * k_tiles, &bytes_))) return rc;
-            if constexpr (kF32)
-                HIPCHK(launch_tile_nonzero_f32((const float*)bel_.p, S_pad_, (int)Bp, k_tiles, nzA_.as<uint8_t>(), stream_));
-            else
-                HIPCHK(launch_tile_nonzero_f64((const double*)bel_.p, S_pad_, (int)Bp, k_tiles, nzA_.as<uint8_t>(), stream_));
-        }
-        HIPCHK(hipStreamSynchronize(stream_));
+        // the zero map first: the score GEMM's tile lists (another stream) need nothing else of the block
+        hipLaunchKernelGGL(k_tile_or, dim3((k_tiles + 63) / 64, (unsigned)(Bp / GEMM_BM)), dim3(256), 0, stream_,
+                           rowflags_.as<uint8_t>(), perm, (int)B, k_tiles, nzA_.as<uint8_t>());
+        HIPCHK(hipGetLastError());
+        if (!ev_nzA_) HIPCHK(hipEventCreateWithFlags(&ev_nzA_, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_nzA_, stream_));
+        constexpr int NS = 16 / (int)sizeof(T);
+        hipLaunchKernelGGL(k_gather_rows_v<T>, dim3((S_pad_ / NS + 255) / 256, (unsigned)B), dim3(256), 0, stream_, src, bel_.as<T>(),
+                           S_pad_, perm, src_ids);
+        HIPCHK(hipGetLastError());
         B_ = B;
         B_pad_ = Bp;
         ++bel_ver_;
+        rowflags_ver_ = bel_ver_;
+        nzA_ver_ = bel_ver_;
+        h_perm_valid_ = false;
         have_result_ = false;
         btl_valid_ = false;
+        return PBVI_OK;
+    }
+
+    // h_perm_[i] = caller's index of engine row i (sorted blocks), for the host-side consumers of the order
+    int host_perm() {
+        if (!sorted_ || h_perm_valid_) return PBVI_OK;
+        h_perm_.resize((size_t)B_);
+        HIPCHK(hipMemcpyAsync(h_perm_.data(), perm_.p, (size_t)B_ * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        h_perm_valid_ = true;
         return PBVI_OK;
     }
 
@@ -957,7 +1082,9 @@ class EngineT : public EngineBase {
         HIPCHK(hipMemsetAsync(stage_.p, 0, (size_t)B * S_pad_ * sizeof(T), stream_));
         HIPCHK(hipMemcpy2DAsync(stage_.p, (size_t)S_pad_ * sizeof(T), bel, (size_t)S_ * sizeof(T), (size_t)S_ * sizeof(T),
                                 (size_t)B, hipMemcpyHostToDevice, stream_));
-        return beliefs_finish(B);
+        if ((rc = beliefs_finish(B, stage_.as<T>(), nullptr))) return rc;
+        HIPCHK(hipStreamSynchronize(stream_));               // the caller's array is free again
+        return PBVI_OK;
     }
 
     // ---- batched belief update ---------------------------------------------- //
@@ -1000,6 +1127,7 @@ class EngineT : public EngineBase {
         if ((rc = bu_mass_.ensure((size_t)B_ * sizeof(double), &bytes_))) return rc;
         if ((rc = bu_out_.ensure((size_t)B_ * S_ * sizeof(T), &bytes_))) return rc;
         // act/obs arrive in the caller's belief order; the resident block may be sorted
+        if ((rc = host_perm())) return rc;
         std::vector<int32_t> ha((size_t)B_), ho((size_t)B_);
         for (int64_t i = 0; i < B_; ++i) {
             const int64_t c = sorted_ ? h_perm_[(size_t)i] : i;
@@ -1055,6 +1183,7 @@ class EngineT : public EngineBase {
         if ((rc = bu_unnorm_.ensure((size_t)B_ * S_ * sizeof(double), &bytes_))) return rc;
         if ((rc = bu_mass_.ensure((size_t)B_ * sizeof(double), &bytes_))) return rc;
         if ((rc = stage_.ensure((size_t)nb * S_pad_ * sizeof(T), &bytes_))) return rc;
+        if ((rc = host_perm())) return rc;
         std::vector<int32_t> ha((size_t)B_), ho((size_t)B_), hr((size_t)B_);
         for (int64_t i = 0; i < B_; ++i) {               // engine row i holds the caller's row c
             const int64_t c = sorted_ ? h_perm_[(size_t)i] : i;
@@ -1071,7 +1200,7 @@ class EngineT : public EngineBase {
                                        bu_act_.as<int32_t>(), bu_obs_.as<int32_t>(), bu_row_.as<int32_t>(),
                                        bu_unnorm_.as<double>(), bu_mass_.as<double>(), stage_.as<T>(), S_pad_, stream_));
         HIPCHK(hipStreamSynchronize(stream_));           // ha/ho/hr are pageable host vectors
-        return beliefs_finish(nb);
+        return beliefs_finish(nb, stage_.as<T>(), nullptr);
     }
 
     // resident belief block back to the host (or a device buffer), caller order: [B][S] T
@@ -1083,6 +1212,8 @@ class EngineT : public EngineBase {
             HIPCHK(hipMemcpy2DAsync(out, (size_t)S_ * sizeof(T), bel_.p, (size_t)S_pad_ * sizeof(T), (size_t)S_ * sizeof(T),
                                     (size_t)B_, hipMemcpyDefault, stream_));
         } else {
+            int rc = host_perm();
+            if (rc) return rc;
             for (int64_t i = 0; i < B_; ++i)
                 HIPCHK(hipMemcpyAsync((char*)out + (size_t)h_perm_[(size_t)i] * S_ * sizeof(T),
                                       bel_.as<T>() + (size_t)i * S_pad_, (size_t)S_ * sizeof(T), hipMemcpyDefault, stream_));
@@ -1327,7 +1458,28 @@ class EngineT : public EngineBase {
         HIPCHK(hipSetDevice(device_));
         int rc = ids_.ensure((size_t)n * sizeof(int32_t), &bytes_);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(ids_.p, ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        if (which == 1) {   // not synchronised below: the ids travel through a pinned buffer of the engine's own
+            const size_t bytes = (size_t)n * sizeof(int32_t);
+            if (ids_pin_cap_ < bytes) {
+                HIPCHK(hipStreamSynchronize(stream_));
+                if (ids_pin_) (void)hipHostFree(ids_pin_);
+                ids_pin_ = nullptr;
+                ids_pin_cap_ = 0;
+                if (hipHostMalloc(&ids_pin_, std::max<size_t>(bytes, 65536), hipHostMallocDefault) != hipSuccess) {
+                    (void)hipGetLastError();
+                    FAIL(PBVI_ENOMEM, "store_select: pinned staging for the ids");
+                }
+                ids_pin_cap_ = std::max<size_t>(bytes, 65536);
+            } else if (ev_ids_) {
+                HIPCHK(hipEventSynchronize(ev_ids_));        // the previous selection's copy has left the buffer
+            }
+            std::memcpy(ids_pin_, ids, bytes);
+            HIPCHK(hipMemcpyAsync(ids_.p, ids_pin_, bytes, hipMemcpyHostToDevice, stream_));
+            if (!ev_ids_) HIPCHK(hipEventCreateWithFlags(&ev_ids_, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ev_ids_, stream_));
+        } else {
+            HIPCHK(hipMemcpyAsync(ids_.p, ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+        }
         if (which == 0) {   // working alpha set := stored rows in the caller's order
             static const bool no_prepend = getenv("PBVI_NO_ALPHA_PREPEND") != nullptr;      // debug / A-B only
             auto gather = [&](T* dst, int64_t first, int64_t cnt) -> int {             // ids [first, first + cnt) -> dst rows
@@ -1394,11 +1546,9 @@ class EngineT : public EngineBase {
             have_result_ = false;
             return PBVI_OK;
         }
-        if ((rc = stage_.ensure((size_t)n * S_pad_ * sizeof(T), &bytes_))) return rc;
-        hipLaunchKernelGGL(k_gather_rows<T>, dim3((S_pad_ + 255) / 256, (unsigned)n), dim3(256), 0, stream_,
-                           store_[1].as<T>(), stage_.as<T>(), S_pad_, ids_.as<int32_t>());
-        HIPCHK(hipGetLastError());
-        return beliefs_finish(n);
+        // the block is gathered straight from the store rows, in sorted order (no staging copy); nothing here waits for the
+        // device: the backup that follows is enqueued behind it
+        return beliefs_finish(n, store_[1].as<T>(), ids_.as<int32_t>());
     }
 
     // device pointer to the stream-K share size (K-tile steps of the longest f32 chain) or nullptr
@@ -1729,6 +1879,7 @@ class EngineT : public EngineBase {
         double* dv = out_value;
         int32_t* di = out_index;
         if (sorted_) {                      // device results are in sorted belief order
+            if ((rc = host_perm())) return rc;
             tv.resize((size_t)B_);
             ti.resize((size_t)B_);
             dv = tv.data();
@@ -2166,8 +2317,13 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
     const int64_t n_rows_alloc = kF32 ? round_up(N, GEMM_BN) : N;
     if (!use_push) {
         if ((rc = gam_.ensure((size_t)n_rows_alloc * S_pad_ * sizeof(T), &bytes_))) return rc;
-        if (n_rows_alloc > N)   // zero the Gamma pad rows the GEMM tiles read
+        // zero the Gamma pad rows the GEMM tiles read -- once per (buffer, row count): nothing writes rows >= N, and the
+        // fill of up to 255 rows (27 MB, 39 us at |S| = 30000) sat in front of every backup's score GEMM
+        if (n_rows_alloc > N && (gam_pad_ptr_ != gam_.p || gam_pad_N_ != N || mode_ == PBVI_DENSE)) {
             HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)N * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
+            gam_pad_ptr_ = gam_.p;
+            gam_pad_N_ = N;
+        }
     }
     SlabView<T> sv;
     out->extra_row0 = -1;
@@ -2445,7 +2601,9 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     HIPCHK(hipStreamWaitEvent(side, ev_fork_, 0));
     static const bool lists_on_side = getenv("PBVI_LISTS_ON_SIDE") != nullptr;      // debug / A-B only: lists behind k_dead
     hipStream_t lists = no_side ? nullptr : (lists_on_side ? side : stream3_);
-    if (lists != nullptr && lists != side) HIPCHK(hipStreamWaitEvent(lists, ev_fork_, 0));
+    // (the tile lists need the block's zero map only: where the block was indexed just now they do not wait for its gather)
+    if (lists != nullptr && lists != side)
+        HIPCHK(hipStreamWaitEvent(lists, (!screened && ev_nzA_ != nullptr && nzA_ver_ == bel_ver_) ? ev_nzA_ : ev_fork_, 0));
     if (windows) {   // exact, from the supports of the ORIGINAL operands (an fp32 copy may have flushed tiny values to zero)
         if ((rc = btl_.ensure((size_t)B_ * k_tiles * sizeof(int32_t), &bytes_))) return rc;
         if ((rc = btc_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
@@ -2456,8 +2614,11 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         // the block's sort order and zero-tile map they index the INPUT; nothing of a backup's result is kept.
         static const bool no_cache = getenv("PBVI_NO_DEAD_CACHE") != nullptr;       // debug / A-B only
         if (dead_ver_ != bel_ver_ || !btl_valid_ || dead_pairs_ != pairs || no_cache) {
-            HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzB_.as<uint8_t>(), k_tiles, dead_.as<uint8_t>(),
-                                  btl_.as<int32_t>(), btc_.as<int32_t>(), counters_.as<int>() + 5, side));
+            const bool have_flags = rowflags_ver_ == bel_ver_ && rowflags_.p != nullptr;   // left by the block's indexing pass
+            HIPCHK(launch_dead<T>(bel_.as<T>(), S_pad_, (int)B_, mv, nzBw_.as<unsigned long long>(), k_tiles, dead_.as<uint8_t>(),
+                                  btl_.as<int32_t>(), btc_.as<int32_t>(), counters_.as<int>() + 5, side,
+                                  have_flags ? rowflags_.as<uint8_t>() : nullptr,
+                                  have_flags && sorted_ ? perm_.as<int32_t>() : nullptr));
             btl_valid_ = true;
             dead_ver_ = bel_ver_;
             dead_pairs_ = pairs;
