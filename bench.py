@@ -261,6 +261,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    exchange_parts = []
+
     def step():
         if distributed:
             if exchange_rows:
@@ -269,7 +271,10 @@ def main():
                 return st
             # local backup -> one all-gather of integers -> global dedup -> every replica appends the distinct rows
             eng.reset_store('alpha')                                # same store contents every step
-            return sharded_engine_step(shard, dist, None, n_total)[5]
+            timing = {}
+            st = sharded_engine_step(shard, dist, None, n_total, timing=timing)[5]
+            exchange_parts.append(timing)
+            return st
         if rotate:                                                    # a block the engine has no indexes of
             eng.select_beliefs(block_ids[step.n % len(block_ids)])
             step.n += 1
@@ -354,6 +359,13 @@ def main():
             st = stats[-1]
             out.update({'unique_rows': int(st['n_unique']), 'refined_pairs': int(st['n_refined']), 'dead_pairs': int(st['n_dead']),
                         'refined_actions': int(st['n_refined_actions']), 'pairs': int(st['n_pairs']), 'split_k': int(st['split_k'])})
+        if exchange_parts:
+            # host-side split of the sharded step on rank 0 (wall clock around each part; the timed steps only): local
+            # backup + the engine packing its message | all-gather | message to host | merge | append of the distinct rows
+            parts = exchange_parts[-K:]
+            out['exchange_ms'] = {k: float(np.median([p[k] for p in parts])) for k in parts[0]}
+            out['exchange_ms']['note'] = ('collective = ' + str(dist.get_backend()) + f', {world} rank(s); RCCL with more than one '
+                                          'rank has not run on GPUs in any round (one-GPU boxes)')
         if reused is not None:
             out['value_reused_block'] = B / reused
             out['ms_per_step_reused_block'] = reused * 1e3

@@ -233,6 +233,18 @@ int pbvi_assemble_rows(pbvi_engine_t* e, double gamma, int64_t n, const int32_t*
  * backup, src/pomdp.py:1521-1522 / src/mdp.py:763-779): returns the store id of the first of the n appended rows,
  * or a negative error code.  out_rows (host or device, [n][S] T) may be NULL. */
 int64_t pbvi_assemble_rows_store(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows);
+/*
+ * Host side of the key exchange of a belief-sharded backup (the step between the all-gather and
+ * pbvi_assemble_rows_store; the reference has no counterpart: one device, Experiments/Olfactory Navigation/run_test.py:12).
+ * all_meta: the `world` messages of pbvi_backup_fetch_exchange_padded in rank order, `stride` int32 apart
+ * (stride >= 1 + 3 per + per key_width: a caller may carry its own trailer behind each message), HOST memory.
+ * Rank r holds the beliefs [r per, min((r+1) per, n_total)).  Equal keys found by different ranks are ONE row.
+ *   out_keys   [sum of the messages' counts][key_width]  the globally distinct keys in order of first occurrence
+ *   out_index  [n_total]  position of each belief's key in out_keys     out_action / out_keep [n_total]
+ * Returns the number of distinct keys, or a negative error code.  Pure host code: needs no engine and no device.
+ */
+int64_t pbvi_exchange_merge(const int32_t* all_meta, int32_t world, int64_t stride, int64_t per, int32_t key_width,
+                            int64_t n_total, int32_t* out_keys, int32_t* out_index, int32_t* out_action, uint8_t* out_keep);
 
 /*
  * Device addresses of the last run's results, for the multi-GPU layer to hand to

@@ -3109,6 +3109,82 @@ int64_t pbvi_assemble_rows_store(pbvi_engine_t* e, double gamma, int64_t n, cons
     NEED(e);
     return e->impl->assemble_keys_store(gamma, n, keys, out_rows);
 }
+// Host side of the key exchange (no engine, no device): the ranks' messages -> globally distinct keys in order of first
+// occurrence + per-belief positions.  A few hundred keys and <= 65535 beliefs per rank: one pass with a small
+// open-addressing table (the NumPy version -- np.unique over key rows, five fancy-index passes -- took 0.36 ms for eight
+// messages of 1024 beliefs; this is a few microseconds).
+int64_t pbvi_exchange_merge(const int32_t* all_meta, int32_t world, int64_t stride, int64_t per, int32_t key_width,
+                            int64_t n_total, int32_t* out_keys, int32_t* out_index, int32_t* out_action, uint8_t* out_keep) {
+    if (!all_meta || world <= 0 || per <= 0 || key_width <= 0 || key_width > 64 || n_total < 0 || !out_keys || !out_index ||
+        !out_action || !out_keep) {
+        pbvi::set_error("exchange_merge: bad arguments");
+        return PBVI_EINVAL;
+    }
+    const int64_t n_meta = 1 + 3 * per + per * (int64_t)key_width;
+    if (stride < n_meta || n_total > (int64_t)world * per || (int64_t)world * per > 0x7fffffff) {
+        pbvi::set_error("exchange_merge: message stride / belief count do not fit the block size");
+        return PBVI_EINVAL;
+    }
+    int64_t total = 0;
+    for (int r = 0; r < world; ++r) {
+        const int64_t c = all_meta[(int64_t)r * stride];
+        if (c < 0 || c > per) {
+            pbvi::set_error("exchange_merge: corrupt message (unique-row count out of range)");
+            return PBVI_EINVAL;
+        }
+        total += c;
+    }
+    size_t cap = 16;
+    while (cap < (size_t)total * 2 + 1) cap <<= 1;
+    std::vector<int32_t> table, pos;
+    try {
+        table.assign(cap, -1);                               // slot -> position in out_keys
+        pos.assign((size_t)std::max<int64_t>(total, 1), 0);  // (rank, u) -> position, ranks concatenated
+    } catch (const std::bad_alloc&) {
+        pbvi::set_error("exchange_merge: host allocation failed");
+        return PBVI_ENOMEM;
+    }
+    int64_t n_keys = 0, base = 0;
+    for (int r = 0; r < world; ++r) {
+        const int32_t* msg = all_meta + (int64_t)r * stride;
+        const int32_t* keys = msg + 1 + 3 * per;
+        const int64_t c = msg[0];
+        for (int64_t u = 0; u < c; ++u) {
+            const int32_t* k = keys + u * key_width;
+            uint64_t h = 1469598103934665603ull;
+            for (int j = 0; j < key_width; ++j) h = (h ^ (uint32_t)k[j]) * 1099511628211ull;
+            size_t slot = (size_t)(h ^ (h >> 29)) & (cap - 1);
+            for (;;) {
+                const int32_t at = table[slot];
+                if (at < 0) {                                // first occurrence: the key gets the next position
+                    std::memcpy(out_keys + n_keys * key_width, k, (size_t)key_width * sizeof(int32_t));
+                    table[slot] = (int32_t)n_keys;
+                    pos[(size_t)(base + u)] = (int32_t)n_keys++;
+                    break;
+                }
+                if (std::memcmp(out_keys + (int64_t)at * key_width, k, (size_t)key_width * sizeof(int32_t)) == 0) {
+                    pos[(size_t)(base + u)] = at;            // the same row found by another rank (or twice by this one)
+                    break;
+                }
+                slot = (slot + 1) & (cap - 1);
+            }
+        }
+        // this rank's beliefs, global belief order: rank r holds [r * per, min((r + 1) * per, n_total))
+        const int64_t lo = std::min<int64_t>((int64_t)r * per, n_total), hi = std::min<int64_t>(lo + per, n_total);
+        for (int64_t j = 0; j < hi - lo; ++j) {
+            const int32_t u = msg[1 + j];
+            if (u < 0 || u >= c) {
+                pbvi::set_error("exchange_merge: corrupt message (row index out of range)");
+                return PBVI_EINVAL;
+            }
+            out_index[lo + j] = pos[(size_t)(base + u)];
+            out_action[lo + j] = msg[1 + per + j];
+            out_keep[lo + j] = msg[1 + 2 * per + j] ? 1 : 0;
+        }
+        base += c;
+    }
+    return n_keys;
+}
 int pbvi_assemble_rows(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows) {
     NEED(e);
     return e->impl->assemble_keys(gamma, n, keys, out_rows);

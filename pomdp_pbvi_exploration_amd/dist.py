@@ -19,8 +19,16 @@ Two exchanges:
 Every message is padded to the common block size, so ragged splits (B % G != 0) and empty shards (B < G) send
 equally long messages; a rank without beliefs contributes a zero-count message instead of skipping the collective.
 
-``sharded_backup`` is what ``PBVI_Solver.backup`` calls when a process group with more than one rank is up
-(``active()``): same arguments, same return value as the single-process backup.
+``sharded_backup`` is what ``PBVI_Solver.backup`` calls when sharding was ASKED FOR (``PBVI_Solver.shard_beliefs =
+True``, ``enable(True)`` or ``PBVI_SHARD=1``) and a process group with more than one rank is up: same arguments, same
+return value as the single-process backup.  It is opt-in because it is only correct when every rank calls it with
+the same model, belief set and value function -- ranks that run independent experiments (the reference's
+one-process-per-GPU ``run_test.py`` pattern) must not be coupled by a collective they did not ask for.  What can be
+checked is checked: every message carries ``(n_total, |V|, a fingerprint of the alpha set's store ids)`` behind the
+engine's payload and every rank compares all of them after the gather (``ReplicaMismatch``).
+
+Hardware status: the >= 2-rank RCCL path has not run on GPUs in any round (one-GPU boxes); it is covered by gloo tests
+with one engine per rank and by a one-rank RCCL group.
 """
 from __future__ import annotations
 
@@ -30,12 +38,66 @@ import sys
 import numpy as np
 
 
-def active(group=None) -> bool:
-    """True when this process is one rank of a multi-rank ``torch.distributed`` job (and ``PBVI_NO_SHARD`` is unset)."""
-    if 'torch' not in sys.modules or os.environ.get('PBVI_NO_SHARD'):
+_ENABLED = None          # None: the environment decides (PBVI_SHARD=1); True / False: enable() was called
+
+
+class ReplicaMismatch(RuntimeError):
+    """The ranks of a sharded backup do not hold the same problem (belief count, alpha set)."""
+
+
+def enable(on: bool = True) -> None:
+    """Process-wide opt-in (or opt-out) for belief sharding in ``PBVI_Solver.backup``."""
+    global _ENABLED
+    _ENABLED = bool(on)
+
+
+def requested(solver=None) -> bool:
+    """Was sharding asked for?  The solver's ``shard_beliefs`` attribute wins, then ``enable()``, then ``PBVI_SHARD=1``."""
+    want = getattr(solver, 'shard_beliefs', None)
+    if want is None:
+        want = _ENABLED
+    if want is None:
+        want = os.environ.get('PBVI_SHARD', '') not in ('', '0')
+    return bool(want) and not os.environ.get('PBVI_NO_SHARD')
+
+
+def active(group=None, solver=None) -> bool:
+    """True when sharding was asked for (``requested``) and this process is one rank of a multi-rank
+    ``torch.distributed`` job."""
+    if 'torch' not in sys.modules or not requested(solver):
         return False
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+# Trailer every rank appends to its exchange message: what must be equal on all ranks for the keys to mean the same rows
+TRAILER = 4
+_MAGIC = 0x50425649
+
+
+def alpha_fingerprint(engine) -> int:
+    """31-bit fingerprint of the working alpha set's identity: the store ids it was selected by (replicas that appended
+    the same rows in the same order hold the same ids), or just its size when it was uploaded as an array."""
+    import zlib
+    ids = engine._resident.get('alpha') if hasattr(engine, '_resident') else None
+    if ids is None:
+        return int(engine.alpha_count()) & 0x7fffffff
+    return zlib.crc32(np.ascontiguousarray(ids, dtype=np.int32).tobytes()) & 0x7fffffff
+
+
+def trailer_values(n_total: int, V: int, fingerprint: int) -> np.ndarray:
+    return np.array([_MAGIC, n_total & 0x7fffffff, V & 0x7fffffff, fingerprint & 0x7fffffff], dtype=np.int32)
+
+
+def check_trailers(all_meta: np.ndarray, n_meta: int, mine: np.ndarray) -> None:
+    """all_meta [world, n_meta + TRAILER]: every rank's trailer must equal this rank's."""
+    got = all_meta[:, n_meta:n_meta + TRAILER]
+    bad = np.flatnonzero(np.any(got != mine[None, :], axis=1))
+    if bad.size:
+        r = int(bad[0])
+        raise ReplicaMismatch(f'sharded backup: rank {r} sent (magic, n_total, |V|, alpha fingerprint) = {got[r].tolist()}, '
+                              f'this rank has {mine.tolist()}: the ranks do not hold the same belief set / value function '
+                              f'(belief sharding needs replicated inputs; unset shard_beliefs / PBVI_SHARD for independent runs)')
 
 
 def shard_bounds(n: int, world: int, rank: int):
@@ -193,44 +255,56 @@ def pack_exchange(keys, count: int, index, actions, keep, per: int = None):
 
 
 def merge_exchange(all_meta: np.ndarray, per: int, key_width: int, n_total: int):
-    """Host side of the key exchange.  ``all_meta [world, 1 + 3 per + per kw]`` int32 (every rank's message) ->
-    ``(keys [n, kw], index [n_total], actions [n_total], keep [n_total])``: the globally distinct keys in order of
-    first occurrence over ranks, and per belief (global belief order) the position of its key in that list."""
-    world = all_meta.shape[0]
-    counts = all_meta[:, 0].astype(np.int64)
-    if np.any(counts < 0) or np.any(counts > per):
-        raise ValueError('corrupt exchange message: unique-row count out of range')
-    k0 = 1 + 3 * per
-    keys = np.concatenate([all_meta[r, k0:k0 + counts[r] * key_width].reshape(counts[r], key_width) for r in range(world)])
-    offs = np.cumsum(counts) - counts
-    idx = (all_meta[:, 1:1 + per].astype(np.int64) + offs[:, None]).reshape(-1)
-    act = all_meta[:, 1 + per:1 + 2 * per].reshape(-1)
-    keep = all_meta[:, 1 + 2 * per:1 + 3 * per].reshape(-1)
-    if world * per != n_total:
-        valid = _valid_mask(n_total, world, per)
-        idx, act, keep = idx[valid], act[valid], keep[valid]
-    if keys.shape[0] == 0:
-        return keys, idx, act.astype(np.int64), keep.astype(bool)
-    # equal keys on different ranks are the same row (replicated alpha set): keep the first, in concatenation order
-    _, first, inv = np.unique(keys, axis=0, return_index=True, return_inverse=True)
-    order = np.argsort(first, kind='stable')
-    pos = np.empty_like(order)
-    pos[order] = np.arange(len(order))
-    return keys[first[order]], pos[inv.reshape(-1)][idx], act.astype(np.int64), keep.astype(bool)
+    """Host side of the key exchange.  ``all_meta [world, >= 1 + 3 per + per kw]`` int32 (every rank's message, a
+    trailer may follow the payload) -> ``(keys [n, kw], index [n_total], actions [n_total], keep [n_total])``: the
+    globally distinct keys in order of first occurrence over ranks, and per belief (global belief order) the
+    position of its key in that list.  Native (``pbvi_exchange_merge``): one pass with a hash table."""
+    from .engine import load_library
+    lib = load_library()
+    all_meta = np.ascontiguousarray(all_meta, dtype=np.int32)
+    world, stride = all_meta.shape
+    total = int(np.clip(all_meta[:, 0], 0, per).sum())
+    keys = np.empty((max(total, 1), key_width), dtype=np.int32)
+    idx = np.empty(n_total, dtype=np.int32)
+    act = np.empty(n_total, dtype=np.int32)
+    keep = np.empty(n_total, dtype=np.uint8)
+    n = int(lib.pbvi_exchange_merge(all_meta.ctypes.data, world, stride, per, key_width, n_total, keys.ctypes.data,
+                                    idx.ctypes.data, act.ctypes.data, keep.ctypes.data))
+    if n < 0:
+        raise ValueError('corrupt exchange message: ' + (lib.pbvi_last_error() or b'').decode())
+    return keys[:n], idx.astype(np.int64), act.astype(np.int64), keep.astype(bool)
 
 
-def exchange_keys(dist, group, meta, per: int, key_width: int, n_total: int):
+def exchange_keys(dist, group, meta, per: int, key_width: int, n_total: int, trailer=None, timing=None):
     """ONE ``all_gather_into_tensor`` of the per-rank int32 messages (``meta``: a torch tensor on the backend's
-    carrier device), then the host-side merge.  Returns ``merge_exchange``'s tuple."""
+    carrier device; ``1 + 3 per + per kw`` payload entries, ``+ TRAILER`` when ``trailer`` -- this rank's
+    ``trailer_values`` -- is given: it is written behind the payload here and compared across ranks after the
+    gather), then the host-side merge.  Returns ``merge_exchange``'s tuple.  ``timing``: a dict that receives the
+    wall-clock split ``gather_ms`` / ``to_host_ms`` / ``merge_ms``."""
+    import time
     import torch
     world = dist.get_world_size(group)
     _check_common_per(per, n_total, world)
     n_meta = 1 + 3 * per + per * key_width
-    if meta.shape[0] != n_meta:
-        raise ValueError(f'exchange message has {meta.shape[0]} entries, block size {per} needs {n_meta}')
-    flat = torch.empty(world * n_meta, dtype=torch.int32, device=meta.device)
+    n_msg = int(meta.shape[0])
+    if n_msg != n_meta + TRAILER and not (trailer is None and n_msg == n_meta):
+        raise ValueError(f'exchange message has {n_msg} entries, block size {per} needs {n_meta} (+ {TRAILER} with a trailer)')
+    if trailer is not None:
+        meta[n_meta:] = torch.from_numpy(trailer).to(meta.device)
+    t0 = time.perf_counter()
+    flat = torch.empty(world * n_msg, dtype=torch.int32, device=meta.device)
     dist.all_gather_into_tensor(flat, meta, group=group)
-    return merge_exchange(flat.view(world, n_meta).cpu().numpy(), per, key_width, n_total)
+    if timing is not None and flat.is_cuda:
+        torch.cuda.synchronize(flat.device)
+    t1 = time.perf_counter()
+    host = flat.view(world, n_msg).cpu().numpy()
+    t2 = time.perf_counter()
+    if trailer is not None:
+        check_trailers(host, n_meta, trailer)
+    out = merge_exchange(host, per, key_width, n_total)
+    if timing is not None:
+        timing.update(gather_ms=(t1 - t0) * 1e3, to_host_ms=(t2 - t1) * 1e3, merge_ms=(time.perf_counter() - t2) * 1e3)
+    return out
 
 
 def gather_packed(dist, group, meta, per: int, key_width: int, n_total: int, assemble):
@@ -289,12 +363,15 @@ class EngineShard:
         return rows, self.engine.unique_count, idx, acts, keep, stats
 
     def message(self, per: int):
-        """The int32 carrier tensor of one exchange message for block size ``per``."""
+        """The int32 carrier tensor of one exchange message for block size ``per``: the engine's payload + the trailer."""
         t = self.torch
-        n = self.engine.exchange_size(per)
+        n = self.engine.exchange_size(per) + TRAILER
         if self._keys is None or self._keys.shape[0] != n:
             self._keys = t.zeros(n, dtype=t.int32, device=self.device)
         return self._keys
+
+    def trailer(self, n_total: int) -> np.ndarray:
+        return trailer_values(n_total, int(self.engine.alpha_count()), alpha_fingerprint(self.engine))
 
     def run_resident_packed(self, per: int = None):
         """For the key exchange: run, then the engine packs count, index, actions, keep and the keys of its distinct rows
@@ -326,22 +403,30 @@ class EngineShard:
         return rows, acts, keep
 
 
-def sharded_engine_step(shard: EngineShard, dist, group, n_total: int, store: bool = True):
+def sharded_engine_step(shard: EngineShard, dist, group, n_total: int, store: bool = True, timing=None):
     """One sharded backup of the belief blocks RESIDENT on the ranks' engines (``bench.py --gpus N``): local backup,
     key exchange, global dedup, and every replica appends the globally distinct rows to its alpha store
-    (``pbvi_assemble_rows_store``).  Returns ``(first store id, n distinct rows, index [n_total], actions, keep, stats)``."""
+    (``pbvi_assemble_rows_store``).  Returns ``(first store id, n distinct rows, index [n_total], actions, keep, stats)``.
+    ``timing``: a dict that receives the host-side split of the step in ms (``backup_pack_ms``: local backup + the
+    engine writing its message, ``gather_ms``, ``to_host_ms``, ``merge_ms``, ``append_ms``)."""
+    import time
     world = dist.get_world_size(group)
     per = -(-n_total // world)
     eng = shard.engine
+    t0 = time.perf_counter()
     if eng.B > 0:
         meta, per, kw, stats = shard.run_resident_packed(per)
     else:
         meta, per, kw = shard.empty_message(per)
         stats = {}
-    keys, idx, act, keep = exchange_keys(dist, group, meta, per, kw, n_total)
+    t1 = time.perf_counter()
+    keys, idx, act, keep = exchange_keys(dist, group, meta, per, kw, n_total, trailer=shard.trailer(n_total), timing=timing)
+    t2 = time.perf_counter()
     first = -1
     if store and len(keys):
         _, first = eng.assemble_rows_store(keys, shard.gamma, want_rows=False)
+    if timing is not None:
+        timing.update(backup_pack_ms=(t1 - t0) * 1e3, append_ms=(time.perf_counter() - t2) * 1e3)
     return first, len(keys), idx, act, keep, stats
 
 
@@ -392,7 +477,7 @@ def sharded_backup(solver, model, belief_set, value_function, belief_dominance_p
         meta, per, kw, _ = shard.run_resident_packed(per)
     else:
         meta, per, kw = shard.empty_message(per)
-    keys, idx, act, keep = exchange_keys(dist, group, meta, per, kw, n_total)
+    keys, idx, act, keep = exchange_keys(dist, group, meta, per, kw, n_total, trailer=shard.trailer(n_total))
     if belief_dominance_prune:
         idx, act = idx[keep], act[keep]
     used, first_pos = _first_occurrence(idx)              # the order the reference's byte-dedup produces

@@ -33,7 +33,7 @@ EXPORTS = [
     'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact', 'pbvi_alpha_layout',
     'pbvi_belief_walk_keys', 'pbvi_backup_fetch_value_max',
     'pbvi_backup_fetch_compact', 'pbvi_host_alloc', 'pbvi_host_free', 'pbvi_debug_gemm_dense',
-    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_set_f64_screen', 'pbvi_set_fused_projection', 'pbvi_backup_fetch_row_hashes',
+    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_exchange_merge', 'pbvi_set_f64_screen', 'pbvi_set_fused_projection', 'pbvi_backup_fetch_row_hashes',
 ]
 
 
@@ -128,6 +128,7 @@ def load_library(path: str = LIB_PATH):
         'pbvi_backup_fetch_exchange': (C.c_int, [vp, vp]),
         'pbvi_backup_fetch_exchange_padded': (C.c_int, [vp, C.c_int64, vp]),
         'pbvi_assemble_rows_store': (C.c_int64, [vp, C.c_double, C.c_int64, vp, vp]),
+        'pbvi_exchange_merge': (C.c_int64, [vp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64, vp, vp, vp, vp]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
     }

@@ -431,16 +431,19 @@ class PBVI_Solver(Solver):
     # hot path
     # ------------------------------------------------------------------ #
     BELIEF_BLOCK = 32768      # beliefs per engine call on the GPU path
+    shard_beliefs = None      # True: shard `backup` over the ranks of the torch.distributed job; None: dist.enable() / PBVI_SHARD
 
     def backup(self, model: Model, belief_set: BeliefSet, value_function: ValueFunction,
                append: bool = False, belief_dominance_prune: bool = True) -> ValueFunction:
         """One point-based backup (``src/pomdp.py:1447-1524``): B beliefs x V
         alpha-vectors -> at most B new alpha-vectors (+ union with the old set).
 
-        As one rank of a multi-rank ``torch.distributed`` job (one process per GPU) the beliefs are sharded over the
-        ranks, one all-gather makes every rank hold the whole result and every replica appends the same rows
-        (``dist.sharded_backup``); the return value is the single-process one on every rank."""
-        if _dist.active() and len(belief_set) > 0:
+        With ``self.shard_beliefs = True`` (or ``dist.enable()`` / ``PBVI_SHARD=1``) as one rank of a multi-rank
+        ``torch.distributed`` job (one process per GPU) the beliefs are sharded over the ranks, one all-gather makes
+        every rank hold the whole result and every replica appends the same rows (``dist.sharded_backup``); the return
+        value is the single-process one on every rank.  Opt-in: every rank must call with the same model, beliefs and
+        value function (checked as far as a message trailer can: ``dist.ReplicaMismatch``)."""
+        if _dist.active(solver=self) and len(belief_set) > 0:
             new_vf = _dist.sharded_backup(self, model, belief_set, value_function, belief_dominance_prune)
         elif value_function.is_on_gpu:
             # Residency: every AlphaVector / Belief row is uploaded once into the engine's device stores; the

@@ -24,6 +24,7 @@ def main():
                                             load_POMDP_file, set_quiet, synth)
     from pomdp_pbvi_exploration_amd import dist as pdist
     set_quiet(True)
+    pdist.enable(True)                                    # sharding is opt-in
     assert pdist.active() and world == 2
 
     # 1. the reference's seeded FSVI run of the 4x3 grid with the f64 engine, every backup sharded

@@ -193,6 +193,8 @@ def _worker_solver(rank, world, port, out_dir, case):
     try:
         from pomdp_pbvi_exploration_amd import (Belief, BeliefSet, FSVI_Solver, PBVI_Solver, ValueFunction, load_POMDP_file)
         from pomdp_pbvi_exploration_amd import dist as pdist
+        assert not pdist.active()                                 # a process group alone shards nothing: opt-in
+        pdist.enable(True)
         assert pdist.active()
         model, _ = load_POMDP_file(os.path.join(REPO, 'tests', 'golden', 'models', '4x3.95-no_loop_2_grid.POMDP'))
         model.end_states = [3, 6]
@@ -238,3 +240,154 @@ def test_solver_takes_the_sharded_route(tmp_path, case, world):
     port = _free_port()
     mp.spawn(_worker_solver, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'sok{r}') for r in range(world))
+
+
+def _worker_mismatch(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import torch
+        from pomdp_pbvi_exploration_amd import dist as pdist
+        # two ranks whose replicas have diverged (different |V|): the trailer check names it instead of rebuilding rows
+        # from keys against another alpha set
+        per, kw, n_total = 4, 3, 8
+        meta = torch.zeros(1 + 3 * per + per * kw + pdist.TRAILER, dtype=torch.int32)
+        meta[0] = 1
+        trailer = pdist.trailer_values(n_total, 10 + rank, 12345)
+        try:
+            pdist.exchange_keys(dist, None, meta, per, kw, n_total, trailer=trailer)
+        except pdist.ReplicaMismatch as e:
+            assert 'do not hold the same' in str(e)
+            open(os.path.join(out_dir, f'mok{rank}'), 'w').write('ok')
+        # equal trailers pass, and the timing split is reported
+        timing = {}
+        keys, idx, act, keep = pdist.exchange_keys(dist, None, meta, per, kw, n_total, trailer=pdist.trailer_values(n_total, 10, 1),
+                                                   timing=timing)
+        assert keys.shape == (1, kw) and idx.shape == (n_total,) and set(timing) == {'gather_ms', 'to_host_ms', 'merge_ms'}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_diverged_replicas_are_named_not_merged(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_mismatch, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / f'mok{r}') for r in range(2))
+
+
+def test_solver_does_not_shard_unless_asked(monkeypatch):
+    """A torch.distributed group alone must not couple ranks that run independent experiments (the reference's
+    one-process-per-GPU run_test.py pattern): sharding is opt-in, per solver, per process or by environment."""
+    from pomdp_pbvi_exploration_amd import PBVI_Solver
+    from pomdp_pbvi_exploration_amd import dist as pdist
+    monkeypatch.delenv('PBVI_SHARD', raising=False)
+    monkeypatch.setattr(pdist, '_ENABLED', None)
+    s = PBVI_Solver(gamma=0.9)
+    assert not pdist.requested(s)
+    s.shard_beliefs = True
+    assert pdist.requested(s)
+    s.shard_beliefs = None
+    monkeypatch.setenv('PBVI_SHARD', '1')
+    assert pdist.requested(s)
+    monkeypatch.setenv('PBVI_NO_SHARD', '1')
+    assert not pdist.requested(s)
+    s.shard_beliefs = False
+    monkeypatch.delenv('PBVI_NO_SHARD')
+    assert not pdist.requested(s)
+
+
+def test_merge_of_eight_headline_sized_messages_is_bounded():
+    """BASELINE config 5's exchange on the host: eight messages of 1024 beliefs and ~70 distinct keys each (what each
+    GPU contributes at |B| = 8192) merged by ``pbvi_exchange_merge`` -- against a NumPy restatement, and timed: the
+    merge sits on the critical path of every sharded step."""
+    import time
+    from pomdp_pbvi_exploration_amd.dist import merge_exchange
+    rng = np.random.default_rng(0)
+    world, per, kw = 8, 1024, 4
+    n_meta = 1 + 3 * per + per * kw
+    allm = np.zeros((world, n_meta + 4), dtype=np.int32)            # with a trailer behind each payload
+    pool = rng.integers(0, 1024, size=(200, kw)).astype(np.int32)
+    pool[:, 0] %= 6
+    for r in range(world):
+        u = 60 + r
+        ks = pool[rng.choice(200, u, replace=False)]
+        allm[r, 0] = u
+        allm[r, 1:1 + per] = rng.integers(0, u, per)
+        allm[r, 1 + per:1 + 2 * per] = rng.integers(0, 6, per)
+        allm[r, 1 + 2 * per:1 + 3 * per] = rng.integers(0, 2, per)
+        allm[r, 1 + 3 * per:1 + 3 * per + u * kw] = ks.reshape(-1)
+    keys, idx, act, keep = merge_exchange(allm, per, kw, world * per)
+    # restatement: concatenate, first occurrence order
+    cat = np.concatenate([allm[r, 1 + 3 * per:1 + 3 * per + allm[r, 0] * kw].reshape(-1, kw) for r in range(world)])
+    seen, order = {}, []
+    for k in map(tuple, cat):
+        if k not in seen:
+            seen[k] = len(order)
+            order.append(k)
+    assert keys.tolist() == [list(k) for k in order]
+    offs = np.cumsum(allm[:, 0]) - allm[:, 0]
+    want = np.array([seen[tuple(cat[offs[r] + allm[r, 1 + j]])] for r in range(world) for j in range(per)])
+    assert np.array_equal(idx, want)
+    assert np.array_equal(act, allm[:, 1 + per:1 + 2 * per].reshape(-1)) and np.array_equal(keep, allm[:, 1 + 2 * per:1 + 3 * per].reshape(-1) != 0)
+    merge_exchange(allm, per, kw, world * per)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        merge_exchange(allm, per, kw, world * per)
+    ms = (time.perf_counter() - t0) / 50 * 1e3
+    print(f'merge of 8 x 1024 beliefs, {len(order)} distinct keys: {ms:.3f} ms')
+    assert ms < 0.2, f'{ms:.3f} ms'
+
+
+def _worker_world8(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import time
+        import torch
+        from pomdp_pbvi_exploration_amd import dist as pdist
+        per, kw = 1024, 4
+        n_total = world * per - 5                                    # ragged: the last rank holds fewer beliefs
+        rng = np.random.default_rng(100 + rank)
+        pool = np.random.default_rng(7).integers(0, 1024, size=(200, kw)).astype(np.int32)
+        u = 60 + rank
+        meta = torch.zeros(1 + 3 * per + per * kw + pdist.TRAILER, dtype=torch.int32)
+        meta[0] = u
+        meta[1:1 + per] = torch.from_numpy(rng.integers(0, u, per).astype(np.int32))
+        meta[1 + 3 * per:1 + 3 * per + u * kw] = torch.from_numpy(pool[rng.choice(200, u, replace=False)].reshape(-1))
+        tr = pdist.trailer_values(n_total, 1024, 99)
+        outs, times = [], []
+        for _ in range(12):
+            timing = {}
+            dist.barrier()
+            t0 = time.perf_counter()
+            outs.append(pdist.exchange_keys(dist, None, meta, per, kw, n_total, trailer=tr, timing=timing))
+            times.append(((time.perf_counter() - t0) * 1e3, timing))
+        keys, idx, act, keep = outs[-1]
+        assert idx.shape == (n_total,) and idx.max() == keys.shape[0] - 1 and keys.shape[0] <= 200
+        # every rank ends with the same merge
+        digest = torch.tensor([int(keys.astype(np.int64).sum()), int(idx.sum()), keys.shape[0]], dtype=torch.int64)
+        all_d = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(all_d, digest)
+        assert all(torch.equal(d, digest) for d in all_d)
+        if rank == 0:
+            tot = sorted(t for t, _ in times[2:])
+            mid = times[2:][len(times[2:]) // 2][1]
+            open(os.path.join(out_dir, 'w8'), 'w').write(
+                f'exchange_keys, gloo world 8, 1024 beliefs / ~64 keys per rank: median {tot[len(tot) // 2]:.3f} ms per step '
+                f'(gather {mid["gather_ms"]:.3f}, to host {mid["to_host_ms"]:.3f}, merge {mid["merge_ms"]:.3f})')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_key_exchange_of_eight_ranks(tmp_path):
+    """The exchange step of BASELINE config 5 with all eight ranks present (gloo on the CPU: the collective's cost here
+    says nothing about RCCL over xGMI, which has not run with more than one rank on GPUs; the message layout, the ragged
+    last shard, the trailer check and the merge are the product path's)."""
+    port = _free_port()
+    mp.spawn(_worker_world8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    line = open(tmp_path / 'w8').read()
+    print(line)
+    assert 'median' in line
