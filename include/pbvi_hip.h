@@ -405,6 +405,17 @@ int pbvi_set_tie_window(pbvi_engine_t* e, double rel);
  * allocation is filled with 0xFF bytes (NaN floats, -1 indices), so a read of memory the engine never
  * wrote fails the parity tests instead of hiding behind zero-filled pages.  Returns the previous state. */
 int pbvi_debug_poison(int enable);
+/*
+ * The MemoryError contract of src/pomdp.py:2399-2401 ("Memory full ... returning value function and history as is"):
+ * a device allocation that fails makes the call return PBVI_ENOMEM (-2), which the Python seam raises as MemoryError and
+ * PBVI_Solver.solve turns into the partial result.
+ *   pbvi_debug_alloc_limit : cap (MiB, < 0 = none; also PBVI_ALLOC_LIMIT_MB) on the bytes of device buffers ONE engine
+ *                            may hold, so that the contract can be tested deterministically; returns the previous cap.
+ *   pbvi_engine_after_oom  : after a -2, release every working set, row store and scratch buffer (the model tables stay):
+ *                            the engine is as freshly created and usable again.
+ */
+int64_t pbvi_debug_alloc_limit(int64_t mb);
+int pbvi_engine_after_oom(pbvi_engine_t* e);
 
 /* Benchmark / debug: list every K tile of every GEMM tile pair, zero or not -- the "dense backup" configuration of
  * BASELINE.json is measured this way (results are unchanged: skipped tiles only ever add +0).  Also enabled by

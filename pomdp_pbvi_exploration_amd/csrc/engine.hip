@@ -129,6 +129,13 @@ static void host_copy(void* dst, const void* src, size_t bytes) { CopyPool::get(
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    // Deterministic out-of-memory for tests of the MemoryError contract (src/pomdp.py:2399-2401): an engine may hold at
+    // most this many bytes of device buffers (pbvi_debug_alloc_limit / PBVI_ALLOC_LIMIT_MB; < 0 = no cap).
+    static int64_t& limit_bytes() {
+        static int64_t v = getenv("PBVI_ALLOC_LIMIT_MB") ? (int64_t)atoll(getenv("PBVI_ALLOC_LIMIT_MB")) << 20 : -1;
+        return v;
+    }
+    static bool over_limit(int64_t held, size_t want) { return limit_bytes() >= 0 && held + (int64_t)want > limit_bytes(); }
     // grow-only; contents are NOT preserved on growth.  A buffer that grows again doubles (25 % if that fails): in a solve
     // loop the alpha set gains a few rows per backup, and re-allocating a multi-GB buffer (hipFree + hipMalloc,
     // both synchronising, hundreds of ms at 20 GB) on every call would dwarf the backup itself.
@@ -143,6 +150,7 @@ struct DevBuf {
         }
         if (regrow) {
             for (const size_t want : {bytes * 2, bytes + bytes / 4}) {     // HBM is plentiful; re-allocations are not
+                if (over_limit(*total, want)) continue;
                 if (hipMalloc(&p, want) == hipSuccess) {
                     cap = want;
                     *total += (int64_t)want;
@@ -155,6 +163,11 @@ struct DevBuf {
                 (void)hipGetLastError();                 // no room for that much headroom: try less, then the exact size
                 p = nullptr;
             }
+        }
+        if (over_limit(*total, bytes)) {
+            set_error("device allocation of " + std::to_string(bytes) + " bytes refused: the engine holds " + std::to_string(*total) +
+                      " bytes and its cap is " + std::to_string(limit_bytes()) + " (pbvi_debug_alloc_limit)");
+            return PBVI_ENOMEM;
         }
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
@@ -563,6 +576,7 @@ class EngineBase {
     virtual int64_t store_append_unique(const int32_t* unique_idx, int64_t n) = 0;
     virtual int store_select(int which, const int32_t* ids, int64_t n) = 0;
     virtual int store_reset(int which) = 0;
+    virtual int after_oom() = 0;
     virtual int belief_update(const int32_t* act, const int32_t* obs, void* out) = 0;
     virtual int beliefs_advance(const int32_t* act, const int32_t* obs, const uint8_t* keep, int64_t* out_B) = 0;
     virtual int beliefs_fetch(void* out) = 0;
@@ -643,11 +657,13 @@ class EngineT : public EngineBase {
     bool sorted_ = false;
     const void* gam_pad_ptr_ = nullptr;                      // Gamma buffer / row count whose pad rows are zero
     int64_t gam_pad_N_ = -1;
+    DevBuf scr_flag_;                                        // fp64 engines: 1 = the screen's fp32 alpha copy holds an overflowed value
     DevBuf rowflags_;                                        // [B][k_tiles] 1 = caller's belief row b has mass in K tile kt
     uint64_t rowflags_ver_ = 0;                              // belief-block version rowflags_ describes
     uint64_t nzA_ver_ = 0;                                   // belief-block version ev_nzA_ was recorded for
     void* ids_pin_ = nullptr;                                // pinned staging of the ids of a store selection
     size_t ids_pin_cap_ = 0;
+    int* h_flag_ = nullptr;                                  // pinned: see pinned_flag()
     hipEvent_t ev_ids_ = nullptr;
     hipEvent_t ev_nzA_ = nullptr;                            // the resident block's zero map (nzA_) is complete
     DevBuf nzBw_;                                            // [A*O][ceil(k_tiles/64)] support tiles of RTO as bit words
@@ -697,7 +713,7 @@ class EngineT : public EngineBase {
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &snz_, &sbtl_, &sbtc_, &vmax_bk_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
-                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_};
+                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_, &scr_flag_};
         // every call is checked only to name a failure when PBVI_DEBUG is set; the thread's sticky last-error is cleared at
         // the end either way, so that a later launch check does not report a stale error of this teardown
         static const bool dbg = getenv("PBVI_DEBUG") != nullptr;
@@ -709,6 +725,7 @@ class EngineT : public EngineBase {
         for (DevBuf* b : all) b->release();
         if (host_stage_) chk(hipHostFree(host_stage_), "hipHostFree(stage)");
         if (ids_pin_) chk(hipHostFree(ids_pin_), "hipHostFree(ids)");
+        if (h_flag_) chk(hipHostFree(h_flag_), "hipHostFree(flag)");
         if (ev_ids_) chk(hipEventDestroy(ev_ids_), "hipEventDestroy(ids)");
         if (ev_nzA_) chk(hipEventDestroy(ev_nzA_), "hipEventDestroy(nzA)");
         for (auto& e : ev_)
@@ -1061,6 +1078,16 @@ class EngineT : public EngineBase {
         have_result_ = false;
         btl_valid_ = false;
         return PBVI_OK;
+    }
+
+    // one page-locked int for flags read back with the results (a stack variable would be written by the copy after an
+    // early error return had released it)
+    int* pinned_flag() {
+        if (!h_flag_ && hipHostMalloc((void**)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h_flag_ = nullptr;
+        }
+        return h_flag_;
     }
 
     // h_perm_[i] = caller's index of engine row i (sorted blocks), for the host-side consumers of the order
@@ -1439,6 +1466,52 @@ class EngineT : public EngineBase {
         return out_finish();
     }
 
+    // After a call returned PBVI_ENOMEM: back to the state of a fresh engine (model tables kept, every working set, row
+    // store and scratch buffer released), so that the caller -- PBVI_Solver.solve turns the error into "return the
+    // partial result" like src/pomdp.py:2399-2401 -- can go on using the engine with whatever it uploads next.
+    int after_oom() override {
+        HIPCHK(hipSetDevice(device_));
+        (void)hipStreamSynchronize(stream_);
+        if (stream2_) (void)hipStreamSynchronize(stream2_);
+        if (stream3_) (void)hipStreamSynchronize(stream3_);
+        DevBuf* drop[] = {&alpha_buf_, &alpha_small_, &bel_, &gam_, &slabs_, &best_v_, &best_score_, &err_, &dead_, &queue_, &rdot_,
+                          &action_, &aqueue_, &out_, &keep_, &bv2_, &bs2_, &err2_, &queue2_, &prune_cnt_, &nzA_, &klist_, &kcount_,
+                          &nchunks_, &need_, &skws_, &stage_, &keys_, &perm_, &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_,
+                          &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &bu_act_, &bu_obs_, &bu_unnorm_,
+                          &bu_mass_, &bu_out_, &bu_row_, &walk64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_,
+                          &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_, &snz_, &sbtl_, &sbtc_, &vmax_bk_,
+                          &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_, &nzAlpha_, &prod_, &klistD_,
+                          &kcountD_, &nchunksD_, &mat_, &vlist_, &rowflags_};
+        for (DevBuf* b : drop) {
+            bytes_ -= (int64_t)b->cap;
+            b->release();
+        }
+        alpha_ = DevBuf{};                                   // a view into alpha_buf_ / alpha_small_
+        V_ = 0;
+        B_ = B_pad_ = 0;
+        prim_valid_ = alpha_on_primary_ = false;
+        prim_ids_.clear();
+        prim_off_ = 0;
+        store_rows_[0] = store_rows_[1] = 0;
+        snz_rows_ = sbt_rows_ = 0;
+        walk_rows_ = 0;
+        have_result_ = have_bk_vmax_ = false;
+        btl_valid_ = false;
+        sorted_ = false;
+        h_perm_valid_ = false;
+        mat_V_ = -1;
+        gam_pad_ptr_ = nullptr;
+        last_deferred_nothing_ = false;
+        ++alpha_ver_;
+        ++bel_ver_;
+        if (screen_) {
+            screen_alpha_seen_ = screen_bel_seen_ = 0;
+            screen_layout_seen_ = 0;
+            return screen_->after_oom();
+        }
+        return PBVI_OK;
+    }
+
     int store_reset(int which) override {
         if (which < 0 || which > 1) FAIL(PBVI_EINVAL, "store_reset: bad store");
         store_rows_[which] = 0;
@@ -1787,11 +1860,13 @@ class EngineT : public EngineBase {
         HIPCHK(hipGetLastError());
         HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, view(), gamma, keys_act_.as<int32_t>(), keys_best_.as<int32_t>(), nullptr,
                                   nullptr, (int)n, keys_rows_.as<T>(), S_, stream_));
-        int h_bad = 0;
-        HIPCHK(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        int* h_bad = pinned_flag();
+        if (!h_bad) FAIL(PBVI_ENOMEM, "assemble_keys: pinned flag");
+        *h_bad = 0;
+        HIPCHK(hipMemcpyAsync(h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipMemcpyAsync(out_rows, keys_rows_.p, (size_t)n * S_ * sizeof(T), hipMemcpyDefault, stream_));
         HIPCHK(hipStreamSynchronize(stream_));
-        if (h_bad) FAIL(PBVI_EINVAL, "assemble_keys: action or alpha index out of range");
+        if (*h_bad) FAIL(PBVI_EINVAL, "assemble_keys: action or alpha index out of range");
         return PBVI_OK;
     }
 
@@ -1816,8 +1891,10 @@ class EngineT : public EngineBase {
         if (S_pad_ > S_) HIPCHK(hipMemsetAsync(dst, 0, (size_t)n * S_pad_ * sizeof(T), stream_));   // pad columns stay zero
         HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, view(), gamma, keys_act_.as<int32_t>(), keys_best_.as<int32_t>(), nullptr,
                                   nullptr, (int)n, dst, S_pad_, stream_));
-        int h_bad = 0;
-        HIPCHK(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        int* h_bad = pinned_flag();
+        if (!h_bad) FAIL(PBVI_ENOMEM, "assemble_rows_store: pinned flag");
+        *h_bad = 0;
+        HIPCHK(hipMemcpyAsync(h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, stream_));
         if (out_rows) {
             if (is_device_pointer(out_rows) || is_pinned_host_pointer(out_rows)) {
                 HIPCHK(hipMemcpy2DAsync(out_rows, (size_t)S_ * sizeof(T), dst, (size_t)S_pad_ * sizeof(T), (size_t)S_ * sizeof(T),
@@ -1832,7 +1909,7 @@ class EngineT : public EngineBase {
             }
         }
         HIPCHK(hipStreamSynchronize(stream_));
-        if (h_bad) FAIL(PBVI_EINVAL, "assemble_rows_store: action or alpha index out of range");
+        if (*h_bad) FAIL(PBVI_EINVAL, "assemble_rows_store: action or alpha index out of range");
         const int64_t first = store_rows_[0];
         store_rows_[0] = first + n;
         return first;
@@ -2270,14 +2347,23 @@ int EngineT<T>::value_max_device() {
 }
 
 // fp64 -> fp32 copy of operand rows for the screen (round to nearest even, like NumPy's astype)
-__global__ void k_narrow(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
+// *overflow (may be null) is set when a finite value leaves the fp32 range: the screen's scores would be inf / NaN
+__global__ void k_narrow(const double* __restrict__ src, float* __restrict__ dst, int64_t n, int* __restrict__ overflow) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    int bad = 0;
     if (i + 3 < n) {
         const double2 a = *(const double2*)(src + i), b = *(const double2*)(src + i + 2);
-        *(float4*)(dst + i) = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+        const float4 f = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+        *(float4*)(dst + i) = f;
+        bad = (isinf(f.x) && !isinf(a.x)) || (isinf(f.y) && !isinf(a.y)) || (isinf(f.z) && !isinf(b.x)) || (isinf(f.w) && !isinf(b.y));
     } else {
-        for (int64_t j = i; j < n; ++j) dst[j] = (float)src[j];
+        for (int64_t j = i; j < n; ++j) {
+            const float f = (float)src[j];
+            dst[j] = f;
+            bad |= isinf(f) && !isinf(src[j]);
+        }
     }
+    if (bad && overflow != nullptr) atomicOr(overflow, 1);
 }
 
 template <typename T>
@@ -2485,10 +2571,15 @@ int EngineT<T>::sync_screen() {
         EngineT<float>* sc = screen_;
         int rc;
         if (screen_alpha_seen_ != alpha_ver_) {
+            if (!scr_flag_.p) {
+                if ((rc = scr_flag_.ensure(sizeof(int), &bytes_))) return rc;
+                HIPCHK(hipMemsetAsync(scr_flag_.p, 0, sizeof(int), stream_));
+            }
             auto narrow = [&](const double* src, float* dst, int64_t rows) -> int {
                 const int64_t n = rows * S_pad_;
                 if (n <= 0) return PBVI_OK;
-                hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, src, dst, n);
+                hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, src, dst, n,
+                                   scr_flag_.as<int>());
                 HIPCHK(hipGetLastError());
                 return PBVI_OK;
             };
@@ -2507,6 +2598,7 @@ int EngineT<T>::sync_screen() {
                 if ((rc = sc->alpha_buf_.ensure(rows_total * S_pad_ * sizeof(float), &sc->bytes_))) return rc;
                 sc->alpha_view(sc->alpha_buf_, off);
                 sc->V_ = V_;
+                HIPCHK(hipMemsetAsync(scr_flag_.p, 0, sizeof(int), stream_));        // a fresh copy: no row has overflowed yet
                 if ((rc = narrow(alpha_.as<double>(), sc->alpha_.template as<float>(), V_))) return rc;
                 HIPCHK(hipMemsetAsync(sc->alpha_.template as<float>() + (size_t)V_ * S_pad_, 0,
                                       (rows_total - (size_t)off - (size_t)V_) * S_pad_ * sizeof(float), stream_));
@@ -2524,7 +2616,7 @@ int EngineT<T>::sync_screen() {
             if ((rc = sc->nzA_.ensure((size_t)(B_pad_ / GEMM_BM) * k_tiles, &sc->bytes_))) return rc;
             const int64_t n = (int64_t)B_pad_ * S_pad_;      // same row order as this engine's block (pad rows are zero)
             hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, bel_.as<double>(),
-                               sc->bel_.template as<float>(), n);
+                               sc->bel_.template as<float>(), n, (int*)nullptr);
             HIPCHK(hipGetLastError());
             HIPCHK(launch_tile_nonzero_f32(sc->bel_.template as<float>(), S_pad_, (int)B_pad_, k_tiles, sc->nzA_.template as<uint8_t>(), stream_));
             sc->B_ = B_;
@@ -2554,7 +2646,11 @@ int EngineT<T>::backup_run(double gamma, int flags, pbvi_stats_t* st) {
             int rc = ensure_screen();
             if (rc) return rc;
             if ((rc = sync_screen())) return rc;
-            return run_pipeline<float>(*screen_, gamma, flags, st);
+            if (int* f = pinned_flag()) f[1] = 0;
+            if ((rc = run_pipeline<float>(*screen_, gamma, flags, st))) return rc;
+            // |alpha| beyond FLT_MAX became inf in the screen's copy (NaN scores follow): the fp64 pipeline decides alone
+            if (h_flag_ && h_flag_[1]) return run_pipeline<T>(*this, gamma, flags, st);
+            return PBVI_OK;
         }
     }
     return run_pipeline<T>(*this, gamma, flags, st);
@@ -2770,6 +2866,10 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
             HIPCHK(hipMemsetAsync(keep_.p, 1, (size_t)B_, stream_));
         }
         HIPCHK(hipMemcpyAsync(h_cnt, counters_.p, sizeof(h_cnt), hipMemcpyDeviceToHost, stream_));
+        if constexpr (screened) {   // did an alpha value leave the fp32 range when the screen's copy was made?
+            int* f = pinned_flag();
+            if (f && scr_flag_.p) HIPCHK(hipMemcpyAsync(f + 1, scr_flag_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        }
         HIPCHK(hipEventRecord(ev_[7], stream_));
         HIPCHK(hipStreamSynchronize(stream_));
         return PBVI_OK;
@@ -2999,6 +3099,12 @@ int pbvi_debug_poison(int enable) {
     pbvi::g_poison = enable ? 1 : 0;
     return prev;
 }
+int64_t pbvi_debug_alloc_limit(int64_t mb) {
+    const int64_t prev = pbvi::DevBuf::limit_bytes();
+    pbvi::DevBuf::limit_bytes() = mb < 0 ? -1 : mb << 20;
+    return prev < 0 ? -1 : prev >> 20;
+}
+
 
 int pbvi_device_count(void) {
     int n = 0;
@@ -3188,6 +3294,10 @@ int64_t pbvi_exchange_merge(const int32_t* all_meta, int32_t world, int64_t stri
 int pbvi_assemble_rows(pbvi_engine_t* e, double gamma, int64_t n, const int32_t* keys, void* out_rows) {
     NEED(e);
     return e->impl->assemble_keys(gamma, n, keys, out_rows);
+}
+int pbvi_engine_after_oom(pbvi_engine_t* e) {
+    NEED(e);
+    return e->impl->after_oom();
 }
 int pbvi_backup_device_results(pbvi_engine_t* e, void** d_alpha, int32_t** d_action, uint8_t** d_keep) {
     NEED(e);

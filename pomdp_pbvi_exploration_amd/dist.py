@@ -81,7 +81,7 @@ def alpha_fingerprint(engine) -> int:
     import zlib
     ids = engine._resident.get('alpha') if hasattr(engine, '_resident') else None
     if ids is None:
-        return int(engine.alpha_count()) & 0x7fffffff
+        return int(engine.alpha_count) & 0x7fffffff
     return zlib.crc32(np.ascontiguousarray(ids, dtype=np.int32).tobytes()) & 0x7fffffff
 
 
@@ -371,7 +371,7 @@ class EngineShard:
         return self._keys
 
     def trailer(self, n_total: int) -> np.ndarray:
-        return trailer_values(n_total, int(self.engine.alpha_count()), alpha_fingerprint(self.engine))
+        return trailer_values(n_total, int(self.engine.alpha_count), alpha_fingerprint(self.engine))
 
     def run_resident_packed(self, per: int = None):
         """For the key exchange: run, then the engine packs count, index, actions, keep and the keys of its distinct rows

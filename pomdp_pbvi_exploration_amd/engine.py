@@ -33,7 +33,7 @@ EXPORTS = [
     'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact', 'pbvi_alpha_layout',
     'pbvi_belief_walk_keys', 'pbvi_backup_fetch_value_max',
     'pbvi_backup_fetch_compact', 'pbvi_host_alloc', 'pbvi_host_free', 'pbvi_debug_gemm_dense',
-    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_exchange_merge', 'pbvi_set_f64_screen', 'pbvi_set_fused_projection', 'pbvi_backup_fetch_row_hashes',
+    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_exchange_merge', 'pbvi_debug_alloc_limit', 'pbvi_engine_after_oom', 'pbvi_set_f64_screen', 'pbvi_set_fused_projection', 'pbvi_backup_fetch_row_hashes',
 ]
 
 
@@ -128,6 +128,8 @@ def load_library(path: str = LIB_PATH):
         'pbvi_backup_fetch_exchange': (C.c_int, [vp, vp]),
         'pbvi_backup_fetch_exchange_padded': (C.c_int, [vp, C.c_int64, vp]),
         'pbvi_assemble_rows_store': (C.c_int64, [vp, C.c_double, C.c_int64, vp, vp]),
+        'pbvi_debug_alloc_limit': (C.c_int64, [C.c_int64]),
+        'pbvi_engine_after_oom': (C.c_int, [vp]),
         'pbvi_exchange_merge': (C.c_int64, [vp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64, vp, vp, vp, vp]),
         'pbvi_set_tie_window': (C.c_int, [vp, C.c_double]),
         'pbvi_device_bytes': (C.c_int64, [vp]),
@@ -145,6 +147,12 @@ def debug_poison(enable: bool) -> bool:
     return bool(load_library().pbvi_debug_poison(1 if enable else 0))
 
 
+def debug_alloc_limit(mb: int) -> int:
+    """Cap (MiB; < 0: none) on the device bytes one engine may hold (``pbvi_debug_alloc_limit``): a deterministic
+    out-of-memory for tests of the ``MemoryError`` contract of ``PBVI_Solver.solve``.  Returns the previous cap."""
+    return int(load_library().pbvi_debug_alloc_limit(int(mb)))
+
+
 def debug_gemm_dense(enable: bool) -> bool:
     """List every GEMM tile, zero or not (``pbvi_debug_gemm_dense``: BASELINE's "dense backup" measurement);
     returns the previous setting."""
@@ -155,9 +163,17 @@ def device_count() -> int:
     return int(load_library().pbvi_device_count())
 
 
+class _PinnedArray(np.ndarray):
+    """An array carved from a ``PinnedBuffer``: it (and every view of it) keeps the buffer alive."""
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, '_owner', None)
+
+
 class PinnedBuffer:
     """Page-locked host memory from ``pbvi_host_alloc`` viewed as NumPy arrays: results fetched into it are written
-    by the GPU's DMA engine directly (no bounce buffer, no CPU copy)."""
+    by the GPU's DMA engine directly (no bounce buffer, no CPU copy).  Carved arrays hold a reference to the buffer, so
+    it is not freed under them by garbage collection; ``close()`` refuses while any of them is still alive."""
 
     def __init__(self, nbytes: int):
         self._lib = load_library()
@@ -167,6 +183,7 @@ class PinnedBuffer:
             raise MemoryError((self._lib.pbvi_last_error() or b'').decode(errors='replace'))
         self._raw = (C.c_uint8 * self.nbytes).from_address(self._p)
         self._off = 0
+        self._views = []
 
     def carve(self, shape, dtype) -> np.ndarray:
         """Next 256-byte-aligned slice of the buffer as an array of ``shape`` / ``dtype``."""
@@ -176,10 +193,16 @@ class PinnedBuffer:
         if off + n > self.nbytes:
             raise MemoryError('PinnedBuffer exhausted')
         self._off = off + n
-        return np.frombuffer(self._raw, dtype=dtype, count=int(np.prod(shape)), offset=off).reshape(shape)
+        import weakref
+        arr = np.frombuffer(self._raw, dtype=dtype, count=int(np.prod(shape)), offset=off).reshape(shape).view(_PinnedArray)
+        arr._owner = self
+        self._views.append(weakref.ref(arr))
+        return arr
 
     def close(self) -> None:
         if getattr(self, '_p', None):
+            if any(r() is not None for r in self._views):
+                raise RuntimeError('PinnedBuffer.close(): arrays carved from it are still referenced')
             self._raw = None
             self._lib.pbvi_host_free(self._p)
             self._p = None
@@ -342,6 +365,8 @@ class Engine:
     """One model on one GPU: resident tables, alpha set and belief block."""
 
     _serials = iter(range(1, 1 << 62))      # process-wide: a residency tag must never match a dead engine's (ids are reused)
+    _nonce = None                           # ... nor an engine's of another process or run (pickled / copied objects keep
+                                            # their tags): the serial carries (pid, 48 random bits drawn once per process)
 
     def __init__(self, S: int, A: int, O: int, R: int, reach_states: np.ndarray, rto: np.ndarray,
                  exp_rewards: np.ndarray, dtype: str = 'f32', mode: str = 'sparse', device: int = 0):
@@ -367,7 +392,10 @@ class Engine:
                                       PBVI_F32 if dtype == 'f32' else PBVI_F64,
                                       PBVI_SPARSE if mode == 'sparse' else PBVI_DENSE))
         self._lib = lib
-        self.serial = next(Engine._serials)
+        if Engine._nonce is None or Engine._nonce[0] != os.getpid():
+            import secrets
+            Engine._nonce = (os.getpid(), secrets.randbits(48))
+        self.serial = Engine._nonce + (next(Engine._serials),)
         self._alpha_token = None
         self._store_epoch = {'alpha': 0, 'belief': 0}
         self._resident = {'alpha': None, 'belief': None}     # store ids of the working alpha set / belief block
@@ -378,7 +406,7 @@ class Engine:
             # the belief walk returns fp64 belief values to the host containers: keep them independent of the
             # engine's arithmetic type by giving it the fp64 table too (a few MB)
             r64 = np.ascontiguousarray(rto, dtype=np.float64)
-            _check(lib.pbvi_engine_set_rto_f64(self._h, r64.ctypes.data_as(C.POINTER(C.c_double))))
+            self._ck(lib.pbvi_engine_set_rto_f64(self._h, r64.ctypes.data_as(C.POINTER(C.c_double))))
 
     @classmethod
     def for_model(cls, model, dtype: str = 'f64', device: int = 0, mode: str = 'sparse') -> 'Engine':
@@ -398,6 +426,23 @@ class Engine:
         except Exception:
             pass
 
+    def _ck(self, rc: int) -> None:
+        """``_check`` for calls on this engine: a device allocation failure (-2) first returns the engine to its freshly
+        created state (``pbvi_engine_after_oom``: working sets, row stores and scratch released) and forgets everything
+        this wrapper cached about device residency, then raises ``MemoryError`` -- which ``PBVI_Solver.solve`` turns into
+        "return the partial result" like the reference (``src/pomdp.py:2399-2401``)."""
+        if rc == -2:
+            msg = (self._lib.pbvi_last_error() or b'').decode(errors='replace')
+            self._lib.pbvi_engine_after_oom(self._h)
+            self._resident = {'alpha': None, 'belief': None}
+            for k in self._store_epoch:                  # residency tags of AlphaVector / Belief objects no longer match
+                self._store_epoch[k] += 1
+            self._vmax_cache, self._vmax_epochs = [], None
+            self._alpha_token = None
+            self.B = 0
+            raise MemoryError(msg)
+        _check(rc)
+
     # -- residency ------------------------------------------------------- #
     def _as_rows(self, arr: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(arr, dtype=self.np_dtype)
@@ -408,13 +453,13 @@ class Engine:
     def set_alpha(self, alpha: np.ndarray) -> None:
         a = self._as_rows(alpha)
         self._resident['alpha'] = None
-        _check(self._lib.pbvi_alpha_set(self._h, _ptr(a), a.shape[0]))
+        self._ck(self._lib.pbvi_alpha_set(self._h, _ptr(a), a.shape[0]))
         self._alpha_token = None
 
     def append_alpha(self, alpha: np.ndarray) -> None:
         a = self._as_rows(alpha)
         self._resident['alpha'] = None
-        _check(self._lib.pbvi_alpha_append(self._h, _ptr(a), a.shape[0]))
+        self._ck(self._lib.pbvi_alpha_append(self._h, _ptr(a), a.shape[0]))
         self._alpha_token = None
 
     @property
@@ -424,7 +469,7 @@ class Engine:
     def set_beliefs(self, beliefs: np.ndarray) -> None:
         b = self._as_rows(beliefs)
         self._resident['belief'] = None
-        _check(self._lib.pbvi_beliefs_set(self._h, _ptr(b), b.shape[0]))
+        self._ck(self._lib.pbvi_beliefs_set(self._h, _ptr(b), b.shape[0]))
         self.B = b.shape[0]
 
     # -- device row stores: upload once, select by id in host order ------- #
@@ -434,7 +479,7 @@ class Engine:
         fn = self._lib.pbvi_alpha_store_append if which == 'alpha' else self._lib.pbvi_belief_store_append
         first = int(fn(self._h, _ptr(a), a.shape[0]))
         if first < 0:
-            _check(first)
+            self._ck(first)
         return first
 
     def store_unique(self, unique_idx) -> int:
@@ -443,7 +488,7 @@ class Engine:
         i = np.ascontiguousarray(unique_idx, dtype=np.int32)
         first = int(self._lib.pbvi_backup_store_unique(self._h, i.ctypes.data_as(C.POINTER(C.c_int32)), i.shape[0]))
         if first < 0:
-            _check(first)
+            self._ck(first)
         return first
 
     def store_tag(self, which: str):
@@ -459,7 +504,7 @@ class Engine:
         if have is not None and have.shape == i.shape and np.array_equal(have, i):
             return
         self._resident['alpha'] = None
-        _check(self._lib.pbvi_alpha_select(self._h, i.ctypes.data_as(C.POINTER(C.c_int32)), i.shape[0]))
+        self._ck(self._lib.pbvi_alpha_select(self._h, i.ctypes.data_as(C.POINTER(C.c_int32)), i.shape[0]))
         self._resident['alpha'] = i.copy()
 
     def select_beliefs(self, ids) -> None:
@@ -468,7 +513,7 @@ class Engine:
         if have is not None and have.shape == i.shape and np.array_equal(have, i):
             return
         self._resident['belief'] = None
-        _check(self._lib.pbvi_beliefs_select(self._h, i.ctypes.data_as(C.POINTER(C.c_int32)), i.shape[0]))
+        self._ck(self._lib.pbvi_beliefs_select(self._h, i.ctypes.data_as(C.POINTER(C.c_int32)), i.shape[0]))
         self.B = i.shape[0]
         self._resident['belief'] = i.copy()
 
@@ -479,12 +524,12 @@ class Engine:
         free, lay = C.c_int64(0), C.c_int64(0)
         rc = self._lib.pbvi_alpha_layout(self._h, C.byref(free), C.byref(lay))
         if rc < 0:
-            _check(rc)
+            self._ck(rc)
         return bool(rc), int(free.value), int(lay.value)
 
     def reset_store(self, which: str) -> None:
         self._resident[which] = None
-        _check((self._lib.pbvi_alpha_store_reset if which == 'alpha' else self._lib.pbvi_belief_store_reset)(self._h))
+        self._ck((self._lib.pbvi_alpha_store_reset if which == 'alpha' else self._lib.pbvi_belief_store_reset)(self._h))
         self._store_epoch[which] += 1
 
     def row_ids(self, which: str, objects, values_of, owner=None) -> np.ndarray:
@@ -533,7 +578,7 @@ class Engine:
             n = int(self._lib.pbvi_belief_store_count(self._h))
         val = np.empty(n, dtype=np.float64)
         idx = np.empty(n, dtype=np.int32)
-        _check(self._lib.pbvi_value_max_store(self._h, n, val.ctypes.data_as(C.POINTER(C.c_double)),
+        self._ck(self._lib.pbvi_value_max_store(self._h, n, val.ctypes.data_as(C.POINTER(C.c_double)),
                                               idx.ctypes.data_as(C.POINTER(C.c_int32))))
         return val, idx
 
@@ -577,7 +622,7 @@ class Engine:
         rc = self._lib.pbvi_backup_fetch_value_max(self._h, vals.ctypes.data_as(C.POINTER(C.c_double)))
         if rc == -4:
             return False
-        _check(rc)
+        self._ck(rc)
         a_ids = self.row_ids('alpha', alpha_objects, alpha_values, alpha_owner)
         b_ids = self.row_ids('belief', belief_objects, belief_values, belief_owner)
         if len(b_ids) != len(vals):
@@ -601,7 +646,7 @@ class Engine:
 
     def set_value_max_exact(self, exact: bool) -> None:
         """f32 engines: fp64 re-scoring of ``max_value_*`` results on (default) or off (``pbvi_set_value_max_exact``)."""
-        _check(self._lib.pbvi_set_value_max_exact(self._h, 1 if exact else 0))
+        self._ck(self._lib.pbvi_set_value_max_exact(self._h, 1 if exact else 0))
 
     def max_value_objects(self, alpha_objects, belief_objects, alpha_values, belief_values, alpha_owner=None,
                           belief_owner=None, exact: bool = True) -> np.ndarray:
@@ -671,7 +716,7 @@ class Engine:
     def run(self, gamma: float, belief_dominance_prune: bool = False) -> dict:
         """Backup of the resident belief block against the resident alpha set; results stay on the device."""
         st = PbviStats()
-        _check(self._lib.pbvi_backup_run(self._h, float(gamma), PBVI_BELIEF_DOMINANCE if belief_dominance_prune else 0,
+        self._ck(self._lib.pbvi_backup_run(self._h, float(gamma), PBVI_BELIEF_DOMINANCE if belief_dominance_prune else 0,
                                          C.byref(st)))
         return st.as_dict()
 
@@ -687,7 +732,7 @@ class Engine:
         best = np.empty((B, self.A, self.O), dtype=np.int32)
         keep = np.empty(B, dtype=np.uint8)
         i32p = C.POINTER(C.c_int32)
-        _check(self._lib.pbvi_backup_fetch_compact(self._h, _ptr(rows), index.ctypes.data_as(i32p), act.ctypes.data_as(i32p),
+        self._ck(self._lib.pbvi_backup_fetch_compact(self._h, _ptr(rows), index.ctypes.data_as(i32p), act.ctypes.data_as(i32p),
                                                    best.ctypes.data_as(i32p), keep.ctypes.data_as(C.POINTER(C.c_uint8))))
         return BackupResult(rows, index.astype(np.int64), act.astype(np.int64), best.astype(np.int64),
                             keep.astype(bool), {})
@@ -706,7 +751,7 @@ class Engine:
             if a is not None and (a.shape != shape or a.dtype != dt or not a.flags.c_contiguous):
                 raise ValueError(f'{name} must be a C-contiguous {shape} {np.dtype(dt).name} array')
         i32p = C.POINTER(C.c_int32)
-        _check(self._lib.pbvi_backup_fetch_compact(
+        self._ck(self._lib.pbvi_backup_fetch_compact(
             self._h, _ptr(rows), index.ctypes.data_as(i32p), actions.ctypes.data_as(i32p),
             best.ctypes.data_as(i32p) if best is not None else None,
             keep.ctypes.data_as(C.POINTER(C.c_uint8)) if keep is not None else None))
@@ -719,7 +764,7 @@ class Engine:
             out = np.empty((self.B, self.S), dtype=self.np_dtype)
         elif out.shape != (self.B, self.S) or out.dtype != self.np_dtype or not out.flags.c_contiguous:
             raise ValueError(f'out must be a C-contiguous [{self.B}, {self.S}] {self.dtype} array')
-        _check(self._lib.pbvi_backup_fetch(self._h, _ptr(out), None, None, None))
+        self._ck(self._lib.pbvi_backup_fetch(self._h, _ptr(out), None, None, None))
         return out
 
     @property
@@ -728,7 +773,7 @@ class Engine:
 
     def fetch_unique_into(self, rows_ptr: int, index_ptr: int) -> None:
         """Copy unique rows [U,S] / index [B] to raw (host or device) addresses."""
-        _check(self._lib.pbvi_backup_fetch_unique(self._h, C.c_void_p(rows_ptr) if rows_ptr else None,
+        self._ck(self._lib.pbvi_backup_fetch_unique(self._h, C.c_void_p(rows_ptr) if rows_ptr else None,
                                                   C.cast(index_ptr, C.POINTER(C.c_int32)) if index_ptr else None))
 
     def fetch_row_hashes(self) -> np.ndarray:
@@ -737,7 +782,7 @@ class Engine:
         U = self.unique_count
         out = np.empty(max(U, 0), dtype=np.uint64)
         if U > 0:
-            _check(self._lib.pbvi_backup_fetch_row_hashes(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+            self._ck(self._lib.pbvi_backup_fetch_row_hashes(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out
 
     def fetch_unique_keys(self) -> np.ndarray:
@@ -745,19 +790,19 @@ class Engine:
         U = self.unique_count
         keys = np.empty((U, 1 + self.O), dtype=np.int32)
         if U:
-            _check(self._lib.pbvi_backup_fetch_unique_keys(self._h, _ptr(keys)))
+            self._ck(self._lib.pbvi_backup_fetch_unique_keys(self._h, _ptr(keys)))
         return keys
 
     def fetch_unique_keys_into(self, keys_ptr: int) -> None:
-        _check(self._lib.pbvi_backup_fetch_unique_keys(self._h, C.c_void_p(keys_ptr)))
+        self._ck(self._lib.pbvi_backup_fetch_unique_keys(self._h, C.c_void_p(keys_ptr)))
 
     def fetch_exchange_into(self, ptr: int, per: int = None) -> None:
         """``[U | index[per] | actions[per] | keep[per] | keys[per][1+O]]`` int32 at a raw (host or device) address;
         ``per`` (default B) >= B is the common block size of a sharded run."""
         if per is None:
-            _check(self._lib.pbvi_backup_fetch_exchange(self._h, C.c_void_p(ptr)))
+            self._ck(self._lib.pbvi_backup_fetch_exchange(self._h, C.c_void_p(ptr)))
         else:
-            _check(self._lib.pbvi_backup_fetch_exchange_padded(self._h, int(per), C.c_void_p(ptr)))
+            self._ck(self._lib.pbvi_backup_fetch_exchange_padded(self._h, int(per), C.c_void_p(ptr)))
 
     def exchange_size(self, per: int) -> int:
         """int32 entries of one rank's exchange message for block size ``per``."""
@@ -773,14 +818,14 @@ class Engine:
         first = int(self._lib.pbvi_assemble_rows_store(self._h, float(gamma), k.shape[0], _ptr(k),
                                                        _ptr(out) if out is not None else None))
         if first < 0:
-            _check(first)
+            self._ck(first)
         return out, first
 
     def assemble_rows_store_from(self, keys_ptr: int, n: int, gamma: float) -> int:
         """Same for keys at a raw (host or device) address; rows stay on the device.  Returns the first store id."""
         first = int(self._lib.pbvi_assemble_rows_store(self._h, float(gamma), int(n), C.c_void_p(keys_ptr), None))
         if first < 0:
-            _check(first)
+            self._ck(first)
         return first
 
     def assemble_rows(self, keys: np.ndarray, gamma: float) -> np.ndarray:
@@ -790,16 +835,16 @@ class Engine:
             raise ValueError(f'keys must be [n, {1 + self.O}]')
         out = np.empty((k.shape[0], self.S), dtype=self.np_dtype)
         if k.shape[0]:
-            _check(self._lib.pbvi_assemble_rows(self._h, float(gamma), k.shape[0], _ptr(k), _ptr(out)))
+            self._ck(self._lib.pbvi_assemble_rows(self._h, float(gamma), k.shape[0], _ptr(k), _ptr(out)))
         return out
 
     def assemble_rows_into(self, keys_ptr: int, n: int, gamma: float, out_ptr: int) -> None:
-        _check(self._lib.pbvi_assemble_rows(self._h, float(gamma), int(n), C.c_void_p(keys_ptr), C.c_void_p(out_ptr)))
+        self._ck(self._lib.pbvi_assemble_rows(self._h, float(gamma), int(n), C.c_void_p(keys_ptr), C.c_void_p(out_ptr)))
 
     def fetch_into(self, alpha_ptr: int, action_ptr: int, keep_ptr: int) -> None:
         """Copy the last run's alpha rows / actions / keep mask to raw addresses (host or
         device memory of this GPU), e.g. the ``data_ptr()`` of the RCCL send buffers."""
-        _check(self._lib.pbvi_backup_fetch(self._h, C.c_void_p(alpha_ptr) if alpha_ptr else None,
+        self._ck(self._lib.pbvi_backup_fetch(self._h, C.c_void_p(alpha_ptr) if alpha_ptr else None,
                                            C.cast(action_ptr, C.POINTER(C.c_int32)) if action_ptr else None, None,
                                            C.cast(keep_ptr, C.POINTER(C.c_uint8)) if keep_ptr else None))
 
@@ -821,21 +866,21 @@ class Engine:
     def device_results(self):
         """Raw device addresses ``(alpha_ptr, action_ptr, keep_ptr)`` of the last run (for RCCL)."""
         a, c, k = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        _check(self._lib.pbvi_backup_device_results(self._h, C.byref(a), C.byref(c), C.byref(k)))
+        self._ck(self._lib.pbvi_backup_device_results(self._h, C.byref(a), C.byref(c), C.byref(k)))
         return a.value, c.value, k.value
 
     # -- companions of the backup --------------------------------------- #
     def prune_dominated(self, alpha: np.ndarray) -> np.ndarray:
         self._ensure_alpha(alpha)
         keep = np.empty(alpha.shape[0], dtype=np.uint8)
-        _check(self._lib.pbvi_prune_dominated(self._h, keep.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self._ck(self._lib.pbvi_prune_dominated(self._h, keep.ctypes.data_as(C.POINTER(C.c_uint8))))
         return keep.astype(bool)
 
     def prune_dominated_objects(self, objects, values_of, owner=None) -> np.ndarray:
         """Same for a list of AlphaVector objects: rows already in the device store are not uploaded again."""
         self.sync_rows('alpha', objects, values_of, owner)
         keep = np.empty(len(objects), dtype=np.uint8)
-        _check(self._lib.pbvi_prune_dominated(self._h, keep.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self._ck(self._lib.pbvi_prune_dominated(self._h, keep.ctypes.data_as(C.POINTER(C.c_uint8))))
         return keep.astype(bool)
 
     def max_value(self, alpha: np.ndarray, beliefs: np.ndarray):
@@ -848,7 +893,7 @@ class Engine:
         """Same, for the working alpha set / belief block already selected on the device."""
         val = np.empty(self.B, dtype=np.float64)
         idx = np.empty(self.B, dtype=np.int32)
-        _check(self._lib.pbvi_value_max(self._h, val.ctypes.data_as(C.POINTER(C.c_double)),
+        self._ck(self._lib.pbvi_value_max(self._h, val.ctypes.data_as(C.POINTER(C.c_double)),
                                         idx.ctypes.data_as(C.POINTER(C.c_int32))))
         return val, idx.astype(np.int64)
 
@@ -861,7 +906,7 @@ class Engine:
         if a.shape != (self.B,) or o.shape != (self.B,):
             raise ValueError('actions / observations must be [B]')
         out = np.empty((self.B, self.S), dtype=self.np_dtype)
-        _check(self._lib.pbvi_belief_update(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)),
+        self._ck(self._lib.pbvi_belief_update(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)),
                                             o.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(out)))
         return out
 
@@ -887,14 +932,14 @@ class Engine:
         first = int(self._lib.pbvi_belief_walk(self._h, start.ctypes.data_as(f64p), n, a.ctypes.data_as(i32p),
                                                o.ctypes.data_as(i32p), rp, out.ctypes.data_as(f64p)))
         if first < 0:
-            _check(first)
+            self._ck(first)
         return out, first
 
     def belief_walk_keys(self, n: int) -> np.ndarray:
         """``[n]`` uint64: position-weighted bit-pattern hashes of the fp64 rows of the last ``belief_walk`` (what ``_RowKey`` computes on
         the host), from the device."""
         keys = np.empty(n, dtype=np.uint64)
-        _check(self._lib.pbvi_belief_walk_keys(self._h, n, keys.ctypes.data_as(C.POINTER(C.c_uint64))))
+        self._ck(self._lib.pbvi_belief_walk_keys(self._h, n, keys.ctypes.data_as(C.POINTER(C.c_uint64))))
         return keys
 
     def belief_tag(self):
@@ -916,7 +961,7 @@ class Engine:
             kp = k.ctypes.data_as(C.POINTER(C.c_uint8))
         nb = C.c_int64(0)
         self._resident['belief'] = None
-        _check(self._lib.pbvi_beliefs_advance(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)),
+        self._ck(self._lib.pbvi_beliefs_advance(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)),
                                               o.ctypes.data_as(C.POINTER(C.c_int32)), kp, C.byref(nb)))
         self.B = int(nb.value)
         return self.B
@@ -924,27 +969,27 @@ class Engine:
     def fetch_beliefs(self) -> np.ndarray:
         """The resident belief block, ``[B,S]`` in caller order."""
         out = np.empty((self.B, self.S), dtype=self.np_dtype)
-        _check(self._lib.pbvi_beliefs_fetch(self._h, _ptr(out)))
+        self._ck(self._lib.pbvi_beliefs_fetch(self._h, _ptr(out)))
         return out
 
     def set_formulation(self, which: str = 'auto') -> None:
         """Operand projected through the model: ``'auto'``, ``'alpha'`` (Gamma, the reference's order) or
         ``'belief'`` (beliefs pushed through every (a, o); cheaper when B << V)."""
-        _check(self._lib.pbvi_set_formulation(self._h, {'auto': 0, 'alpha': 1, 'belief': 2}[which]))
+        self._ck(self._lib.pbvi_set_formulation(self._h, {'auto': 0, 'alpha': 1, 'belief': 2}[which]))
 
     def set_fused_projection(self, enable=True) -> None:
         """fp32 scoring: Gamma tiles generated inside the score GEMM (``True``: where that is faster, i.e. R = 1; default) or
         projected first (``False``); ``2`` also fuses R = 2..7 (slower; tests).  Same scores bit for bit
         (``pbvi_set_fused_projection``)."""
-        _check(self._lib.pbvi_set_fused_projection(self._h, int(enable)))
+        self._ck(self._lib.pbvi_set_fused_projection(self._h, int(enable)))
 
     def set_f64_screen(self, mode: str = 'auto') -> None:
         """fp64 engines: ``'off'`` (pure fp64 arithmetic), ``'auto'`` (fp32 screen + fp64 re-decision of near-ties when the
         score GEMM is large; default) or ``'always'`` (``pbvi_set_f64_screen``)."""
-        _check(self._lib.pbvi_set_f64_screen(self._h, {'off': 0, 'auto': 1, 'always': 2}[mode]))
+        self._ck(self._lib.pbvi_set_f64_screen(self._h, {'off': 0, 'auto': 1, 'always': 2}[mode]))
 
     def set_tie_window(self, rel: float) -> None:
-        _check(self._lib.pbvi_set_tie_window(self._h, float(rel)))
+        self._ck(self._lib.pbvi_set_tie_window(self._h, float(rel)))
 
     @property
     def device_bytes(self) -> int:

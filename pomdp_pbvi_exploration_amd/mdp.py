@@ -285,8 +285,12 @@ def _draw_index(p) -> int:
     expansion draws 99 observations one at a time).  The reference's trajectories depend on that stream, so the draw has
     to stay this one, call for call."""
     cdf = np.cumsum(p, dtype=np.float64)
-    if not cdf[-1] > 0.0:
-        raise ValueError('probabilities do not sum to a positive number')
+    # np.random.choice's own argument checks, at the cost of one comparison and one min (a denormalised belief or
+    # observation row must raise here as it does in the reference, not be renormalised silently)
+    if not abs(cdf[-1] - 1.0) <= 1.4901161193847656e-08:          # sqrt(eps of float64), choice's tolerance
+        raise ValueError('probabilities do not sum to 1')
+    if np.min(p) < 0:
+        raise ValueError('probabilities are not non-negative')
     cdf /= cdf[-1]
     return int(cdf.searchsorted(np.random.random_sample(), side='right'))
 

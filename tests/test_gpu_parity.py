@@ -1634,3 +1634,103 @@ def test_c5_sharded_over_two_ranks_against_reference():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
     assert 'c5 sharded ok' in out.stdout
+
+
+def test_memory_error_contract_of_solve_and_engine_recovery(capsys):
+    """``src/pomdp.py:2399-2401``: an out-of-memory inside the solve loop ends the loop and returns the value function and
+    history "as is".  A cap on the engine's device bytes (``pbvi_debug_alloc_limit``) makes the allocation failure
+    deterministic: the C-ABI returns -2, the seam raises ``MemoryError``, ``solve`` prints the reference's message and returns
+    the partial result -- the seeded host solve cut at the same backup -- and the engine, returned to its freshly created
+    state (``pbvi_engine_after_oom``), serves the next call."""
+    import random
+    from pomdp_pbvi_exploration_amd import FSVI_Solver
+    from pomdp_pbvi_exploration_amd.engine import debug_alloc_limit
+    from test_policy_eval import mirror_model
+    m = synth.olfactory_model(H=30, W=80, R=1, f32=False)
+    model = mirror_model(m)
+
+    def run(expansions, use_gpu):
+        np.random.seed(3)
+        random.seed(3)
+        return FSVI_Solver(gamma=m.gamma, eps=1e-6).solve(model, expansions=expansions, max_belief_growth=40, use_gpu=use_gpu,
+                                                          print_progress=False)
+    run(2, True)                                            # engine created, first buffers allocated
+    eng = model.gpu_model.engine
+    held = eng.device_bytes
+    prev = debug_alloc_limit(held // (1 << 20) + 24)        # 24 MiB of head room: the row stores outgrow it within a dozen expansions
+    try:
+        capsys.readouterr()
+        vf, hist = run(80, True)
+        out = capsys.readouterr().out
+    finally:
+        debug_alloc_limit(prev)
+    n_done = len(hist.backup_times)
+    assert 'Memory full' in out and 'Returning value function and history as is' in out
+    assert 0 < n_done < 80 and len(vf) > 0, n_done
+    # the partial result is the seeded run cut where the memory ran out (host solve of as many expansions)
+    want_vf, want_hist = run(n_done, False)
+    assert hist.alpha_vector_counts[:n_done + 1] == want_hist.alpha_vector_counts[:n_done + 1]
+    np.testing.assert_allclose(np.asarray(vf.alpha_vector_array, dtype=np.float64), want_vf.alpha_vector_array, rtol=1e-9, atol=1e-12)
+    # the engine is usable again: a direct backup on GPU objects equals the host's
+    gm = model.gpu_model
+    rows = synth.belief_points(m, 20, max_depth=10)
+    host_vf = ValueFunction(model, want_vf.alpha_vector_array, want_vf.actions)
+    got = PBVI_Solver(gamma=m.gamma).backup(gm, BeliefSet(gm, [Belief(gm, r) for r in rows]), host_vf.to_gpu() if hasattr(host_vf, 'to_gpu') else host_vf,
+                                           belief_dominance_prune=False)
+    ref = PBVI_Solver(gamma=m.gamma).backup(model, BeliefSet(model, [Belief(model, r) for r in rows]), host_vf, belief_dominance_prune=False)
+    assert np.array_equal(got.actions, ref.actions)
+    np.testing.assert_allclose(np.asarray(got.alpha_vector_array, dtype=np.float64), ref.alpha_vector_array, rtol=1e-9, atol=1e-12)
+
+
+def test_engine_call_over_the_allocation_cap_raises_memory_error_and_recovers():
+    from pomdp_pbvi_exploration_amd.engine import debug_alloc_limit
+    z, rs, rto, er = small(1)
+    eng = Engine(600, 6, 3, 1, rs, rto, er, dtype='f32')
+    want = eng.backup_full(z['alpha'], z['beliefs'], float(z['gamma']))
+    big = np.tile(z['alpha'], (400, 1))                     # 19200 alpha rows: ~46 MB, Gamma ~0.8 GB
+    prev = debug_alloc_limit(eng.device_bytes // (1 << 20) + 64)
+    try:
+        with pytest.raises(MemoryError):
+            eng.backup_full(big, z['beliefs'], float(z['gamma']))
+        assert eng.alpha_count == 0                       # back to the freshly created state
+        again = eng.backup_full(z['alpha'], z['beliefs'], float(z['gamma']))
+    finally:
+        debug_alloc_limit(prev)
+    assert np.array_equal(again.best_alpha_ind, want.best_alpha_ind) and np.array_equal(again.alpha, want.alpha)
+    eng.close()
+
+
+def test_f64_screen_steps_aside_when_alpha_leaves_the_fp32_range():
+    """An fp64 engine's fp32 screen narrows the alpha set; a value beyond FLT_MAX would become inf there and the screen's
+    scores NaN.  The narrowing kernel flags it and the backup is decided by the fp64 pipeline alone."""
+    z, rs, rto, er = small(1)
+    alpha = z['alpha'].astype(np.float64).copy()
+    alpha[3] *= 1e36                                         # finite in fp64, inf in fp32
+    alpha[7] *= -1e36
+    want_rows, want_a, want_v = orc.backup_core(alpha, z['beliefs'].astype(np.float64), rs, rto, er, float(z['gamma']))
+    eng = Engine(600, 6, 3, 1, rs, rto, er, dtype='f64')
+    eng.set_f64_screen('always')
+    res = eng.backup_full(alpha, z['beliefs'], float(z['gamma']))
+    assert np.array_equal(res.best_alpha_ind, want_v) and np.array_equal(res.actions, want_a)
+    np.testing.assert_allclose(res.alpha, want_rows, rtol=1e-12)
+    ok = eng.backup_full(z['alpha'].astype(np.float64), z['beliefs'], float(z['gamma']))       # a representable set: screened again
+    assert ok.stats['screened'] == 1 and np.array_equal(ok.best_alpha_ind, z['core_best'])
+    eng.close()
+
+
+def test_pinned_buffer_outlives_its_arrays():
+    import gc
+    from pomdp_pbvi_exploration_amd.engine import PinnedBuffer
+    buf = PinnedBuffer(1 << 16)
+    a = buf.carve((16, 16), np.float32)
+    view = a[2:]
+    with pytest.raises(RuntimeError):
+        buf.close()                                          # arrays carved from it are alive
+    del a
+    gc.collect()
+    with pytest.raises(RuntimeError):
+        buf.close()                                          # ... and so is a view of one
+    view[:] = 1.0                                            # still valid memory
+    del view
+    gc.collect()
+    buf.close()
