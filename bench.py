@@ -67,6 +67,29 @@ def cpu_baseline(m, alpha, beliefs, sample: int):
                       f'{cores} schedulable cores, OpenBLAS threads {blas_threads}'}
 
 
+_PMC = None
+
+
+def load_pmc():
+    """profiles/r03_pmc_traffic.json: {configuration: {kernel, traffic_bytes, kernels: {name: {...}}}} or {}."""
+    global _PMC
+    if _PMC is None:
+        try:
+            with open(os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')) as fh:
+                _PMC = json.load(fh)
+        except (OSError, ValueError):
+            _PMC = {}
+    return _PMC
+
+
+def attach_traffic(roofline, tag):
+    """`traffic` of a roofline entry: PMC bytes per launch of its kernel, measured on this configuration by rocprofv3."""
+    pmc = load_pmc().get(tag)
+    if pmc and pmc.get('traffic_bytes') and roofline is not None and pmc['kernel'].split('<')[0] in roofline['kernel']:
+        roofline['traffic'] = pmc['traffic_bytes']
+        roofline['traffic_source'] = f'profiles/r03_pmc_traffic.json[{tag}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+
+
 class HostResults:
     """Page-locked destination of one step's results (pbvi_host_alloc): U rows (room for B), index, actions."""
 
@@ -144,12 +167,16 @@ def timed_steps(step, steps: int, warmup: int, fence):
     return np.asarray(per), time.perf_counter() - t0, outs
 
 
-def measure_config(name, m, alpha, beliefs, dtype, mode, steps, warmup, fence, true_dense=False, screen=None, fused=None):
-    """One single-GPU configuration measured like the headline one (run + results to pinned host, median)."""
+def measure_config(name, m, alpha, beliefs, dtype, mode, steps, warmup, fence, true_dense=False, screen=None, fused=None,
+                   formulation=None, pmc_tag=None):
+    """One single-GPU configuration measured like round 2's headline (run + results to pinned host, median; the SAME
+    belief block every step -- ``reused_block`` in the entry -- the fresh-block protocol is the headline's)."""
     from pomdp_pbvi_exploration_amd.engine import Engine, debug_gemm_dense
     prev = debug_gemm_dense(True) if true_dense else None
     try:
         eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=dtype, mode=mode)
+        if formulation is not None:
+            eng.set_formulation(formulation)
         if screen is not None:
             eng.set_f64_screen(screen)
         if fused is not None:
@@ -167,10 +194,13 @@ def measure_config(name, m, alpha, beliefs, dtype, mode, steps, warmup, fence, t
         per, _, stats = timed_steps(step, steps, warmup, fence)
         med = float(np.median(per))
         out = {'workload': name, 'dtype': dtype, 'value': B / med, 'unit': 'backups/s', 'ms_per_step': med * 1e3,
-               'steps': steps, 'warmup': warmup, 'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': int(alpha.shape[0]), 'B': B,
+               'steps': steps, 'warmup': warmup, 'reused_block': True, 'formulation': {1: 'alpha-side', 2: 'belief-side'}.get(int(stats[-1].get('formulation', 0)), '?'),
+               'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': int(alpha.shape[0]), 'B': B,
                'roofline': gemm_roofline(stats, dtype, mode),
                'stage_ms': {k: float(np.mean([s[k] for s in stats])) for k in STAGES},
                'unique_rows': int(stats[-1]['n_unique'])}
+        if pmc_tag:
+            attach_traffic(out['roofline'], pmc_tag)
         host.close()
         eng.close()
         return out
@@ -372,32 +402,26 @@ def main():
         if resident_ms is not None:
             out['value_device_resident'] = B / (resident_ms * 1e-3)
             out['ms_per_step_device_resident'] = resident_ms
-        # HBM-side bytes per launch of the roofline kernel come from a separate rocprofv3 --pmc run
-        # (FETCH_SIZE / WRITE_SIZE cannot be read inside this process); reported only for the exact
-        # workload they were measured on.
-        try:
-            pmc_path = next(p for p in (os.path.join(REPO, 'profiles', f) for f in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'))
-                            if os.path.exists(p))
-            with open(pmc_path) as fh:
-                pmc = json.load(fh)
-            if (sparse and args.dtype == 'f32' and m.S == 30000 and m.R == 1 and args.alphas == 1024 and B == 1024
-                    and out['roofline'] is not None):
-                out['roofline']['traffic'] = pmc['traffic_bytes']
-                out['roofline']['traffic_source'] = f'{os.path.relpath(pmc_path, REPO)} (rocprofv3 --pmc, separate passes)'
+        # HBM-side bytes per launch of the roofline kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE /
+        # WRITE_SIZE cannot be read inside this process); reported only for the exact workload they were measured on
+        # (profiles/collect_r03.sh -> profiles/r03_pmc_traffic.json, one entry per configuration).
+        if (sparse and args.dtype == 'f32' and m.S == 30000 and m.R == 1 and args.alphas == 1024 and B == 1024
+                and out['roofline'] is not None):
+            attach_traffic(out['roofline'], 'c4')
+            pmc = load_pmc().get('c4')
+            if pmc:
                 # the HBM-bound stages beside the GEMM: PMC bytes of the stage's main kernel / the stage's live time
                 # (the stage time also holds its small helper kernels, so these fractions are lower bounds)
-                other = pmc.get('other_kernels', {})
                 sec = {}
-                for stage, kern in (('ms_project', 'k_project'), ('ms_argmax', 'k_argmax'), ('ms_refine', 'k_refine')):
-                    if kern in other:
+                for stage, kern in (('ms_argmax', 'k_argmax<float>'), ('ms_refine', 'k_refine<float, float, true>')):
+                    if kern in pmc['kernels']:
                         ms = out['stage_ms'][stage]
-                        gbs = other[kern]['traffic_bytes'] / (ms * 1e-3) / 1e9
-                        sec[kern] = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                     'frac': gbs / PEAK_HBM_GBS, 'traffic': other[kern]['traffic_bytes'], 'ms': ms}
+                        tb = pmc['kernels'][kern]['traffic_bytes']
+                        gbs = tb / (ms * 1e-3) / 1e9
+                        sec[kern] = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
+                                     'traffic': tb, 'ms': ms}
                 if sec:
                     out['stage_roofline'] = sec
-        except (StopIteration, OSError, KeyError, ValueError):
-            pass
         if host_ms is not None:
             out['pcie_inclusive'] = {'ms_per_step': host_ms, 'value': B / (host_ms * 1e-3), 'unit': 'backups/s',
                                      'what': 'pageable beliefs (engine dtype) uploaded + run + unique rows and the expanded [B][S] alpha\' matrix fetched into a pageable array the caller keeps; mean of 3 after one warm-up'}
@@ -415,19 +439,39 @@ def main():
                                                'f32', 'sparse', 20, 5, fence, fused=False)
             sec['c4_f64'] = measure_config('olfactory-30000 reachable-sparse R=1, fp64 engine (the reference\'s precision; scores '
                                            'screened in fp32, near-ties re-decided from the fp64 operands)',
-                                           m, alpha, beliefs, 'f64', 'sparse', 10, 3, fence)
+                                           m, alpha, beliefs, 'f64', 'sparse', 10, 3, fence, pmc_tag='c4_f64')
             sec['c4_f64_pure'] = measure_config('olfactory-30000 reachable-sparse R=1, fp64 engine with the screen off '
                                                 '(fp64 MFMA score GEMM)', m, alpha, beliefs, 'f64', 'sparse', 5, 2, fence,
-                                                screen='off')
+                                                screen='off', pmc_tag='c4_f64_pure')
             m5 = synth.olfactory_model(H=H, W=W, R=5)
             alpha5, _ = synth.alpha_set(m5, args.alphas)
             beliefs5 = synth.belief_points(m5, B)
             sec['c4_r5'] = measure_config('olfactory-30000 reachable-sparse R=5 (stochastic moves)', m5, alpha5, beliefs5,
-                                          'f32', 'sparse', 20, 5, fence)
+                                          'f32', 'sparse', 20, 5, fence, pmc_tag='c4_r5')
             del m5, alpha5, beliefs5
+            # the protocol behind the reference's published 0.63 s per backup (Olfactory_Alternation_Paper_Wrap.ipynb:728-734):
+            # ~100 new beliefs against a value function of thousands of rows, fp64 -- here B = 100, V = 8192, the engine
+            # solve(use_gpu=True) uses by default (fp64, fp32 screen, belief-side formulation chosen by the cost model)
+            alpha8k, _ = synth.alpha_set(m, 8192)
+            sec['solve_shape'] = measure_config('olfactory-30000 R=1, the solve loop\'s shape: B=100 new beliefs x V=8192 alpha-vectors, '
+                                                'fp64 engine as PBVI_Solver.solve(use_gpu=True) runs it', m, alpha8k, beliefs[:100],
+                                                'f64', 'sparse', 20, 5, fence)
+            del alpha8k
+            # the shape at which the reference's CuPy path ran out of memory (Sea_Robin_Real.ipynb:913: 21.95 GB for Gamma in
+            # fp64 at |V| = 1386, S = 61875, A = 16, O = 2); synthetic tables of that shape
+            from types import SimpleNamespace
+            S2, A2, O2, rs2, rto2, er2, alpha2, bel2 = synth.sea_robin_like()
+            m2 = SimpleNamespace(S=S2, A=A2, O=O2, R=1, reachable_states=rs2, rto=rto2, expected_rewards=er2, gamma=0.99)
+            sec['sea_robin_v1386'] = measure_config('sea-robin shape S=61875, A=16, O=2, R=1 at |V|=1386 (where the reference\'s '
+                                                    'CuPy run died), B=100, fp64 engine; synthetic tables', m2, alpha2, bel2, 'f64',
+                                                    'sparse', 10, 3, fence)
+            sec['sea_robin_v1386_alpha_side_f32'] = measure_config('the same shape, fp32 engine, alpha-side formulation (Gamma for all '
+                                                                   '1386 x 32 rows on the device)', m2, alpha2, bel2, 'f32', 'sparse', 10, 3,
+                                                                   fence, formulation='alpha')
+            del m2, rs2, rto2, er2, alpha2, bel2
             sec['c3_dense'] = measure_config('olfactory-30000 dense projection (|A||O| MFMA GEMMs over densified T.O, every '
                                              'tile of both GEMMs multiplied), fp32', m, alpha, beliefs, 'f32', 'dense', 3, 1,
-                                             fence, true_dense=True)
+                                             fence, true_dense=True, pmc_tag='c3_dense')
         except (MemoryError, RuntimeError) as e:          # a smaller card: report what was measured
             sec['error'] = f'{type(e).__name__}: {e}'
         out['secondary'] = sec

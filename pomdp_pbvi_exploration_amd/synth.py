@@ -192,6 +192,31 @@ def alpha_set(m: SynthModel, V: int, seed: int = 7, f32: bool = True):
     return alpha, actions
 
 
+def sea_robin_like(H: int = 165, W: int = 375, V: int = 1386, B: int = 100, seed: int = 61875):
+    """Tables of the SHAPE of the reference's largest other model family (``Experiments/Sea Robins/Sea_Robin_Real.ipynb``:
+    S = 61875 = 165 x 375, A = 16, O = 2, one reachable state per (s, a); its CuPy run went out of memory allocating
+    Gamma[A,O,V,S] in fp64 at |V| = 1386, ``:913``): 16 grid moves with wrap-around, a random two-way observation model with
+    impossible observations, a sparse reward, V alpha-vectors and B sparse beliefs.  Synthetic -- the notebook's data files
+    are not shipped.  Returns ``(S, A, O, rs, rto, er, alpha, beliefs)`` (fp32-representable fp64 arrays)."""
+    rng = np.random.default_rng(seed)
+    A, O = 16, 2
+    S = H * W
+    y, x = np.divmod(np.arange(S), W)
+    moves = [(-1, 0), (0, 1), (1, 0), (0, -1), (-2, 0), (0, 2), (2, 0), (0, -2), (-1, 1), (1, 1), (1, -1), (-1, -1), (0, 0),
+             (0, 5), (5, 0), (0, -5)]
+    rs = np.stack([((y + dy) % H) * W + (x + dx) % W for dy, dx in moves], axis=1)[:, :, None].astype(np.int64)
+    p = 0.05 + 0.9 * rng.random((S, A))
+    p[rng.random((S, A)) < 0.2] = 0.0                                  # states where one observation is impossible
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    rto = r32(np.stack([p, 1.0 - p], axis=2)[:, :, :, None])
+    er = (rng.random((S, A)) < 0.01).astype(np.float64)
+    alpha = r32(rng.random((V, S)) * rng.random((V, 1)) * 10.0)
+    b = rng.random((B, S)) * (rng.random((B, S)) < 0.1)
+    b[:, 17] += 1e-3
+    beliefs = r32(b / b.sum(axis=1, keepdims=True))
+    return S, A, O, rs, rto, er, alpha, beliefs
+
+
 def checksum(*arrays) -> str:
     """sha256 over the raw bytes of the given arrays (fixture input pin)."""
     h = hashlib.sha256()
