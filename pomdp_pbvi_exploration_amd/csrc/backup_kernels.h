@@ -83,7 +83,8 @@ hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gam
                                                           others are generated inside the fused score GEMM */,
                           const int* vlist = nullptr, int n_vlist = 0 /* device list of the 4-row alpha blocks to visit */,
                           const int32_t* irr = nullptr /* [A][k_tiles]: K tiles written whatever `mat` says (the fused GEMM
-                                                          for R > 1 reads the tiles it does not generate) */);
+                                                          for R > 1 reads the tiles it does not generate) */,
+                          const int32_t* ctile = nullptr /* compact layout: 256-row tile t of Gamma is stored at tile ctile[t] */);
 hipError_t launch_need_tiles(const uint8_t* nzA, int tiles_m, const uint8_t* nzB /* [AO+1][k_tiles] */, int AO, int V,
                              int k_tiles, uint8_t* need, hipStream_t st);
 
@@ -184,7 +185,8 @@ hipError_t launch_belief_tiles(const T* bel, int ldb, int B, int S, int k_tiles,
 // K4: val[b][a] = b.ER[:,a] + sum_o best_score[b][a][o]; action = first max; near-ties queued
 // Gamma tail rows [A*O*V + A*O, +2A): ER[:,a] and |ER[:,a]|, so the score GEMM also yields b.ER[:,a]
 template <typename T>
-hipError_t launch_tail_rows(ModelView<T> mv, T* gam_tail, int ldg, hipStream_t st);
+hipError_t launch_tail_rows(ModelView<T> mv, T* gam /* row 0 */, int64_t row0 /* first tail row */, int ldg, hipStream_t st,
+                            const int32_t* ctile = nullptr);
 template <typename T>
 hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, const int* chain_steps,
                          const double* best_score, const double* err, double* rdot, double* rdot_err, int32_t* action,

@@ -153,7 +153,8 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
                           const int* __restrict__ vlist /* blocks of 4 alpha rows to visit (nullptr = blockIdx.y) */,
                           const int32_t* __restrict__ irr /* [A][k_tiles]: K tiles written whatever `mat` says (fused GEMM, R > 1:
                                                              it reads the tiles it cannot generate), or nullptr */,
-                          int nx, int ny, int tile_x, int tile_y /* 1-D grid in L2-tiled order (see below); tile_x <= 0: 3-D grid */) {
+                          int nx, int ny, int tile_x, int tile_y /* 1-D grid in L2-tiled order (see below); tile_x <= 0: 3-D grid */,
+                          const int32_t* __restrict__ ctile /* compact layout: 256-row tile t of Gamma lives at tile ctile[t], or nullptr */) {
 #pragma clang fp contract(off)   // einsum then scale: sum_r (rto*alpha), one rounding per op, as the reference
     // NS consecutive states per thread = 16 bytes of every table load and Gamma store (float: 4, double: 2; S_pad is a
     // multiple of 32), 4 alpha-vectors x up to 4 observations per pass: 16 NS-wide accumulators.  (With 4 doubles per
@@ -289,7 +290,10 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
                     const int v = v0 + vj;
                     // alpha rows -> group-major rows; the magnitude row (v == V-1 of the Vt rows) -> tail
                     const int64_t row = (v < V - 1) ? ao * (V - 1) + v : (int64_t)mv.A * mv.O * (V - 1) + ao;
-                    if (mat == nullptr || irr_here || mat[row >> 8]) *(TN*)(gam + row * ldg + s) = gamma * acc[vj][oj];
+                    if (mat == nullptr || irr_here || mat[row >> 8]) {
+                        const int64_t at = ctile != nullptr ? (int64_t)ctile[row >> 8] * 256 + (row & 255) : row;
+                        *(TN*)(gam + at * ldg + s) = gamma * acc[vj][oj];
+                    }
                 }
     }
 }
@@ -297,7 +301,7 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
 template <typename T>
 hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gamma, T* gam, int ldg,
                           const uint8_t* need, int k_tiles, hipStream_t st, const uint8_t* mat, const int* vlist, int n_vlist,
-                          const int32_t* irr) {
+                          const int32_t* irr, const int32_t* ctile) {
     if (V <= 0) return hipSuccess;
     if (vlist != nullptr && n_vlist <= 0) return hipSuccess;
     constexpr int NS = 16 / (int)sizeof(T);
@@ -309,10 +313,10 @@ hipError_t launch_project(const T* alpha, int lda, int V, ModelView<T> mv, T gam
     // observations per pass = accumulator rows per alpha-vector: exactly O when O < 4 (16 fewer VGPRs per missing one)
     auto launch = [&](dim3 grid, int tx, int ty) {
         switch (mv.O < 4 ? mv.O : 4) {
-            case 1: hipLaunchKernelGGL((k_project<T, 1>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty); break;
-            case 2: hipLaunchKernelGGL((k_project<T, 2>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty); break;
-            case 3: hipLaunchKernelGGL((k_project<T, 3>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty); break;
-            default: hipLaunchKernelGGL((k_project<T, 4>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty); break;
+            case 1: hipLaunchKernelGGL((k_project<T, 1>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty, ctile); break;
+            case 2: hipLaunchKernelGGL((k_project<T, 2>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty, ctile); break;
+            case 3: hipLaunchKernelGGL((k_project<T, 3>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty, ctile); break;
+            default: hipLaunchKernelGGL((k_project<T, 4>), grid, dim3(256), 0, st, alpha, lda, V, mv, gamma, gam, ldg, need, k_tiles, mat, vlist, irr, nx, ny, tx, ty, ctile); break;
         }
         return hipGetLastError();
     };
@@ -1190,17 +1194,19 @@ hipError_t launch_refine(bool proj, SlabView<TS> sv, int V, int G, int max_entri
 //   row j <  A : ER[:, j]         -> score column = b . ER[:,a]      (rdot)
 //   row j >= A : |ER[:, j-A]|     -> score column = b . |ER[:,a]|    (scales rdot's f32 error bound)
 template <typename T>
-__global__ void k_tail_rows(ModelView<T> mv, T* __restrict__ gam_tail, int ldg) {
+__global__ void k_tail_rows(ModelView<T> mv, T* __restrict__ gam, int64_t row0, int ldg, const int32_t* __restrict__ ctile) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     const int j = blockIdx.y;
     if (s >= mv.S_pad) return;
     const T e = mv.er[(int64_t)(j % mv.A) * mv.S_pad + s];
-    gam_tail[(int64_t)j * ldg + s] = (j < mv.A) ? e : (e < T(0) ? -e : e);
+    const int64_t row = row0 + j;
+    const int64_t at = ctile != nullptr ? (int64_t)ctile[row >> 8] * 256 + (row & 255) : row;      // compact layout of a fused GEMM
+    gam[at * ldg + s] = (j < mv.A) ? e : (e < T(0) ? -e : e);
 }
 
 template <typename T>
-hipError_t launch_tail_rows(ModelView<T> mv, T* gam_tail, int ldg, hipStream_t st) {
-    hipLaunchKernelGGL(k_tail_rows<T>, dim3((mv.S_pad + 255) / 256, 2 * mv.A), dim3(256), 0, st, mv, gam_tail, ldg);
+hipError_t launch_tail_rows(ModelView<T> mv, T* gam, int64_t row0, int ldg, hipStream_t st, const int32_t* ctile) {
+    hipLaunchKernelGGL(k_tail_rows<T>, dim3((mv.S_pad + 255) / 256, 2 * mv.A), dim3(256), 0, st, mv, gam, row0, ldg, ctile);
     return hipGetLastError();
 }
 
@@ -1875,8 +1881,8 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
 #define PBVI_INST(T)                                                                                                   \
     template hipError_t launch_support<T>(ModelView<T>, uint8_t*, hipStream_t);                                        \
     template hipError_t launch_project<T>(const T*, int, int, ModelView<T>, T, T*, int, const uint8_t*, int,           \
-                                          hipStream_t, const uint8_t*, const int*, int, const int32_t*);               \
-    template hipError_t launch_tail_rows<T>(ModelView<T>, T*, int, hipStream_t);                                       \
+                                          hipStream_t, const uint8_t*, const int*, int, const int32_t*, const int32_t*); \
+    template hipError_t launch_tail_rows<T>(ModelView<T>, T*, int64_t, int, hipStream_t, const int32_t*);               \
     template hipError_t launch_dead<T>(const T*, int, int, ModelView<T>, const unsigned long long*, int, uint8_t*, int32_t*, \
                                        int32_t*, int*, hipStream_t, const uint8_t*, const int32_t*);                                                   \
     template hipError_t launch_belief_tiles<T>(const T*, int, int, int, int, int32_t*, int32_t*, hipStream_t);         \

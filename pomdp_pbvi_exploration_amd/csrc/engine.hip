@@ -686,6 +686,10 @@ class EngineT : public EngineBase {
     double irr_frac_ = 0.0;                                  // share of (action, K tile) with non-consecutive successors
     DevBuf irr_;                                             // [A][k_tiles] 1 = a 4-state chunk of the K tile has non-consecutive successors
     DevBuf mat_, vlist_;                                     // [n-tiles] 1 = projected (straddles groups / tail), 0 = generated
+    DevBuf ctile_;                                           // [n-tiles] compact tile index of a projected tile (-1: generated)
+    std::vector<int32_t> h_ctile_;
+    int n_mat_ = 0;                                          // projected tiles = tiles of Gamma that exist in memory when fused
+    bool gam_pad_compact_ = false;
     std::vector<uint8_t> h_mat_;
     std::vector<int> h_vlist_;
     int64_t mat_V_ = -1;
@@ -713,7 +717,7 @@ class EngineT : public EngineBase {
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &snz_, &sbtl_, &sbtc_, &vmax_bk_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
-                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_, &scr_flag_};
+                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_, &scr_flag_, &ctile_};
         // every call is checked only to name a failure when PBVI_DEBUG is set; the thread's sticky last-error is cleared at
         // the end either way, so that a later launch check does not report a stale error of this teardown
         static const bool dbg = getenv("PBVI_DEBUG") != nullptr;
@@ -1481,7 +1485,7 @@ class EngineT : public EngineBase {
                           &bu_mass_, &bu_out_, &bu_row_, &walk64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_,
                           &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_, &snz_, &sbtl_, &sbtc_, &vmax_bk_,
                           &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_, &nzAlpha_, &prod_, &klistD_,
-                          &kcountD_, &nchunksD_, &mat_, &vlist_, &rowflags_};
+                          &kcountD_, &nchunksD_, &mat_, &vlist_, &rowflags_, &ctile_};
         for (DevBuf* b : drop) {
             bytes_ -= (int64_t)b->cap;
             b->release();
@@ -2401,16 +2405,64 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
     const ModelView<T> mv = view();
     const int k_tiles = S_pad_ / GEMM_BK;
     const int64_t n_rows_alloc = kF32 ? round_up(N, GEMM_BN) : N;
-    if (!use_push) {
-        if ((rc = gam_.ensure((size_t)n_rows_alloc * S_pad_ * sizeof(T), &bytes_))) return rc;
-        // zero the Gamma pad rows the GEMM tiles read -- once per (buffer, row count): nothing writes rows >= N, and the
-        // fill of up to 255 rows (27 MB, 39 us at |S| = 30000) sat in front of every backup's score GEMM
-        if (n_rows_alloc > N && (gam_pad_ptr_ != gam_.p || gam_pad_N_ != N || mode_ == PBVI_DENSE)) {
-            HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)N * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
-            gam_pad_ptr_ = gam_.p;
-            gam_pad_N_ = N;
+    // One reachable state per (s, a) -- every large model of the reference -- on an fp32 engine: the score GEMM generates
+    // the Gamma tiles that lie inside one (a, o) group itself (gemm.hip, scheduler 2b); only the tiles that straddle two
+    // groups and the tail tile are projected ("mat" tiles).  Then only THOSE tiles exist in memory: tile tn of Gamma
+    // lives at compact tile ctile[tn] (C4: one tile, 30 MB, instead of 2.24 GB; the reference's CuPy path died
+    // allocating Gamma[A,O,V,S], Sea_Robin_Real.ipynb:913).
+    bool will_fuse = false;
+    if constexpr (kF32) {
+        static const bool no_fuse = getenv("PBVI_NO_FUSED_PROJECT") != nullptr;     // debug / A-B only
+        will_fuse = !use_push && mode_ == PBVI_SPARSE && !no_fuse && irr_.p != nullptr &&
+                    (R_ == 1 ? fuse_project_ >= 1 : (R_ <= 7 && fuse_project_ >= 2));
+    }
+    static const bool no_compact = getenv("PBVI_NO_COMPACT_GAMMA") != nullptr;      // debug / A-B only
+    const bool compact = will_fuse && R_ == 1 && !no_compact;
+    if (will_fuse) {
+        const int tiles_n = (int)(n_rows_alloc / GEMM_BN);
+        if (mat_V_ != V_ || (int)h_mat_.size() != tiles_n) {
+            h_mat_.assign((size_t)tiles_n, 0);
+            h_ctile_.assign((size_t)tiles_n, -1);
+            n_mat_ = 0;
+            for (int tn = 0; tn < tiles_n; ++tn) {
+                const int64_t r0 = (int64_t)tn * 256, r1 = r0 + 255;
+                h_mat_[(size_t)tn] = (r1 >= (int64_t)AO * V_ || r0 / V_ != r1 / V_) ? 1 : 0;
+                if (h_mat_[(size_t)tn]) h_ctile_[(size_t)tn] = n_mat_++;
+            }
+            // the 4-row blocks of alpha rows the projection still has to visit: those with a row in a
+            // projected tile for some group, and the block that holds the magnitude row
+            h_vlist_.clear();
+            for (int64_t vb = 0; vb * 4 < Vt; ++vb) {
+                bool hit = vb * 4 + 4 > V_;
+                for (int ao = 0; ao < AO && !hit; ++ao)
+                    for (int64_t v = vb * 4; v < vb * 4 + 4 && v < V_ && !hit; ++v) hit = h_mat_[(size_t)((ao * V_ + v) >> 8)] != 0;
+                if (hit) h_vlist_.push_back((int)vb);
+            }
+            if ((rc = mat_.ensure((size_t)tiles_n, &bytes_))) return rc;
+            if ((rc = ctile_.ensure((size_t)tiles_n * sizeof(int32_t), &bytes_))) return rc;
+            if ((rc = vlist_.ensure(h_vlist_.size() * sizeof(int), &bytes_))) return rc;
+            HIPCHK(hipMemcpyAsync(mat_.p, h_mat_.data(), (size_t)tiles_n, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(ctile_.p, h_ctile_.data(), (size_t)tiles_n * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(vlist_.p, h_vlist_.data(), h_vlist_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+            mat_V_ = V_;
+            gam_pad_ptr_ = nullptr;                          // the pad rows sit elsewhere now
         }
     }
+    if (!use_push) {
+        const int64_t rows_held = compact ? (int64_t)n_mat_ * GEMM_BN : n_rows_alloc;
+        if ((rc = gam_.ensure((size_t)rows_held * S_pad_ * sizeof(T), &bytes_))) return rc;
+        // zero the Gamma pad rows the GEMM tiles read -- once per (buffer, row count, layout): nothing writes rows >= N,
+        // and the fill of up to 255 rows (27 MB, 39 us at |S| = 30000) sat in front of every backup's score GEMM
+        if (n_rows_alloc > N && (gam_pad_ptr_ != gam_.p || gam_pad_N_ != N || gam_pad_compact_ != compact || mode_ == PBVI_DENSE)) {
+            // (the pad rows are the end of the last tile, which is always a projected one: contiguous in either layout)
+            const int64_t first = compact ? (int64_t)(n_mat_ - 1) * GEMM_BN + (N - (n_rows_alloc - GEMM_BN)) : N;
+            HIPCHK(hipMemsetAsync(gam_.as<T>() + (size_t)first * S_pad_, 0, (size_t)(n_rows_alloc - N) * S_pad_ * sizeof(T), stream_));
+            gam_pad_ptr_ = gam_.p;
+            gam_pad_N_ = N;
+            gam_pad_compact_ = compact;
+        }
+    }
+    const int32_t* ctile = compact ? ctile_.as<int32_t>() : nullptr;
     SlabView<T> sv;
     out->extra_row0 = -1;
     out->fused = false;
@@ -2466,34 +2518,8 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
                 HIPCHK(hipMemcpyAsync(h_kcountD_.data(), kcountD_.p, kcountD_.cap, hipMemcpyDeviceToHost, stream_));
             }
         } else {
-            // One reachable state per (s, a) -- every large model of the reference -- on an fp32 engine: the score GEMM
-            // generates the Gamma tiles that lie inside one (a, o) group itself (gemm.hip, scheduler 2b); only the tiles
-            // that straddle two groups and the tail tile are projected here.
             if constexpr (kF32) {
-                static const bool no_fuse = getenv("PBVI_NO_FUSED_PROJECT") != nullptr;     // debug / A-B only
-                if ((R_ == 1 ? fuse_project_ >= 1 : (R_ <= 7 && fuse_project_ >= 2)) && !no_fuse && irr_.p != nullptr) {
-                    const int tiles_n = (int)(round_up(N, GEMM_BN) / GEMM_BN);
-                    if (mat_V_ != V_ || (int)h_mat_.size() != tiles_n) {
-                        h_mat_.assign((size_t)tiles_n, 0);
-                        for (int tn = 0; tn < tiles_n; ++tn) {
-                            const int64_t r0 = (int64_t)tn * 256, r1 = r0 + 255;
-                            h_mat_[(size_t)tn] = (r1 >= (int64_t)AO * V_ || r0 / V_ != r1 / V_) ? 1 : 0;
-                        }
-                        // the 4-row blocks of alpha rows the projection still has to visit: those with a row in a
-                        // projected tile for some group, and the block that holds the magnitude row
-                        h_vlist_.clear();
-                        for (int64_t vb = 0; vb * 4 < Vt; ++vb) {
-                            bool hit = vb * 4 + 4 > V_;
-                            for (int ao = 0; ao < AO && !hit; ++ao)
-                                for (int64_t v = vb * 4; v < vb * 4 + 4 && v < V_ && !hit; ++v) hit = h_mat_[(size_t)((ao * V_ + v) >> 8)] != 0;
-                            if (hit) h_vlist_.push_back((int)vb);
-                        }
-                        if ((rc = mat_.ensure((size_t)tiles_n, &bytes_))) return rc;
-                        if ((rc = vlist_.ensure(h_vlist_.size() * sizeof(int), &bytes_))) return rc;
-                        HIPCHK(hipMemcpyAsync(mat_.p, h_mat_.data(), (size_t)tiles_n, hipMemcpyHostToDevice, stream_));
-                        HIPCHK(hipMemcpyAsync(vlist_.p, h_vlist_.data(), h_vlist_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-                        mat_V_ = V_;
-                    }
+                if (will_fuse) {
                     fb.alpha = (const float*)alpha_.p;
                     fb.lda = S_pad_;
                     fb.rs = rs_.as<int32_t>();
@@ -2505,15 +2531,16 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
                     fb.gamma = (float)gamma;
                     fb.mat = mat_.as<uint8_t>();
                     fb.irr = irr_.as<int32_t>();
+                    fb.ctile = ctile;
                     fused = &fb;
                 }
             }
             HIPCHK(launch_project<T>(alpha_.as<T>(), S_pad_, (int)Vt, mv, (T)gamma, gam_.as<T>(), S_pad_, need, k_tiles, stream_,
                                      fused ? mat_.as<uint8_t>() : nullptr, fused && R_ == 1 ? vlist_.as<int>() : nullptr,
                                      fused && R_ == 1 ? (int)h_vlist_.size() : 0,
-                                     fused && R_ > 1 ? irr_.as<int32_t>() : nullptr));
+                                     fused && R_ > 1 ? irr_.as<int32_t>() : nullptr, ctile));
         }
-        HIPCHK(launch_tail_rows<T>(mv, gam_.as<T>() + (size_t)(AO * Vt) * S_pad_, S_pad_, stream_));
+        HIPCHK(launch_tail_rows<T>(mv, gam_.as<T>(), (int64_t)AO * Vt, S_pad_, stream_, ctile));
         HIPCHK(hipEventRecord(io.ev[1], stream_));
         // K2: scores
         // (its tile lists and stream-K plan are built on the side stream, beside the projection)

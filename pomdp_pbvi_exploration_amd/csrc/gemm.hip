@@ -480,7 +480,8 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk_fused(
             f32x16 acc[4][2];
             tile_zero(acc);
             if (fb.mat[tn]) {                            // block-uniform: projected rows, the LDS-DMA path
-                tile_run(t, lds, A + (int64_t)tm * 256 * lda, lda, B + (int64_t)tn * 256 * ldb, ldb,
+                const int bt = fb.ctile != nullptr ? fb.ctile[tn] : tn;      // (compact layout: only these tiles exist)
+                tile_run(t, lds, A + (int64_t)tm * 256 * lda, lda, B + (int64_t)bt * 256 * ldb, ldb,
                          klist + (int64_t)p * k_tiles, lo, hi, acc);
             } else {
                 const int r0 = tn * 256;

@@ -45,6 +45,7 @@ struct FusedB {
     int S_pad, O, V;      // groups of V rows each
     int R;                // reachable states per (s, a): 1 -> scheduler 2b, 2..7 -> scheduler 2c (gemm.hip)
     float gamma;
+    const int32_t* ctile; // [tiles_n] device, or nullptr: B holds only the tiles with mat[tile] != 0, tile tn at tile ctile[tn]
     const uint8_t* mat;   // [tiles_n] device
     const int32_t* irr;   // [A][K_pad/32] device (int32: read with scalar loads): 1 = the K tile holds a 4-state chunk
                           // with non-consecutive successors (R = 1: gathered by the kernel; R > 1: that Gamma tile is

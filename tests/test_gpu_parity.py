@@ -1734,3 +1734,34 @@ def test_pinned_buffer_outlives_its_arrays():
     del view
     gc.collect()
     buf.close()
+
+
+def test_fused_engine_holds_only_the_projected_tiles_of_gamma():
+    """With the projection fused into the score GEMM only the Gamma tiles that are still projected exist in memory (the tail
+    tile and tiles that straddle two groups): at V a multiple of 256 that is ONE 256-row tile instead of A*O*V rows -- the
+    buffer the reference's CuPy path could not allocate (Sea_Robin_Real.ipynb:913).  Switching the same engine to the
+    projected pipeline allocates the full buffer; results are the same bits."""
+    rng = np.random.default_rng(3)
+    S, A, O, V, B = 30000, 2, 2, 1024, 300
+    rs = ((np.arange(S)[:, None] + np.array([1, -400])[None, :]) % S)[:, :, None].astype(np.int64)
+    p = rng.random((S, A, O))
+    rto = (p / p.sum(axis=2, keepdims=True))[:, :, :, None].astype(np.float32).astype(np.float64)
+    er = rng.normal(size=(S, A)).astype(np.float32).astype(np.float64)
+    alpha = rng.normal(size=(V, S)).astype(np.float32).astype(np.float64)
+    b = rng.random((B, S)) * (rng.random((B, S)) < 0.1)
+    b[:, 5] += 1e-3
+    b = (b / b.sum(axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    eng = Engine(S, A, O, 1, rs, rto, er, dtype='f32')
+    eng.set_formulation('alpha')
+    fused = eng.backup_full(alpha, b, 0.9)
+    held_fused = eng.device_bytes
+    eng.set_fused_projection(False)
+    plain = eng.backup_full(alpha, b, 0.9)
+    held_plain = eng.device_bytes
+    if FUSION_ALLOWED and os.environ.get('PBVI_NO_COMPACT_GAMMA') is None:
+        assert fused.stats['fused_projection'] == 1
+        gamma_rows = A * O * (V + 1) + 2 * A
+        full = (gamma_rows + 255) // 256 * 256 * 30016 * 4
+        assert held_plain - held_fused > 0.9 * (full - 256 * 30016 * 4), (held_fused, held_plain, full)
+    assert np.array_equal(fused.best_alpha_ind, plain.best_alpha_ind) and np.array_equal(fused.alpha, plain.alpha)
+    eng.close()
