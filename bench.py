@@ -96,13 +96,14 @@ class HostResults:
     def __init__(self, eng, B: int):
         from pomdp_pbvi_exploration_amd.engine import PinnedBuffer
         item = 4 if eng.dtype == 'f32' else 8
-        self.buf = PinnedBuffer(B * eng.S * item + 2 * B * 4 + 4096)
+        self.buf = PinnedBuffer(B * eng.S * item + 3 * B * 4 + 8192)
         self.rows = self.buf.carve((B, eng.S), eng.np_dtype)
         self.index = self.buf.carve((B,), np.int32)
         self.actions = self.buf.carve((B,), np.int32)
+        self.slot = self.buf.carve((B,), np.int32)           # pbvi_backup_run_fetch: row of distinct key u is rows[slot[u]]
 
     def close(self):
-        self.rows = self.index = self.actions = None
+        self.rows = self.index = self.actions = self.slot = None
         self.buf.close()
 
 
@@ -187,8 +188,7 @@ def measure_config(name, m, alpha, beliefs, dtype, mode, steps, warmup, fence, t
         host = HostResults(eng, B)
 
         def step():
-            st = eng.run(m.gamma)
-            eng.fetch_compact_into(host.rows, host.index, host.actions)
+            st, _, _ = eng.run_fetch_into(m.gamma, host.rows, host.slot, host.index, host.actions)
             return st
 
         per, _, stats = timed_steps(step, steps, warmup, fence)
@@ -227,6 +227,8 @@ def main():
     ap.add_argument('--mode', type=str, default='sparse', choices=['sparse', 'dense'],
                     help="projection: reachable-sparse ELL SpMM (BASELINE config 3, the reference's path) or dense "
                          "|A||O| MFMA GEMMs over densified T.O (config 2; 65 GB of matrices at S=30000)")
+    ap.add_argument('--two-calls', action='store_true', help='time pbvi_backup_run + pbvi_backup_fetch_compact (round 2\'s step) instead '
+                                                            'of pbvi_backup_run_fetch')
     ap.add_argument('--blocks', type=int, default=3, help='belief blocks in the device store the timed steps rotate over')
     ap.add_argument('--secondary', type=str, default='auto', choices=['auto', 'none'],
                     help="'auto': on one GPU with the default workload also measure c3_dense, c4_f64, c4_r5")
@@ -308,8 +310,12 @@ def main():
         if rotate:                                                    # a block the engine has no indexes of
             eng.select_beliefs(block_ids[step.n % len(block_ids)])
             step.n += 1
-        st = eng.run(m.gamma)
-        eng.fetch_compact_into(host.rows, host.index, host.actions)   # U rows + index + actions -> pinned host, synchronised
+        if args.two_calls:
+            st = eng.run(m.gamma)
+            eng.fetch_compact_into(host.rows, host.index, host.actions)   # U rows + index + actions -> pinned host, synchronised
+        else:
+            # the same in one call, the rows leaving for the host while the refinement still runs (pbvi_backup_run_fetch)
+            st, _, _ = eng.run_fetch_into(m.gamma, host.rows, host.slot, host.index, host.actions)
         return st
     step.n = 0
 
@@ -328,8 +334,11 @@ def main():
             eng.set_beliefs(beliefs)
 
             def reused_step():
-                eng.run(m.gamma)
-                eng.fetch_compact_into(host.rows, host.index, host.actions)
+                if args.two_calls:
+                    eng.run(m.gamma)
+                    eng.fetch_compact_into(host.rows, host.index, host.actions)
+                else:
+                    eng.run_fetch_into(m.gamma, host.rows, host.slot, host.index, host.actions)
             per_r, _, _ = timed_steps(reused_step, args.steps, 3, fence)
             reused = float(np.median(per_r))
         _, el2, _ = timed_steps(lambda: eng.run(m.gamma), args.steps, 2, fence)
@@ -365,7 +374,9 @@ def main():
                        'step': ('local backup + all-gather of ' + ('alpha rows' if exchange_rows else 'row keys')
                                 + ' + global dedup + append of the distinct rows to every replica\'s alpha store') if distributed
                                else ('pbvi_beliefs_select (next block of the device belief store) + ' if rotate else '') +
-                                    'pbvi_backup_run + pbvi_backup_fetch_compact (U distinct rows, index, actions) into pinned host memory, synchronised',
+                                    ('pbvi_backup_run + pbvi_backup_fetch_compact' if args.two_calls else 'pbvi_backup_run_fetch (= run + '
+                                     'fetch_compact in one call; rows of the provisional decision cross PCIe under the refinement)') +
+                                    ' -- U distinct rows, index, actions into pinned host memory, synchronised',
                        'parallelism': f'belief-sharded x{world}' if distributed else 'single GPU',
                        'resident_inputs': ('alpha set and the rows of the belief store in HBM before the timed region; every step '
                                            f'selects a block of {B} store rows it has not indexed (rotation over {len(block_ids)} blocks: '

@@ -192,6 +192,25 @@ int pbvi_backup_fetch_compact(pbvi_engine_t* e, void* out_rows, int32_t* out_ind
                               int32_t* out_best_alpha, uint8_t* out_keep);
 
 /*
+ * pbvi_backup_run + pbvi_backup_fetch_compact in ONE call, with the rows leaving early.  The first maxima of the score
+ * GEMM decide most beliefs' keys for good (the fp64 refinement re-decides near-ties only), so the distinct rows of that
+ * provisional decision are assembled and written into out_rows by the device WHILE the refinement, the action stage and the
+ * dedup run; the final keys are then matched against the provisional ones and only rows the refinement changed are appended.
+ *   out_rows  [cap_rows][S] T   page-locked host memory (pbvi_host_alloc), cap_rows >= B; rows arrive in SLOT order
+ *   out_slot  [B] int32         first U entries: row of distinct key u (order of first occurrence, as
+ *                               pbvi_backup_fetch_compact lists them) is out_rows[out_slot[u]]
+ *   out_index [B], out_action [B], out_best_alpha [B][A][O] (may be NULL), out_keep [B] (may be NULL): as
+ *                               pbvi_backup_fetch_compact; alpha'[b] == out_rows[out_slot[out_index[b]]]
+ *   *n_unique = U, *n_slots = rows written (>= U: provisional rows the refinement overturned stay behind, unreferenced)
+ * Same results as the two calls (src/pomdp.py:1485-1506 + the tobytes() of src/mdp.py:667-669), bit for bit; where the
+ * early path does not apply (fp64 scoring, belief-side formulation, belief-dominance test) the rows are copied at the end
+ * and out_slot is the identity.
+ */
+int pbvi_backup_run_fetch(pbvi_engine_t* e, double gamma, int flags, pbvi_stats_t* stats, void* out_rows, int64_t cap_rows,
+                          int32_t* out_slot, int32_t* out_index, int32_t* out_action, int32_t* out_best_alpha, uint8_t* out_keep,
+                          int64_t* n_unique, int64_t* n_slots);
+
+/*
  * Hashes of the U distinct rows of the last backup, out_hashes [U] uint64: sum_i bits(row, i) * (2 i + 1) mod 2^64 over
  * the row's fp32 / fp64 bit patterns.  ValueFunction.__init__ keys its dedup dictionary on `values.tobytes()`
  * (src/mdp.py:667-669) -- 120-240 KB copied and hashed per row; the host mirror keys it on this number instead (equality

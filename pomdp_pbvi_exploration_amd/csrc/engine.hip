@@ -518,6 +518,56 @@ __global__ void k_unpermute(int B, int AO, const int32_t* __restrict__ perm, con
     for (int j = tid; j < AO; j += blockDim.x) best_o[(int64_t)d * AO + j] = best_v[(int64_t)b * AO + j];
 }
 
+// ---- early rows (pbvi_backup_run_fetch) ---------------------------------------------------------------------------- //
+// One block per distinct key u of the FINAL result: is it among the provisional keys (whose rows are on their way to the
+// host already)?  Yes: slot[u] = its provisional position.  No: the row gets the next free slot behind the provisional
+// ones and this block copies it there.  cnt[0] = provisional keys, cnt[1] += new rows, cnt[2] = 1 on overflow of the slots.
+template <typename T>
+__global__ void k_match_rows(int AO, int O, const int* __restrict__ ucount, const int32_t* __restrict__ uniq, const int32_t* __restrict__ action,
+                             const int32_t* __restrict__ best, const int32_t* __restrict__ uniq_p, const int32_t* __restrict__ action_p,
+                             const int32_t* __restrict__ best_p, int* __restrict__ cnt, int cap_rows, int32_t* __restrict__ slot,
+                             const T* __restrict__ rows_dev, T* __restrict__ rows_host, int64_t cols) {
+    __shared__ int found_sh, slot_sh;
+    const int n = *ucount;
+    const int np = cnt[0];
+    for (int u = blockIdx.x; u < n; u += gridDim.x) {
+        const int b = uniq[u], a = action[b];
+        const int32_t* key = best + ((int64_t)b * AO + (int64_t)a * O);
+        __syncthreads();
+        if (threadIdx.x == 0) found_sh = 0x7fffffff;
+        __syncthreads();
+        for (int p = threadIdx.x; p < np; p += blockDim.x) {
+            const int bp = uniq_p[p];
+            bool eq = action_p[bp] == a;
+            const int32_t* kp = best_p + ((int64_t)bp * AO + (int64_t)a * O);
+            for (int o = 0; eq && o < O; ++o) eq = kp[o] == key[o];
+            if (eq) atomicMin(&found_sh, p);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int sl = found_sh;
+            if (sl == 0x7fffffff) {
+                sl = np + atomicAdd(&cnt[1], 1);
+                if (sl >= cap_rows) {
+                    cnt[2] = 1;
+                    sl = -1;
+                }
+                slot_sh = sl;
+            } else {
+                slot_sh = -2;                                // already on the host
+            }
+            slot[u] = sl;
+        }
+        __syncthreads();
+        const int sl = slot_sh;
+        if (sl >= 0) {
+            const T* src = rows_dev + (int64_t)u * cols;
+            T* dst = rows_host + (int64_t)sl * cols;
+            for (int64_t i = threadIdx.x; i < cols; i += blockDim.x) dst[i] = src[i];
+        }
+    }
+}
+
 // The scoring stage (K1, K2, first-max) runs on an engine or on an fp64 engine's fp32 screen (EngineT::stage_scores).
 struct ScoreIO {                      // the pipeline buffers the stage writes / reads: owned by the engine that continues
     int32_t* best_v;
@@ -556,6 +606,9 @@ class EngineBase {
     virtual int64_t unique_count() const = 0;
     virtual int fetch_unique(void* out_rows, int32_t* out_index) = 0;
     virtual int fetch_compact(void* out_rows, int32_t* out_index, int32_t* out_action, int32_t* out_best, uint8_t* out_keep) = 0;
+    virtual int run_fetch(double gamma, int flags, pbvi_stats_t* st, void* out_rows, int64_t cap_rows, int32_t* out_slot,
+                          int32_t* out_index, int32_t* out_action, int32_t* out_best, uint8_t* out_keep, int64_t* n_unique,
+                          int64_t* n_slots) = 0;
     virtual int fetch_unique_keys(int32_t* out_keys) = 0;
     virtual int fetch_row_hashes(uint64_t* out) = 0;
     virtual int fetch_exchange(int32_t* out, int64_t per) = 0;
@@ -664,6 +717,12 @@ class EngineT : public EngineBase {
     void* ids_pin_ = nullptr;                                // pinned staging of the ids of a store selection
     size_t ids_pin_cap_ = 0;
     int* h_flag_ = nullptr;                                  // pinned: see pinned_flag()
+    // early rows (run_fetch): destination of the current call, buffers of the provisional decision pipeline
+    void* early_rows_ = nullptr;
+    int64_t early_cap_ = 0;
+    bool early_used_ = false, early_dma_pending_ = false;
+    DevBuf e_bv_, e_bs_, e_err_, e_rdot_, e_act_, e_ares_, e_bres_, e_rep_, e_uniq_, e_inv_, e_slotd_, e_cnt_, e_out_, e_slot_;
+    hipEvent_t ev_early_[2] = {nullptr, nullptr};
     hipEvent_t ev_ids_ = nullptr;
     hipEvent_t ev_nzA_ = nullptr;                            // the resident block's zero map (nzA_) is complete
     DevBuf nzBw_;                                            // [A*O][ceil(k_tiles/64)] support tiles of RTO as bit words
@@ -717,7 +776,7 @@ class EngineT : public EngineBase {
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &snz_, &sbtl_, &sbtc_, &vmax_bk_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
-                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_, &scr_flag_, &ctile_};
+                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_, &scr_flag_, &ctile_, &e_bv_, &e_bs_, &e_err_, &e_rdot_, &e_act_, &e_ares_, &e_bres_, &e_rep_, &e_uniq_, &e_inv_, &e_slotd_, &e_cnt_, &e_out_, &e_slot_};
         // every call is checked only to name a failure when PBVI_DEBUG is set; the thread's sticky last-error is cleared at
         // the end either way, so that a later launch check does not report a stale error of this teardown
         static const bool dbg = getenv("PBVI_DEBUG") != nullptr;
@@ -730,6 +789,8 @@ class EngineT : public EngineBase {
         if (host_stage_) chk(hipHostFree(host_stage_), "hipHostFree(stage)");
         if (ids_pin_) chk(hipHostFree(ids_pin_), "hipHostFree(ids)");
         if (h_flag_) chk(hipHostFree(h_flag_), "hipHostFree(flag)");
+        for (hipEvent_t& ev : ev_early_)
+            if (ev) chk(hipEventDestroy(ev), "hipEventDestroy(early)");
         if (ev_ids_) chk(hipEventDestroy(ev_ids_), "hipEventDestroy(ids)");
         if (ev_nzA_) chk(hipEventDestroy(ev_nzA_), "hipEventDestroy(nzA)");
         for (auto& e : ev_)
@@ -1485,7 +1546,7 @@ class EngineT : public EngineBase {
                           &bu_mass_, &bu_out_, &bu_row_, &walk64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_,
                           &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_, &snz_, &sbtl_, &sbtc_, &vmax_bk_,
                           &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_, &nzAlpha_, &prod_, &klistD_,
-                          &kcountD_, &nchunksD_, &mat_, &vlist_, &rowflags_, &ctile_};
+                          &kcountD_, &nchunksD_, &mat_, &vlist_, &rowflags_, &ctile_, &e_bv_, &e_bs_, &e_err_, &e_rdot_, &e_act_, &e_ares_, &e_bres_, &e_rep_, &e_uniq_, &e_inv_, &e_slotd_, &e_out_, &e_slot_};
         for (DevBuf* b : drop) {
             bytes_ -= (int64_t)b->cap;
             b->release();
@@ -1700,6 +1761,47 @@ class EngineT : public EngineBase {
 
     // everything a caller of backup() needs, in one staged transfer and one synchronisation: the U distinct rows, the
     // per-belief index into them, actions, best_alpha_ind and the keep mask (any destination may be NULL)
+    // pbvi_backup_run + pbvi_backup_fetch_compact in one call; the rows go to page-locked `out_rows` in SLOT order
+    // (out_slot[u] = row of distinct key u) and most of them leave while the refinement is still running (run_pipeline).
+    int run_fetch(double gamma, int flags, pbvi_stats_t* st, void* out_rows, int64_t cap_rows, int32_t* out_slot, int32_t* out_index,
+                  int32_t* out_action, int32_t* out_best, uint8_t* out_keep, int64_t* n_unique, int64_t* n_slots) override {
+        if (!out_rows || !out_slot || !out_index || !out_action) FAIL(PBVI_EINVAL, "backup_run_fetch: NULL destination");
+        if (cap_rows < B_) FAIL(PBVI_EINVAL, "backup_run_fetch: out_rows must have room for one row per belief");
+        if (!is_pinned_host_pointer(out_rows)) FAIL(PBVI_EINVAL, "backup_run_fetch: out_rows must be page-locked host memory (pbvi_host_alloc)");
+        early_rows_ = out_rows;
+        early_cap_ = cap_rows;
+        int rc = backup_run(gamma, flags, st);
+        early_rows_ = nullptr;
+        if (rc) return rc;
+        const size_t B = (size_t)res_B_;
+        bool slots_done = false;
+        int64_t used = res_unique_;
+        if (early_used_ && h_flag_ && !h_flag_[6]) {         // rows are in place; slots from the device
+            used = (int64_t)h_flag_[4] + h_flag_[5];
+            if ((rc = out_begin())) return rc;
+            if ((rc = out_add(out_slot, e_slot_.p, (size_t)res_unique_ * sizeof(int32_t)))) return rc;
+            slots_done = true;
+        } else {                                             // not applicable (or the slots overflowed): the plain order
+            if ((rc = out_begin())) return rc;
+            if ((rc = out_add(out_rows, out_.p, (size_t)res_unique_ * S_ * sizeof(T)))) return rc;
+        }
+        if ((rc = out_add(out_index, inv_.p, B * sizeof(int32_t)))) return rc;
+        if ((rc = out_add(out_action, res_action_, B * sizeof(int32_t)))) return rc;
+        if (out_best && (rc = out_add(out_best, res_best_, B * A_ * O_ * sizeof(int32_t)))) return rc;
+        if (out_keep && (rc = out_add(out_keep, keep_.p, B))) return rc;
+        if ((rc = out_finish())) return rc;
+        if (slots_done) {
+            for (int64_t u = 0; u < res_unique_; ++u)
+                if (out_slot[u] == -2) out_slot[u] = -1;      // (never left in place: resolved below)
+        } else {
+            for (int64_t u = 0; u < res_unique_; ++u) out_slot[u] = (int32_t)u;
+        }
+        if (n_unique) *n_unique = res_unique_;
+        if (n_slots) *n_slots = used;
+        early_used_ = false;
+        return PBVI_OK;
+    }
+
     int fetch_compact(void* out_rows, int32_t* out_index, int32_t* out_action, int32_t* out_best, uint8_t* out_keep) override {
         if (!have_result_) FAIL(PBVI_EINVAL, "backup_fetch_compact: no backup result resident");
         HIPCHK(hipSetDevice(device_));
@@ -2808,6 +2910,66 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     // of a solve loop) or it has not (the synthetic sets): after a backup that deferred nothing the next one SPECULATES
     // that it will not either -- the later stages are enqueued at once, the counts are read at the end, and if there was
     // deferred work after all it runs then and the later stages are repeated.
+    // Early rows (pbvi_backup_run_fetch): the first maxima and the action values they give decide MOST beliefs' keys for
+    // good -- the refinement re-decides near-ties only -- so the distinct rows of that provisional decision are assembled
+    // and written to the caller's page-locked buffer on the side stream NOW, under the refinement, the action stage and
+    // the dedup (the 8 MB of rows used to cross PCIe after all of them: 0.17 ms of a 3 ms backup).  Afterwards the final
+    // keys are matched against the provisional ones (k_match_rows): rows already on the host keep their slot, the few
+    // that the refinement changed are appended.  Snapshots, because the refinement rewrites best_v / best_score in place.
+    early_used_ = false;
+    if (windows && early_rows_ != nullptr && !use_push && !(flags & PBVI_BELIEF_DOMINANCE) && early_cap_ >= B_ && !no_side) {
+        int rc2;
+        if ((rc2 = e_bv_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc2;
+        if ((rc2 = e_rdot_.ensure((size_t)B_ * A_ * 2 * sizeof(double), &bytes_))) return rc2;
+        if ((rc2 = e_act_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc2;
+        if ((rc2 = e_ares_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc2;
+        if ((rc2 = e_bres_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc2;
+        if ((rc2 = e_rep_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc2;
+        if ((rc2 = e_uniq_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc2;
+        if ((rc2 = e_inv_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc2;
+        if ((rc2 = e_slotd_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc2;
+        if ((rc2 = e_slot_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc2;
+        if ((rc2 = e_cnt_.ensure(4 * sizeof(int), &bytes_))) return rc2;
+        if ((rc2 = e_out_.ensure((size_t)B_ * S_ * sizeof(T), &bytes_))) return rc2;
+        for (hipEvent_t& ev : ev_early_)
+            if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        // The provisional decision itself is 40 us of small kernels: they run HERE, on the main stream in front of the
+        // refinement (which rewrites best_v / best_score in place), and only the copy -- 8 MB over PCIe, ~150 us, few blocks
+        // -- goes to the side stream.  (Snapshots of the three arrays + the whole provisional pipeline beside the
+        // refinement cost it 0.13 ms: a net loss.)
+        HIPCHK(hipMemsetAsync(e_cnt_.p, 0, 4 * sizeof(int), stream_));
+        HIPCHK(launch_action<TS>((int)B_, scorer.view(), sv, sc.rd_col0, sc.tol_rel, sc.chain, best_score_.as<double>(), err_.as<double>(),
+                                 e_rdot_.as<double>(), e_rdot_.as<double>() + (size_t)B_ * A_, e_act_.as<int32_t>(), nullptr, nullptr, stream_,
+                                 io.tol_extra));
+        const int32_t* pa = e_act_.as<int32_t>();
+        const int32_t* pb = e_bv_.as<int32_t>();
+        if (sorted_) {
+            hipLaunchKernelGGL(k_unpermute, dim3((unsigned)B_), dim3(64), 0, stream_, (int)B_, AO, perm_.as<int32_t>(), e_act_.as<int32_t>(),
+                               best_v_.as<int32_t>(), e_ares_.as<int32_t>(), e_bres_.as<int32_t>());
+            HIPCHK(hipGetLastError());
+            pa = e_ares_.as<int32_t>();
+            pb = e_bres_.as<int32_t>();
+        } else {                                             // (one row block: the keys as they are now)
+            HIPCHK(hipMemcpyAsync(e_bv_.p, best_v_.p, (size_t)pairs * sizeof(int32_t), hipMemcpyDeviceToDevice, stream_));
+        }
+        HIPCHK(launch_dedup((int)B_, A_, O_, pa, pb, e_rep_.as<int32_t>(), e_uniq_.as<int32_t>(), e_inv_.as<int32_t>(),
+                            e_slotd_.as<int32_t>(), e_cnt_.as<int>(), stream_));
+        HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, mv, gamma, pa, pb, e_uniq_.as<int32_t>(), e_cnt_.as<int>(), (int)B_,
+                                  e_out_.as<T>(), S_, stream_));
+        HIPCHK(hipEventRecord(ev_early_[0], stream_));
+        hipStream_t es = stream2_;
+        HIPCHK(hipStreamWaitEvent(es, ev_early_[0], 0));
+        // The copy is a plain hipMemcpyAsync on the side stream, sized by the host: it waits (below, once the refinement is
+        // enqueued) for this 4-byte count.  A copy KERNEL storing to the page-locked buffer needs no host and reaches the
+        // link's rate (54.7 GB/s, profiles/microbench/pcie_store.hip) -- but beside it k_refine took 0.24 ms instead of 0.14
+        // whatever its grid (8 .. 1024 blocks): the runtime's copy disturbs the refinement far less (0.15 ms).
+        early_dma_pending_ = true;
+        int* f = pinned_flag();
+        if (!f) FAIL(PBVI_ENOMEM, "run_fetch: pinned flag");
+        HIPCHK(hipMemcpyAsync(f + 8, e_cnt_.p, sizeof(int), hipMemcpyDeviceToHost, es));
+        HIPCHK(hipEventRecord(ev_early_[0], es));
+        early_used_ = true;
+    }
     RefineWork work;
     bool speculate = false;
     if (windows) {
@@ -2841,6 +3003,14 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
                                              best_v_.as<int32_t>(), best_score_.as<double>(), err_.as<double>(), work,
                                              rf_counts_[0], rf_counts_[1], stream_));
         }
+    }
+    if (early_used_ && early_dma_pending_) {   // the refinement is enqueued: now the host can wait for the provisional count
+        HIPCHK(hipEventSynchronize(ev_early_[0]));
+        const int np = h_flag_[8];
+        if (np > 0)
+            HIPCHK(hipMemcpyAsync(early_rows_, e_out_.p, (size_t)np * S_ * sizeof(T), hipMemcpyDeviceToHost, stream2_));
+        HIPCHK(hipEventRecord(ev_early_[1], stream2_));
+        early_dma_pending_ = false;
     }
     HIPCHK(hipEventRecord(ev_[4], stream_));
     const int32_t* perm = sorted_ ? perm_.as<int32_t>() : nullptr;
@@ -2878,6 +3048,19 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         // K3: alpha' rows of the unique keys only
         HIPCHK(launch_assemble<T>(alpha_.as<T>(), S_pad_, mv, gamma, res_action_, res_best_, uniq_.as<int32_t>(), ucount,
                                   (int)B_, out_.as<T>(), S_, stream_));
+        if (early_used_) {   // final keys against the provisional ones whose rows are on their way (or there) already
+            HIPCHK(hipStreamWaitEvent(stream_, ev_early_[1], 0));          // (the provisional count and rows are complete)
+            HIPCHK(hipMemsetAsync(e_cnt_.as<int>() + 1, 0, 2 * sizeof(int), stream_));
+            const int32_t* pa = sorted_ ? e_ares_.as<int32_t>() : e_act_.as<int32_t>();
+            const int32_t* pb = sorted_ ? e_bres_.as<int32_t>() : e_bv_.as<int32_t>();
+            hipLaunchKernelGGL(k_match_rows<T>, dim3((unsigned)std::min<int64_t>(B_, 2048)), dim3(256), 0, stream_, AO, O_, ucount,
+                               uniq_.as<int32_t>(), res_action_, res_best_, e_uniq_.as<int32_t>(), pa, pb, e_cnt_.as<int>(),
+                               (int)early_cap_, e_slot_.as<int32_t>(), out_.as<T>(), (T*)early_rows_, (int64_t)S_);
+            HIPCHK(hipGetLastError());
+            int* f = pinned_flag();
+            if (!f) FAIL(PBVI_ENOMEM, "run_fetch: pinned flag");
+            HIPCHK(hipMemcpyAsync(f + 4, e_cnt_.p, 3 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        }
         HIPCHK(hipEventRecord(ev_[6], stream_));
         if (xr_pending) {                            // the extra rows' maxima read the slabs K5's GEMM is about to overwrite
             HIPCHK(hipStreamWaitEvent(stream_, ev_xr_[1], 0));
@@ -3334,6 +3517,13 @@ int64_t pbvi_backup_unique_count(const pbvi_engine_t* e) { return (e && e->impl)
 int pbvi_backup_fetch_unique(pbvi_engine_t* e, void* out_rows, int32_t* out_index) {
     NEED(e);
     return e->impl->fetch_unique(out_rows, out_index);
+}
+int pbvi_backup_run_fetch(pbvi_engine_t* e, double gamma, int flags, pbvi_stats_t* stats, void* out_rows, int64_t cap_rows,
+                          int32_t* out_slot, int32_t* out_index, int32_t* out_action, int32_t* out_best_alpha, uint8_t* out_keep,
+                          int64_t* n_unique, int64_t* n_slots) {
+    NEED(e);
+    return e->impl->run_fetch(gamma, flags, stats, out_rows, cap_rows, out_slot, out_index, out_action, out_best_alpha, out_keep,
+                              n_unique, n_slots);
 }
 int pbvi_backup_fetch_compact(pbvi_engine_t* e, void* out_rows, int32_t* out_index, int32_t* out_action,
                               int32_t* out_best_alpha, uint8_t* out_keep) {

@@ -33,7 +33,7 @@ EXPORTS = [
     'pbvi_value_max_store', 'pbvi_belief_store_count', 'pbvi_alpha_store_count', 'pbvi_set_value_max_exact', 'pbvi_alpha_layout',
     'pbvi_belief_walk_keys', 'pbvi_backup_fetch_value_max',
     'pbvi_backup_fetch_compact', 'pbvi_host_alloc', 'pbvi_host_free', 'pbvi_debug_gemm_dense',
-    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_exchange_merge', 'pbvi_debug_alloc_limit', 'pbvi_engine_after_oom', 'pbvi_set_f64_screen', 'pbvi_set_fused_projection', 'pbvi_backup_fetch_row_hashes',
+    'pbvi_backup_fetch_exchange_padded', 'pbvi_assemble_rows_store', 'pbvi_exchange_merge', 'pbvi_backup_run_fetch', 'pbvi_debug_alloc_limit', 'pbvi_engine_after_oom', 'pbvi_set_f64_screen', 'pbvi_set_fused_projection', 'pbvi_backup_fetch_row_hashes',
 ]
 
 
@@ -128,6 +128,8 @@ def load_library(path: str = LIB_PATH):
         'pbvi_backup_fetch_exchange': (C.c_int, [vp, vp]),
         'pbvi_backup_fetch_exchange_padded': (C.c_int, [vp, C.c_int64, vp]),
         'pbvi_assemble_rows_store': (C.c_int64, [vp, C.c_double, C.c_int64, vp, vp]),
+        'pbvi_backup_run_fetch': (C.c_int, [vp, C.c_double, C.c_int, sp, vp, C.c_int64, i32p, i32p, i32p, i32p, u8p,
+                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         'pbvi_debug_alloc_limit': (C.c_int64, [C.c_int64]),
         'pbvi_engine_after_oom': (C.c_int, [vp]),
         'pbvi_exchange_merge': (C.c_int64, [vp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64, vp, vp, vp, vp]),
@@ -756,6 +758,28 @@ class Engine:
             best.ctypes.data_as(i32p) if best is not None else None,
             keep.ctypes.data_as(C.POINTER(C.c_uint8)) if keep is not None else None))
         return U
+
+    def run_fetch_into(self, gamma: float, rows: np.ndarray, slot: np.ndarray, index: np.ndarray, actions: np.ndarray,
+                       best=None, keep=None, belief_dominance_prune: bool = False):
+        """``run`` + ``fetch_compact_into`` in one call with the rows leaving early (``pbvi_backup_run_fetch``): ``rows`` must be
+        page-locked (``PinnedBuffer``) with room for B rows; the row of distinct key ``u`` is ``rows[slot[u]]``, and
+        ``alpha'[b] == rows[slot[index[b]]]``.  Returns ``(stats, U, slots_used)``."""
+        if rows.shape[0] < self.B or rows.shape[1] != self.S or rows.dtype != self.np_dtype or not rows.flags.c_contiguous:
+            raise ValueError(f'rows must be a C-contiguous [>= {self.B}, {self.S}] {self.dtype} array')
+        for name, a, shape, dt in (('slot', slot, (self.B,), np.int32), ('index', index, (self.B,), np.int32),
+                                   ('actions', actions, (self.B,), np.int32), ('best', best, (self.B, self.A, self.O), np.int32),
+                                   ('keep', keep, (self.B,), np.uint8)):
+            if a is not None and (a.shape != shape or a.dtype != dt or not a.flags.c_contiguous):
+                raise ValueError(f'{name} must be a C-contiguous {shape} {np.dtype(dt).name} array')
+        i32p = C.POINTER(C.c_int32)
+        st = PbviStats()
+        nu, ns = C.c_int64(0), C.c_int64(0)
+        self._ck(self._lib.pbvi_backup_run_fetch(
+            self._h, float(gamma), PBVI_BELIEF_DOMINANCE if belief_dominance_prune else 0, C.byref(st), _ptr(rows), rows.shape[0],
+            slot.ctypes.data_as(i32p), index.ctypes.data_as(i32p), actions.ctypes.data_as(i32p),
+            best.ctypes.data_as(i32p) if best is not None else None,
+            keep.ctypes.data_as(C.POINTER(C.c_uint8)) if keep is not None else None, C.byref(nu), C.byref(ns)))
+        return st.as_dict(), int(nu.value), int(ns.value)
 
     def fetch_full(self, out=None) -> np.ndarray:
         """Per-belief alpha' matrix [B,S] expanded on the device (``pbvi_backup_fetch``'s out_alpha); ``out``: a

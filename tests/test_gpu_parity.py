@@ -1765,3 +1765,52 @@ def test_fused_engine_holds_only_the_projected_tiles_of_gamma():
         assert held_plain - held_fused > 0.9 * (full - 256 * 30016 * 4), (held_fused, held_plain, full)
     assert np.array_equal(fused.best_alpha_ind, plain.best_alpha_ind) and np.array_equal(fused.alpha, plain.alpha)
     eng.close()
+
+
+@pytest.mark.parametrize('case', ['olfactory_f32', 'olfactory_f64', 'ties_f32', 'prune_f32'])
+def test_run_fetch_with_early_rows_equals_run_then_fetch(case):
+    """``pbvi_backup_run_fetch``: the rows of the provisional decision (first maxima of the fp32 scores) leave for the host
+    while the refinement runs; final keys are matched against them and only changed rows are appended.  Whatever the
+    refinement overturns, the result read through ``slot`` is the plain ``run`` + ``fetch_compact`` result bit for bit:
+    the small olfactory fixture (fp32 and screened fp64), an alpha set of near-duplicates in which the refinement
+    overturns many first maxima, and the belief-dominance call (where the early path steps aside)."""
+    from pomdp_pbvi_exploration_amd.engine import PinnedBuffer
+    z, rs, rto, er = small(1)
+    S, A, O = 600, 6, 3
+    dtype = 'f64' if case.endswith('f64') else 'f32'
+    alpha, beliefs = z['alpha'].astype(np.float64), np.tile(z['beliefs'].astype(np.float64), (5, 1))      # 320 beliefs: sorted blocks
+    if case == 'ties_f32':
+        rng = np.random.default_rng(4)
+        base = alpha[:6]
+        alpha = (np.repeat(base, 40, axis=0) * (1.0 + 3e-7 * rng.standard_normal((240, 1)))).astype(np.float32).astype(np.float64)
+    eng = Engine(S, A, O, 1, rs, rto, er, dtype=dtype)
+    if dtype == 'f64':
+        eng.set_f64_screen('always')
+    eng.set_formulation('alpha')
+    eng.set_alpha(alpha)
+    eng.set_beliefs(beliefs)
+    B = beliefs.shape[0]
+    prune = case == 'prune_f32'
+    st = eng.run(float(z['gamma']), prune)
+    want = eng.fetch()
+    item = 4 if dtype == 'f32' else 8
+    buf = PinnedBuffer(B * S * item + 4 * B * 4 + B * A * O * 4 + B + 8192)
+    rows = buf.carve((B, S), eng.np_dtype)
+    slot, index, actions = (buf.carve((B,), np.int32) for _ in range(3))
+    best = buf.carve((B, A, O), np.int32)
+    keep = buf.carve((B,), np.uint8)
+    for _ in range(2):                                       # twice: the second call re-uses every buffer of the first
+        rows[:] = np.nan
+        st2, U, used = eng.run_fetch_into(float(z['gamma']), rows, slot, index, actions, best=best, keep=keep,
+                                          belief_dominance_prune=prune)
+        assert U == want.unique_alpha.shape[0] and used >= U
+        assert np.array_equal(index, want.index) and np.array_equal(actions, want.actions)
+        assert np.array_equal(best, want.best_alpha_ind) and np.array_equal(keep.astype(bool), want.keep.astype(bool))
+        assert np.all((slot[:U] >= 0) & (slot[:U] < used)) and len(set(slot[:U].tolist())) == U
+        assert np.array_equal(np.asarray(rows)[slot[:U]], want.unique_alpha)
+        assert st2['n_refined'] == st['n_refined']
+    if case == 'ties_f32':
+        assert st['n_refined'] > 100                         # the refinement had work: keys were overturned
+    del rows, slot, index, actions, best, keep
+    buf.close()
+    eng.close()
