@@ -133,6 +133,7 @@ struct RefineWork {
     int32_t* ib_idx = nullptr;           // [slot_cap] (0x7fffffff = none)
     int* cnt = nullptr;                  // [2] items reserved, slots reserved
     int item_cap = 0, slot_cap = 0;
+    int defer_min = 8;                   // more candidates than this in a 256-column chunk go to the grid-wide passes
     size_t zero_bytes = 0;               // cnt, emax, eidx are one allocation starting at cnt: bytes to clear per launch
     // Slots below w_slot_cap take the GEMM path instead of items: the entry's fp64 weight row (the belief pushed
     // through (a, o), or the belief itself) against ALL alpha rows on the fp64 MFMA GEMM, then a first-max.

@@ -880,7 +880,7 @@ __global__ void k_refine(SlabView<TS> sv, int V, int G, const int32_t* __restric
         if (tid == 0 && cand_total != nullptr && ncand > 0) atomicAdd(cand_total, ncand);
         // Many candidates: one block scoring them four at a time is a long latency chain (tens of microseconds per
         // candidate on a wide belief); hand them to the grid-wide pass instead.
-        if (work.items_v != nullptr && !loverflow && (slot >= 0 || ncand > REFINE_DEFER_MIN)) {
+        if (work.items_v != nullptr && !loverflow && (slot >= 0 || ncand > work.defer_min)) {
             if (tid == 0) {
                 int sl = slot;
                 if (sl < 0) {

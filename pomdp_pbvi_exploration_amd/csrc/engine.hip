@@ -2222,6 +2222,7 @@ class EngineT : public EngineBase {
         // GEMM path of the tie-heavy entries: fp64 weight rows for as many slots as ~2 GiB holds
         int64_t w_slots = std::min<int64_t>(std::min<int64_t>(slots, 65535),                       // grid.y of the weights kernel
                                             ((int64_t)2 << 30) / ((int64_t)S_pad_ * sizeof(double)));
+        if (const char* c = getenv("PBVI_REFINE_DEFER_MIN")) w->defer_min = atoi(c);                 // A/B: -1 = every candidate to the grid-wide pass
         if (const char* c = getenv("PBVI_REFINE_W_SLOTS")) w_slots = std::min<int64_t>(slots, std::max<int64_t>(0, atoll(c)));   // tests
         if (w_slots > 0) {
             if ((rc = build_inverse_lists())) return rc;
