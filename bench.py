@@ -241,6 +241,12 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N')
+    # PBVI_DIST_BACKEND=gloo: a rehearsal of the sharded step with several ranks on ONE GPU (RCCL refuses two ranks on one
+    # device): every rank's engine lives on device 0 and the exchange travels through host tensors -- the per-rank backup
+    # times then share the card and mean nothing, the exchange / merge / append split is the product path's.
+    backend = os.environ.get('PBVI_DIST_BACKEND', 'nccl')
+    if backend == 'gloo' and torch.cuda.device_count() < world:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     distributed = world > 1 or os.environ.get('PBVI_FORCE_DIST') == '1'   # the latter: rehearse the RCCL path on one GPU
     dist = None
@@ -248,7 +254,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         with stdout_to_stderr():
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            if backend == 'gloo':
+                dist.init_process_group('gloo')
+            else:
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
             dist.barrier()                                          # brings the communicator (and its banner) up now
 
     from pomdp_pbvi_exploration_amd import synth
@@ -284,7 +293,7 @@ def main():
             block_ids.append(np.arange(first, first + B, dtype=np.int32))
             del rows
     eng.set_beliefs(beliefs)
-    shard = EngineShard(eng, m.gamma)
+    shard = EngineShard(eng, m.gamma, carrier=torch.device('cpu') if (distributed and backend == 'gloo') else None)
     host = HostResults(eng, B)
     exchange_rows = os.environ.get('PBVI_EXCHANGE') == 'rows'       # A-B only: move alpha' rows instead of keys
 
@@ -321,7 +330,7 @@ def main():
 
     per_step, elapsed, stats = timed_steps(step, args.steps, args.warmup, fence)
     if distributed:
-        t = torch.tensor(np.concatenate([[elapsed], per_step]), dtype=torch.float64, device='cuda')
+        t = torch.tensor(np.concatenate([[elapsed], per_step]), dtype=torch.float64, device='cpu' if backend == 'gloo' else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # slowest rank, step by step and over the region
         elapsed, per_step = float(t[0].item()), t[1:].cpu().numpy()
 
