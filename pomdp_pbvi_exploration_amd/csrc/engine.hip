@@ -721,6 +721,11 @@ class EngineT : public EngineBase {
     void* early_rows_ = nullptr;
     int64_t early_cap_ = 0;
     bool early_used_ = false, early_dma_pending_ = false;
+    struct RunFetchDst {                                     // run_fetch: the small per-belief results travel with the pipeline's
+        int32_t *slot = nullptr, *index = nullptr, *action = nullptr, *best = nullptr;   // last read-back, not behind a second
+        uint8_t* keep = nullptr;                                                         // synchronisation
+        bool queued = false;
+    } rf_dst_;
     DevBuf e_bv_, e_bs_, e_err_, e_rdot_, e_act_, e_ares_, e_bres_, e_rep_, e_uniq_, e_inv_, e_slotd_, e_cnt_, e_out_, e_slot_;
     hipEvent_t ev_early_[2] = {nullptr, nullptr};
     hipEvent_t ev_ids_ = nullptr;
@@ -1770,32 +1775,34 @@ class EngineT : public EngineBase {
         if (!is_pinned_host_pointer(out_rows)) FAIL(PBVI_EINVAL, "backup_run_fetch: out_rows must be page-locked host memory (pbvi_host_alloc)");
         early_rows_ = out_rows;
         early_cap_ = cap_rows;
+        rf_dst_ = RunFetchDst{out_slot, out_index, out_action, out_best, out_keep, false};
         int rc = backup_run(gamma, flags, st);
         early_rows_ = nullptr;
+        const bool queued = rf_dst_.queued;
+        rf_dst_ = RunFetchDst{};
         if (rc) return rc;
         const size_t B = (size_t)res_B_;
-        bool slots_done = false;
         int64_t used = res_unique_;
-        if (early_used_ && h_flag_ && !h_flag_[6]) {         // rows are in place; slots from the device
-            used = (int64_t)h_flag_[4] + h_flag_[5];
-            if ((rc = out_begin())) return rc;
-            if ((rc = out_add(out_slot, e_slot_.p, (size_t)res_unique_ * sizeof(int32_t)))) return rc;
-            slots_done = true;
-        } else {                                             // not applicable (or the slots overflowed): the plain order
+        const bool early_ok = early_used_ && h_flag_ && !h_flag_[6];
+        if (early_ok) used = (int64_t)h_flag_[4] + h_flag_[5];
+        if (queued) {                                        // the small arrays came with the pipeline's last read-back
+            if ((rc = out_flush())) return rc;               // (host-side copies of staged items; the stream is idle)
+            if (!early_ok) {                                 // the slots overflowed: rows in the plain order
+                if ((rc = out_begin())) return rc;
+                if ((rc = out_add(out_rows, out_.p, (size_t)res_unique_ * S_ * sizeof(T)))) return rc;
+                if ((rc = out_finish())) return rc;
+            }
+        } else {                                             // the early path did not apply: everything now
             if ((rc = out_begin())) return rc;
             if ((rc = out_add(out_rows, out_.p, (size_t)res_unique_ * S_ * sizeof(T)))) return rc;
+            if ((rc = out_add(out_index, inv_.p, B * sizeof(int32_t)))) return rc;
+            if ((rc = out_add(out_action, res_action_, B * sizeof(int32_t)))) return rc;
+            if (out_best && (rc = out_add(out_best, res_best_, B * A_ * O_ * sizeof(int32_t)))) return rc;
+            if (out_keep && (rc = out_add(out_keep, keep_.p, B))) return rc;
+            if ((rc = out_finish())) return rc;
         }
-        if ((rc = out_add(out_index, inv_.p, B * sizeof(int32_t)))) return rc;
-        if ((rc = out_add(out_action, res_action_, B * sizeof(int32_t)))) return rc;
-        if (out_best && (rc = out_add(out_best, res_best_, B * A_ * O_ * sizeof(int32_t)))) return rc;
-        if (out_keep && (rc = out_add(out_keep, keep_.p, B))) return rc;
-        if ((rc = out_finish())) return rc;
-        if (slots_done) {
-            for (int64_t u = 0; u < res_unique_; ++u)
-                if (out_slot[u] == -2) out_slot[u] = -1;      // (never left in place: resolved below)
-        } else {
+        if (!early_ok)
             for (int64_t u = 0; u < res_unique_; ++u) out_slot[u] = (int32_t)u;
-        }
         if (n_unique) *n_unique = res_unique_;
         if (n_slots) *n_slots = used;
         early_used_ = false;
@@ -3075,6 +3082,18 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
                                   perm, keep_.as<uint8_t>(), stream_));
         } else {
             HIPCHK(hipMemsetAsync(keep_.p, 1, (size_t)B_, stream_));
+        }
+        rf_dst_.queued = false;
+        if (early_used_ && rf_dst_.slot != nullptr) {        // run_fetch: slots, index, actions (best, keep) with this read-back
+            int rc2;
+            if ((rc2 = out_begin())) return rc2;
+            out_used_ = 256;                                 // (the first bytes of the staging buffer hold the refinement's counts)
+            if ((rc2 = out_add(rf_dst_.slot, e_slot_.p, (size_t)B_ * sizeof(int32_t)))) return rc2;
+            if ((rc2 = out_add(rf_dst_.index, inv_.p, (size_t)B_ * sizeof(int32_t)))) return rc2;
+            if ((rc2 = out_add(rf_dst_.action, res_action_, (size_t)B_ * sizeof(int32_t)))) return rc2;
+            if (rf_dst_.best && (rc2 = out_add(rf_dst_.best, res_best_, (size_t)pairs * sizeof(int32_t)))) return rc2;
+            if (rf_dst_.keep && (rc2 = out_add(rf_dst_.keep, keep_.p, (size_t)B_))) return rc2;
+            rf_dst_.queued = true;
         }
         HIPCHK(hipMemcpyAsync(h_cnt, counters_.p, sizeof(h_cnt), hipMemcpyDeviceToHost, stream_));
         if constexpr (screened) {   // did an alpha value leave the fp32 range when the screen's copy was made?
