@@ -2,7 +2,11 @@
 
 Run in the build container only (needs /root/reference, which never travels):
 
-    MPLBACKEND=Agg python tests/golden/make_golden.py [small] [kat] [c2] [full]
+    MPLBACKEND=Agg python tests/golden/make_golden.py [small] [kat] [c2] [full] [full_r5] [c5] [sim] [models] [solve] [e2e]
+                                                      [hsvi] [prune] [limiter]
+
+(`full_r5`: the R = 5 variant at V = B = 1024, the size bench.py's secondary.c4_r5 runs at -- the reference's backup needs
+~30 GB and 173 s for it here.)
 
 It imports ``/root/reference/src/pomdp.py`` (NumPy path; CuPy is absent), feeds it
 inputs produced by this repo's own deterministic generator
