@@ -121,6 +121,59 @@ __device__ __forceinline__ void gamma_dots4(const T* __restrict__ brow, const fl
     for (int c = 0; c < 4; ++c) out[c] = ((sh[c] + sh[4 + c]) + sh[8 + c]) + sh[12 + c];
 }
 
+// Exact (fp64) scores of up to 4 candidates of ONE entry in one pass over its tile list: the belief, the weights and the
+// successor indices are read once and the four alpha gathers of a state are in flight together (one block-wide pass per
+// candidate was two dependent latency chains of ~20 us for the usual two candidates).  The same products and the same
+// b * (gamma * g) association as proj_dot_partial; identical candidate rows give identical sums, so exact ties still go to
+// the lower index.  blockDim.x = 256; every thread gets the 4 sums.
+template <typename T, bool PROJ>
+__device__ __forceinline__ void exact_dots4(const T* __restrict__ brow, const T* const (&arow)[4], int nc /* candidates in use */,
+                                            const ModelView<T>& mv, int a, int o, double gamma, TileList tl, double (&out)[4],
+                                            double* sh /* >= 16 doubles */) {
+    const int32_t* __restrict__ rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
+    const T* __restrict__ rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
+    const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = q; i0 < tl.count; i0 += 16) {            // two list entries per half-wave in flight
+        const int i1 = i0 + 8;
+        const bool ok1 = i1 < tl.count;
+        const int s0 = tl.at(i0) * 32 + l, s1 = tl.at(ok1 ? i1 : i0) * 32 + l;
+        const double b0 = (double)brow[s0], b1 = ok1 ? (double)brow[s1] : 0.0;
+        if constexpr (PROJ) {
+            double g0[4] = {0.0, 0.0, 0.0, 0.0}, g1[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int r = 0; r < mv.R; ++r) {
+                const int64_t ro = (int64_t)r * mv.S_pad;
+                const double w0 = (double)rto[ro + s0], w1 = (double)rto[ro + s1];
+                const int t0 = rs[ro + s0], t1 = rs[ro + s1];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < nc) {                            // block-uniform: no gathers for unused candidate slots
+                        g0[c] += w0 * (double)arow[c][t0];
+                        g1[c] += w1 * (double)arow[c][t1];
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += b0 * (gamma * g0[c]) + b1 * (gamma * g1[c]);
+        } else {
+            const bool in0 = s0 < mv.S, in1 = s1 < mv.S;   // alpha rows are valid for s < S only
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nc) acc[c] += (in0 ? b0 * (double)arow[c][s0] : 0.0) + (in1 ? b1 * (double)arow[c][s1] : 0.0);
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = wave_sum(acc[c]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sh[wid * 4 + c] = acc[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = ((sh[c] + sh[4 + c]) + sh[8 + c]) + sh[12 + c];
+}
+
 // ------------------------------------------------------------------------- //
 // support mask of RTO (engine creation)
 // ------------------------------------------------------------------------- //
@@ -704,7 +757,7 @@ __device__ __forceinline__ double refine_wave_dot(const T* __restrict__ brow, co
     return wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
 }
 
-template <typename T, typename TS, bool PROJ>
+template <typename T, typename TS, bool PROJ, bool L1 /* level-1 screen over projected rows (work.gam); else candidates together */>
 __global__ void k_refine(SlabView<TS> sv, int V, int G, const int32_t* __restrict__ queue,
                          const int* __restrict__ qcount,
                          const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda,
@@ -798,71 +851,103 @@ __global__ void k_refine(SlabView<TS> sv, int V, int G, const int32_t* __restric
             }
         }
     };
-    bool settled = false;                                    // the level-1 screen took the entry (block-uniform)
-    if constexpr (PROJ && sizeof(T) == 4) {
-        if (work.gam != nullptr && !loverflow) {          // (an overflowed list names tiles nobody projected)
-            // -- collect the entry's candidates over all chunks of V (ascending v); more than L1_CAP: the paths below
-            constexpr int L1_CAP = 32;
-            __shared__ int c1[L1_CAP];
-            __shared__ double s1[L1_CAP];
-            __shared__ double l1red[16];
-            __shared__ int n1_sh, n2_sh;
-            if (tid == 0) n1_sh = 0;
+    bool settled = false;                                    // decided before the chunk loop below (block-uniform)
+    if (!loverflow) {                                        // (an overflowed list names tiles nobody projected)
+        // -- collect the entry's candidates over all chunks of V (ascending v); more than L1_CAP: the chunk loop below
+        constexpr int L1_CAP = 32;
+        constexpr int FAST_CAP = 8;                          // candidates scored together, four per pass
+        __shared__ int c1[L1_CAP];
+        __shared__ double s1[L1_CAP];
+        __shared__ double l1red[16];
+        __shared__ int n1_sh, n2_sh;
+        if (tid == 0) n1_sh = 0;
+        __syncthreads();
+        for (int v0 = 0; v0 < V; v0 += 256) {
+            const int v = v0 + tid;
+            int flag = 0;
+            if (v < V) flag = ((double)sv.score(b, g, V, v) >= thr) ? 1 : 0;
+            const unsigned long long mask = __ballot(flag);
+            if (lane == 0) wcount[wid] = __popcll(mask);
             __syncthreads();
-            for (int v0 = 0; v0 < V; v0 += 256) {
-                const int v = v0 + tid;
-                int flag = 0;
-                if (v < V) flag = ((double)sv.score(b, g, V, v) >= thr) ? 1 : 0;
-                const unsigned long long mask = __ballot(flag);
-                if (lane == 0) wcount[wid] = __popcll(mask);
-                __syncthreads();
-                int base = n1_sh;
-                for (int w = 0; w < wid; ++w) base += wcount[w];
-                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-                if (flag && pos < L1_CAP) c1[pos] = v;
-                __syncthreads();
-                if (tid == 0) n1_sh += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-                __syncthreads();
-            }
-            const int n1 = n1_sh;
-            if (n1 <= L1_CAP && n1 > 0) {
-                if (tid == 0 && cand_total != nullptr) atomicAdd(cand_total, n1);
-                const TileList tl{L, n_tiles};
-                for (int c0 = 0; c0 < n1; c0 += 4) {
-                    const float* rows[4];
+            int base = n1_sh;
+            for (int w = 0; w < wid; ++w) base += wcount[w];
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (flag && pos < L1_CAP) c1[pos] = v;
+            __syncthreads();
+            if (tid == 0) n1_sh += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+            __syncthreads();
+        }
+        const int n1 = n1_sh;
+        constexpr bool l1 = L1 && PROJ && sizeof(T) == 4;   // (two instantiations: each carries one of the two paths only)
+        if (n1 > 0 && n1 <= L1_CAP && (l1 || n1 <= FAST_CAP)) {
+            if (tid == 0 && cand_total != nullptr) atomicAdd(cand_total, n1);
+            const TileList tl{L, n_tiles};
+            int n2 = n1;
+            if constexpr (l1) {
+                {   // level 1: fp64 sums over the projected fp32 rows the GEMM read (RefineWork::gam)
+                    for (int c0 = 0; c0 < n1; c0 += 4) {
+                        const float* rows[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        rows[j] = work.gam + ((int64_t)g * V + c1[c0 + j < n1 ? c0 + j : c0]) * work.ldg;
-                    double d[4];
-                    gamma_dots4<T>(brow, rows, tl, d, l1red);
-                    if (tid == 0)
-                        for (int j = 0; j < 4 && c0 + j < n1; ++j) s1[c0 + j] = d[j];
-                }
-                __syncthreads();
-                const double mag = fmax(fabs(m), fabs(sv.magnitude(b, g, G, V)));
-                const double E2 = work.l1_rel * mag;
-                if (tid == 0) {
-                    double m1 = s1[0];
-                    for (int c = 1; c < n1; ++c) m1 = s1[c] > m1 ? s1[c] : m1;
-                    int n2 = 0, keep1 = 0;
-                    for (int c = 0; c < n1; ++c)
-                        if (s1[c] >= m1 - 2.0 * E2) {
-                            cand[n2++] = c1[c];
-                            keep1 = c;
-                        }
-                    n2_sh = n2;
-                    if (n2 == 1) {                           // separated: the exact maximum is this one (within E2 of s1)
-                        best_v[e] = c1[keep1];
-                        best_score[e] = s1[keep1];
-                        err[e] = E2;
+                        for (int j = 0; j < 4; ++j)
+                            rows[j] = work.gam + ((int64_t)g * V + c1[c0 + j < n1 ? c0 + j : c0]) * work.ldg;
+                        double d[4];
+                        gamma_dots4<T>(brow, rows, tl, d, l1red);
+                        if (tid == 0)
+                            for (int j = 0; j < 4 && c0 + j < n1; ++j) s1[c0 + j] = d[j];
                     }
+                    __syncthreads();
+                    const double mag = fmax(fabs(m), fabs(sv.magnitude(b, g, G, V)));
+                    const double E2 = work.l1_rel * mag;
+                    if (tid == 0) {
+                        double m1 = s1[0];
+                        for (int c = 1; c < n1; ++c) m1 = s1[c] > m1 ? s1[c] : m1;
+                        int k = 0, keep1 = 0;
+                        for (int c = 0; c < n1; ++c)
+                            if (s1[c] >= m1 - 2.0 * E2) {
+                                keep1 = c;
+                                c1[k++] = c1[c];             // survivors, still ascending (k <= c)
+                            }
+                        n2_sh = k;
+                        if (k == 1) {                        // separated: the exact maximum is this one (within E2 of s1)
+                            best_v[e] = c1[0];
+                            best_score[e] = s1[keep1];
+                            err[e] = E2;
+                        }
+                    }
+                    __syncthreads();
+                    n2 = n2_sh;
+                    if (n2 == 1) return;
+                }
+            }
+            if constexpr (!l1) {    // exact scores of all of them together, four per pass; first maximum
+                for (int c0 = 0; c0 < n2; c0 += 4) {
+                    const T* rows[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rows[j] = alpha + (int64_t)c1[c0 + j < n2 ? c0 + j : c0] * lda;
+                    double d[4];
+                    exact_dots4<T, PROJ>(brow, rows, n2 - c0 < 4 ? n2 - c0 : 4, mv, a, o, gamma, tl, d, l1red);
+                    if (tid == 0)
+                        for (int j = 0; j < 4 && c0 + j < n2; ++j) s1[c0 + j] = d[j];
                 }
                 __syncthreads();
-                const int n2 = n2_sh;
-                if (n2 == 1) return;
-                score_exact(n2);                             // what the projected rows cannot separate: from the operands
-                settled = true;
+                if (tid == 0) {
+                    double bv = s1[0];
+                    int bi = c1[0];
+                    for (int c = 1; c < n2; ++c)
+                        if (s1[c] > bv) {
+                            bv = s1[c];
+                            bi = c1[c];
+                        }
+                    best_v[e] = bi;
+                    best_score[e] = bv;
+                    err[e] = 0.0;
+                }
+                return;
             }
+            for (int c = tid; c < n2; c += 256) cand[c] = c1[c];
+            __syncthreads();
+            score_exact(n2);                                 // more than that (after level 1): one candidate per wave
+            settled = true;
         }
     }
     for (int v0 = 0; v0 < V && !settled; v0 += 256) {
@@ -1106,10 +1191,16 @@ hipError_t launch_refine_scan(bool proj, SlabView<TS> sv, int V, int G, int max_
         if ((e = hipMemsetAsync(work.cnt, 0, work.zero_bytes, st)) != hipSuccess) return e;
     }
     if (proj)
-        hipLaunchKernelGGL((k_refine<T, TS, true>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,
-                           alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
+    {
+        if (work.gam != nullptr && sizeof(T) == 4)
+            hipLaunchKernelGGL((k_refine<T, TS, true, true>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,
+                               alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
+        else
+            hipLaunchKernelGGL((k_refine<T, TS, true, false>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,
+                               alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
+    }
     else
-        hipLaunchKernelGGL((k_refine<T, TS, false>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel,
+        hipLaunchKernelGGL((k_refine<T, TS, false, false>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel,
                            ldb, alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (work.items_v != nullptr && counts_host != nullptr)
