@@ -714,7 +714,6 @@ hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dea
 //     per candidate).
 // ------------------------------------------------------------------------- //
 constexpr int REFINE_LIST_CAP = 2048;   // tiles kept in LDS (65536 states of support); longer lists stay global
-constexpr int REFINE_DEFER_MIN = 8;     // more candidates than this in a 256-column chunk go to the grid-wide pass
 
 // exact score of one candidate over a tile list, computed by one wave (all lanes get the sum)
 template <typename T, bool PROJ>

@@ -136,6 +136,19 @@ struct DevBuf {
         return v;
     }
     static bool over_limit(int64_t held, size_t want) { return limit_bytes() >= 0 && held + (int64_t)want > limit_bytes(); }
+    // Growth headroom (below) is for engines with memory to spare: under a cap only while the engine stays below 3/4 of it,
+    // on the device only while four times the request is free -- an early buffer's spare half must not be what a later
+    // buffer of the same call lacks.
+    static bool headroom_ok(int64_t held, size_t want) {
+        if (limit_bytes() >= 0) return held + (int64_t)want <= limit_bytes() / 4 * 3;
+        if (want < ((size_t)256 << 20)) return true;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return fr / 4 >= want;
+    }
     // grow-only; contents are NOT preserved on growth.  A buffer that grows again doubles (25 % if that fails): in a solve
     // loop the alpha set gains a few rows per backup, and re-allocating a multi-GB buffer (hipFree + hipMalloc,
     // both synchronising, hundreds of ms at 20 GB) on every call would dwarf the backup itself.
@@ -150,7 +163,7 @@ struct DevBuf {
         }
         if (regrow) {
             for (const size_t want : {bytes * 2, bytes + bytes / 4}) {     // HBM is plentiful; re-allocations are not
-                if (over_limit(*total, want)) continue;
+                if (!headroom_ok(*total, want)) continue;
                 if (hipMalloc(&p, want) == hipSuccess) {
                     cap = want;
                     *total += (int64_t)want;
@@ -650,6 +663,16 @@ class EngineT : public EngineBase {
     hipStream_t stream_ = nullptr;
     int S_ = 0, A_ = 0, O_ = 0, R_ = 0, S_pad_ = 0, mode_ = 0;
     int64_t bytes_ = 0;
+    // bytes this engine may still allocate: what its cap leaves, or what the device reports free
+    int64_t room() const {
+        if (DevBuf::limit_bytes() >= 0) return DevBuf::limit_bytes() - bytes_;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+            (void)hipGetLastError();
+            return INT64_MAX;
+        }
+        return (int64_t)fr;
+    }
     double tie_rel_user_ = -1.0;
 
     DevBuf rs_, rto_, er_, sup_;
@@ -2499,7 +2522,29 @@ bool EngineT<T>::choose_push(int64_t N) const {
         return tiles * S_pad_ * (2.0 * bm * bm / rate) + (double)proj_rows * S_pad_ * sizeof(T) / proj_rate;
     };
     const double c_pull = cost(B_, N, N, 6e12), c_push = cost(B_ * AO, V_, B_ * AO, 1e12);
-    return formulation_ == 2 || (formulation_ == 0 && c_push < 0.8 * c_pull);
+    if (formulation_ != 0) return formulation_ == 2;
+    // Memory before speed: Gamma[A,O,V,S] is what the reference's CuPy path dies allocating (Sea_Robin_Real.ipynb:913,
+    // 21.95 GB at |V| = 1386).  Where this engine would have to hold all of it (no fused generation: R > 1, fp64 scoring)
+    // and it does not fit beside what the engine already holds while the projected beliefs do, the belief side is taken
+    // whatever the cost model says -- its footprint grows with B, which the caller can cut (PBVI_Solver.backup halves the
+    // belief block on MemoryError), not with V.
+    const bool gamma_compact = kF32 && R_ == 1 && fuse_project_ >= 1 && irr_.p != nullptr;
+    const int64_t row = (int64_t)S_pad_ * (int64_t)sizeof(T);
+    const int64_t n_pull = kF32 ? round_up(N, GEMM_BN) : N, m_push = round_up((int64_t)B_ * AO + B_, GEMM_BM);
+    const int64_t gam_new = gamma_compact ? 0 : std::max<int64_t>(0, n_pull * row - (int64_t)gam_.cap);
+    if (gam_new > ((int64_t)1 << 28)) {
+        // the score slabs count too: [rows][columns] partial sums, one slab per K part (stream-K: up to 9)
+        auto slabs = [&](int64_t m, int64_t n) {
+            if constexpr (kF32) return (int64_t)make_gemm_plan((int)round_up(m, GEMM_BM), (int)round_up(n, GEMM_BN), S_pad_).max_chunks *
+                                       round_up(m, GEMM_BM) * round_up(n, GEMM_BN) * 4;
+            else return (int64_t)gemm_f64_split((int)m, (int)n, S_pad_ / GEMM_BK) * m * n * 8;
+        };
+        const int64_t pull = gam_new + std::max<int64_t>(0, slabs(B_, N) - (int64_t)slabs_.cap);
+        const int64_t push = std::max<int64_t>(0, m_push * row - (int64_t)bp_.cap) +
+                             std::max<int64_t>(0, slabs((int64_t)B_ * AO + B_, V_) - (int64_t)slabs_.cap);
+        if (push < pull && pull > room()) return true;
+    }
+    return c_push < 0.8 * c_pull;
 }
 
 // K1 + K2 + first-max: projection, score GEMM and the argmax over alpha-vectors with near-tie detection, of THIS

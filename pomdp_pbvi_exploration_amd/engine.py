@@ -399,6 +399,8 @@ class Engine:
             Engine._nonce = (os.getpid(), secrets.randbits(48))
         self.serial = Engine._nonce + (next(Engine._serials),)
         self._alpha_token = None
+        self._formulation = None                # see the property
+        self.last_stats = {}                    # pbvi_stats_t of the last run()
         self._store_epoch = {'alpha': 0, 'belief': 0}
         self._resident = {'alpha': None, 'belief': None}     # store ids of the working alpha set / belief block
         self.B = 0
@@ -720,7 +722,8 @@ class Engine:
         st = PbviStats()
         self._ck(self._lib.pbvi_backup_run(self._h, float(gamma), PBVI_BELIEF_DOMINANCE if belief_dominance_prune else 0,
                                          C.byref(st)))
-        return st.as_dict()
+        self.last_stats = st.as_dict()
+        return self.last_stats
 
     def fetch(self) -> BackupResult:
         """Results of the last run: unique alpha' rows + per-belief index (the D2H copy moves U rows, not B)."""
@@ -1000,6 +1003,15 @@ class Engine:
         """Operand projected through the model: ``'auto'``, ``'alpha'`` (Gamma, the reference's order) or
         ``'belief'`` (beliefs pushed through every (a, o); cheaper when B << V)."""
         self._ck(self._lib.pbvi_set_formulation(self._h, {'auto': 0, 'alpha': 1, 'belief': 2}[which]))
+        self._formulation = which
+
+    @property
+    def formulation(self) -> str:
+        """The setting ``set_formulation`` last made (initially ``PBVI_FORMULATION`` or ``'auto'``, as the engine reads it)."""
+        if self._formulation is None:
+            env = os.environ.get('PBVI_FORMULATION', '')
+            self._formulation = {'alpha': 'alpha', '1': 'alpha', 'belief': 'belief', '2': 'belief'}.get(env, 'auto')
+        return self._formulation
 
     def set_fused_projection(self, enable=True) -> None:
         """fp32 scoring: Gamma tiles generated inside the score GEMM (``True``: where that is faster, i.e. R = 1; default) or

@@ -450,37 +450,17 @@ class PBVI_Solver(Solver):
             # working sets are selected by id in list order (tie-breaks follow the host order), the device
             # runs the backup, and only the distinct new rows come back.
             eng = value_function.model.engine
-            eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values, owner=value_function)
             beliefs = belief_set.belief_list
-            if len(beliefs) <= self.BELIEF_BLOCK:
-                eng.sync_rows('belief', beliefs, lambda b: b.values, owner=belief_set)
-                stats = eng.run(self.gamma, belief_dominance_prune)
-                if stats['formulation'] == 2:
-                    # belief-side GEMM: it also multiplied the beliefs themselves by the alpha set; compute_change asks for
-                    # exactly those maxima next (these beliefs, the value function that was just backed up)
-                    eng.seed_max_values(value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda b: b.values,
-                                        alpha_owner=value_function, belief_owner=belief_set)
-                alpha_new, actions, uidx = eng.fetch().value_function_rows(use_keep=belief_dominance_prune, with_index=True)
-                if len(uidx):
-                    # the new rows join the engine's alpha store device to device: the next call selects them by id;
-                    # their dedup hashes come from the device too (ValueFunction keys its dictionary on them)
-                    first, tag = eng.store_unique(uidx), eng.store_tag('alpha')
-                    hashes = eng.fetch_row_hashes()[uidx]
-                    vectors = []
-                    for k, (row, act) in enumerate(zip(alpha_new, actions)):
-                        v = AlphaVector(row, act)
-                        v._dev = (tag, first + k)
-                        v._hash = int(hashes[k])
-                        vectors.append(v)
-                    alpha_new = vectors
-            else:   # beliefs are independent: larger sets go through the engine in blocks (it takes 65535 at a time)
-                parts = []
-                for i0 in range(0, len(beliefs), self.BELIEF_BLOCK):
-                    eng.sync_rows('belief', beliefs[i0:i0 + self.BELIEF_BLOCK], lambda b: b.values)
-                    eng.run(self.gamma, belief_dominance_prune)
-                    parts.append(eng.fetch().value_function_rows(use_keep=belief_dominance_prune))
-                alpha_new = np.concatenate([p[0] for p in parts])
-                actions = np.concatenate([p[1] for p in parts])
+            try:
+                if self._belief_chunk is not None and len(beliefs) > self._belief_chunk:
+                    raise MemoryError('an earlier backup of this solver only fitted in belief chunks')
+                alpha_new, actions = self._backup_block(eng, value_function, belief_set, beliefs, belief_dominance_prune)
+            except MemoryError as e:
+                if len(beliefs) < 2:
+                    raise
+                if self._belief_chunk is None:
+                    log(f'[Warning] Backup of {len(beliefs)} beliefs does not fit the device ({e}); continuing in belief chunks...')
+                alpha_new, actions = self._backup_in_chunks(eng, value_function, beliefs, belief_dominance_prune)
             new_vf = (ValueFunction(value_function.model, alpha_new) if isinstance(alpha_new, list)
                       else ValueFunction(value_function.model, alpha_new, actions))
         else:
@@ -490,6 +470,73 @@ class PBVI_Solver(Solver):
         if append:
             new_vf.extend(value_function)
         return new_vf
+
+    _belief_chunk = None      # set once a block only fitted the device in pieces: later backups start there
+
+    def _backup_block(self, eng, value_function, belief_set, beliefs, belief_dominance_prune):
+        """The device backup of one belief list against the resident value function: rows (``AlphaVector`` objects tagged
+        with their device residency, or an array) and actions."""
+        eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values, owner=value_function)
+        if len(beliefs) <= self.BELIEF_BLOCK:
+            eng.sync_rows('belief', beliefs, lambda b: b.values, owner=belief_set)
+            stats = eng.run(self.gamma, belief_dominance_prune)
+            if stats['formulation'] == 2:
+                # belief-side GEMM: it also multiplied the beliefs themselves by the alpha set; compute_change asks for
+                # exactly those maxima next (these beliefs, the value function that was just backed up)
+                eng.seed_max_values(value_function.alpha_vector_list, beliefs, lambda v: v.values, lambda b: b.values,
+                                    alpha_owner=value_function, belief_owner=belief_set)
+            alpha_new, actions, uidx = eng.fetch().value_function_rows(use_keep=belief_dominance_prune, with_index=True)
+            if len(uidx):
+                # the new rows join the engine's alpha store device to device: the next call selects them by id;
+                # their dedup hashes come from the device too (ValueFunction keys its dictionary on them)
+                first, tag = eng.store_unique(uidx), eng.store_tag('alpha')
+                hashes = eng.fetch_row_hashes()[uidx]
+                vectors = []
+                for k, (row, act) in enumerate(zip(alpha_new, actions)):
+                    v = AlphaVector(row, act)
+                    v._dev = (tag, first + k)
+                    v._hash = int(hashes[k])
+                    vectors.append(v)
+                alpha_new = vectors
+        else:   # beliefs are independent: larger sets go through the engine in blocks (it takes 65535 at a time)
+            parts = []
+            for i0 in range(0, len(beliefs), self.BELIEF_BLOCK):
+                eng.sync_rows('belief', beliefs[i0:i0 + self.BELIEF_BLOCK], lambda b: b.values)
+                eng.run(self.gamma, belief_dominance_prune)
+                parts.append(eng.fetch().value_function_rows(use_keep=belief_dominance_prune))
+            alpha_new = np.concatenate([p[0] for p in parts])
+            actions = np.concatenate([p[1] for p in parts])
+        return alpha_new, actions
+
+    def _backup_in_chunks(self, eng, value_function, beliefs, belief_dominance_prune):
+        """A backup whose working set did not fit the device (the engine raised ``MemoryError`` and is back in its freshly
+        created state), done in belief chunks: beliefs are independent, so the union of the chunks' rows is the block's
+        result (the constructor of ``ValueFunction`` drops duplicates as it does for one block).  Chunks project the
+        BELIEFS through the model, whose footprint is chunk x A x O rows, instead of Gamma's A x O x V rows -- the array
+        the reference's CuPy path dies allocating (``Sea_Robin_Real.ipynb:913``) -- and are halved until one fits; a
+        single belief that does not fit re-raises, which ``solve`` turns into the partial result
+        (``src/pomdp.py:2399-2401``)."""
+        chunk = self._belief_chunk if self._belief_chunk is not None else (len(beliefs) + 1) // 2
+        chunk = max(1, min(chunk, (len(beliefs) + 1) // 2))
+        setting = eng.formulation
+        while True:
+            # (not inside the try: a value function that does not fit by itself is not cured by smaller chunks)
+            eng.sync_rows('alpha', value_function.alpha_vector_list, lambda v: v.values, owner=value_function)
+            try:
+                eng.set_formulation('belief' if chunk <= len(value_function) else 'auto')
+                parts = []
+                for i0 in range(0, len(beliefs), chunk):
+                    eng.sync_rows('belief', beliefs[i0:i0 + chunk], lambda b: b.values)
+                    eng.run(self.gamma, belief_dominance_prune)
+                    parts.append(eng.fetch().value_function_rows(use_keep=belief_dominance_prune))
+                self._belief_chunk = chunk
+                return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+            except MemoryError:
+                if chunk == 1:
+                    raise
+                chunk = (chunk + 1) // 2
+            finally:
+                eng.set_formulation(setting)
 
     def _backup_numpy(self, model, b, alpha, belief_dominance_prune, return_mask: bool = False):
         """Host path: the reference's array statements (``src/pomdp.py:1485-1515``).  ``return_mask``: every belief's
@@ -820,6 +867,7 @@ class PBVI_Solver(Solver):
         iteration = 0
         expand_value_function = value_function
         old_value_function = value_function
+        self._belief_chunk = None              # (backup: the chunk size an earlier solve settled on says nothing about this one)
         try:
             for expansion_i in range(expansions):
                 t0 = datetime.now()
