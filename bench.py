@@ -279,12 +279,13 @@ def main():
         n_total = B * world
         beliefs = synth.belief_points(m, B, start=rank * B)        # this rank's block of the global set
 
+    exchange_rows_env = os.environ.get('PBVI_EXCHANGE') == 'rows'   # A-B only: move alpha' rows instead of keys
     eng = Engine(m.S, m.A, m.O, m.R, m.reachable_states, m.rto, m.expected_rewards, dtype=args.dtype, device=local_rank,
                  mode=args.mode)
     eng.set_formulation(args.formulation)
     eng.set_alpha(alpha)
     # the belief store: `blocks` blocks of B rows (block 0 = `beliefs`); a timed step selects the next one by id
-    rotate = not distributed and args.blocks > 1
+    rotate = args.blocks > 1 and not exchange_rows_env
     block_ids = []
     if rotate:
         for k in range(args.blocks):
@@ -295,7 +296,7 @@ def main():
     eng.set_beliefs(beliefs)
     shard = EngineShard(eng, m.gamma, carrier=torch.device('cpu') if (distributed and backend == 'gloo') else None)
     host = HostResults(eng, B)
-    exchange_rows = os.environ.get('PBVI_EXCHANGE') == 'rows'       # A-B only: move alpha' rows instead of keys
+    exchange_rows = exchange_rows_env
 
     def fence():
         if distributed:
@@ -305,6 +306,9 @@ def main():
     exchange_parts = []
 
     def step():
+        if rotate:                                                    # a block the engine has no indexes of (SURVEY 8d)
+            eng.select_beliefs(block_ids[step.n % len(block_ids)])
+            step.n += 1
         if distributed:
             if exchange_rows:
                 rows, count, idx, acts, keep, st = shard.run_resident_unique()
@@ -316,9 +320,6 @@ def main():
             st = sharded_engine_step(shard, dist, None, n_total, timing=timing)[5]
             exchange_parts.append(timing)
             return st
-        if rotate:                                                    # a block the engine has no indexes of (SURVEY 8d)
-            eng.select_beliefs(block_ids[step.n % len(block_ids)])
-            step.n += 1
         if args.two_calls:
             st = eng.run(m.gamma)
             eng.fetch_compact_into(host.rows, host.index, host.actions)   # U rows + index + actions -> pinned host, synchronised
@@ -380,7 +381,8 @@ def main():
                                    f'(S={m.S}, A={m.A}, O={m.O}), V={args.alphas} alpha-vectors, '
                                    + (f'B={B} beliefs per GPU' if args.scaling == 'weak' else f'B={n_total} beliefs over {world} GPU(s)'),
                        'S': m.S, 'A': m.A, 'O': m.O, 'R': m.R, 'V': args.alphas, 'B_per_gpu': B, 'B_total': n_total,
-                       'step': ('local backup + all-gather of ' + ('alpha rows' if exchange_rows else 'row keys')
+                       'step': (('pbvi_beliefs_select (next block of this rank\'s belief store) + ' if rotate else '') +
+                                'local backup + all-gather of ' + ('alpha rows' if exchange_rows else 'row keys')
                                 + ' + global dedup + append of the distinct rows to every replica\'s alpha store') if distributed
                                else ('pbvi_beliefs_select (next block of the device belief store) + ' if rotate else '') +
                                     ('pbvi_backup_run + pbvi_backup_fetch_compact' if args.two_calls else 'pbvi_backup_run_fetch (= run + '
