@@ -131,7 +131,14 @@ struct RefineWork {
     int32_t* eidx = nullptr;             // [slot_cap] 0x7fffffff - (smallest candidate index attaining emax); 0 = none
     double* ib_val = nullptr;            // [slot_cap] best of the candidates the entry's own block scored
     int32_t* ib_idx = nullptr;           // [slot_cap] (0x7fffffff = none)
-    int* cnt = nullptr;                  // [2] items reserved, slots reserved
+    int* cnt = nullptr;                  // [4] items reserved, slots reserved, entries handed to k_refine_split, (free)
+    // Entries whose candidates the level-1 screen could not separate, re-decided by k_refine_split (16 blocks per entry)
+    int32_t* q2_entry = nullptr;         // [q2_cap] queue entry
+    int32_t* q2_n = nullptr;             // [q2_cap] surviving candidates (<= 8)
+    int32_t* q2_cand = nullptr;          // [q2_cap][8] their alpha indices, ascending
+    double* q2_part = nullptr;           // [q2_cap][16][8] partial exact scores per tile-list part
+    int* q2_done = nullptr;              // [q2_cap] arrival counters (zero between launches)
+    int q2_cap = 0;
     int item_cap = 0, slot_cap = 0;
     int defer_min = 8;                   // more candidates than this in a 256-column chunk go to the grid-wide passes
     size_t zero_bytes = 0;               // cnt, emax, eidx are one allocation starting at cnt: bytes to clear per launch

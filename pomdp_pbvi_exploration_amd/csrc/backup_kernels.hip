@@ -93,21 +93,17 @@ __device__ __forceinline__ double plain_dot_partial(const T* __restrict__ brow, 
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-// Level-1 screen: fp64 sums of  b[s] * G_c[s]  for up to 4 projected fp32 rows at once over a tile list (the belief is
-// read once); blockDim.x = 256 = 8 half-waves, half-wave q takes list entries q, q+8, ...; every thread gets the 4 sums.
-template <typename T>
-__device__ __forceinline__ void gamma_dots4(const T* __restrict__ brow, const float* const (&grow)[4], TileList tl,
-                                            double (&out)[4], double* sh /* >= 16 doubles */) {
-    const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i0 = q; i0 < tl.count; i0 += 16) {            // two list entries per half-wave in flight
-        const int i1 = i0 + 8;
-        const bool ok1 = i1 < tl.count;
-        const int s0 = tl.at(i0) * 32 + l, s1 = tl.at(ok1 ? i1 : i0) * 32 + l;
-        const double b0 = (double)brow[s0], b1 = ok1 ? (double)brow[s1] : 0.0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] += b0 * (double)grow[c][s0] + b1 * (double)grow[c][s1];
-    }
+// The refinement's dots over a tile list, for up to 4 candidates at once with the belief (and, for exact_dots4, the model
+// tables) read once.  A tile is 32 consecutive states = 128 bytes of an fp32 row: every lane takes 16 bytes of it (4 floats /
+// 2 doubles), so the 256 threads cover 32 (fp32) or 16 (fp64) list entries per pass, two passes in flight.  (One state per
+// lane -- 8 tiles per pass -- made these loops a chain of one memory round trip per 16 tiles: 52 us for the 825 tiles of an
+// average R = 5 entry, 40 us for the 364 of an R = 1 entry, measured with wall_clock64 inside k_refine.)
+// Every thread gets the 4 sums.
+#ifndef PBVI_DOTS_IN_FLIGHT
+#define PBVI_DOTS_IN_FLIGHT 2
+#endif
+constexpr int DOTS_IN_FLIGHT = PBVI_DOTS_IN_FLIGHT;       // passes in flight per thread
+__device__ __forceinline__ void dots4_reduce(double (&acc)[4], double (&out)[4], double* sh /* >= 16 doubles */) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = wave_sum(acc[c]);
@@ -121,57 +117,112 @@ __device__ __forceinline__ void gamma_dots4(const T* __restrict__ brow, const fl
     for (int c = 0; c < 4; ++c) out[c] = ((sh[c] + sh[4 + c]) + sh[8 + c]) + sh[12 + c];
 }
 
-// Exact (fp64) scores of up to 4 candidates of ONE entry in one pass over its tile list: the belief, the weights and the
-// successor indices are read once and the four alpha gathers of a state are in flight together (one block-wide pass per
-// candidate was two dependent latency chains of ~20 us for the usual two candidates).  The same products and the same
-// b * (gamma * g) association as proj_dot_partial; identical candidate rows give identical sums, so exact ties still go to
-// the lower index.  blockDim.x = 256; every thread gets the 4 sums.
+// Level-1 screen: fp64 sums of  b[s] * G_c[s]  over projected fp32 rows (RefineWork::gam); fp32 engines only.
+template <typename T>
+__device__ __forceinline__ void gamma_dots4(const T* __restrict__ brow, const float* const (&grow)[4], TileList tl,
+                                            double (&out)[4], double* sh /* >= 16 doubles */) {
+    static_assert(sizeof(T) == 4, "projected rows are screened by fp32 engines only");
+    typedef float F4 __attribute__((ext_vector_type(4)));
+    constexpr int NF = DOTS_IN_FLIGHT;
+    const int q = threadIdx.x >> 3, l = (threadIdx.x & 7) * 4;
+    const F4 zero = {0.f, 0.f, 0.f, 0.f};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = q; i0 < tl.count; i0 += 32 * NF) {
+        int st[NF];
+        F4 bv[NF], gv[NF][4];
+#pragma unroll
+        for (int h = 0; h < NF; ++h) {
+            const int i = i0 + 32 * h;
+            const bool ok = i < tl.count;
+            st[h] = tl.at(ok ? i : i0) * 32 + l;
+            bv[h] = ok ? *(const F4*)((const float*)brow + st[h]) : zero;
+        }
+#pragma unroll
+        for (int h = 0; h < NF; ++h)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gv[h][c] = *(const F4*)(grow[c] + st[h]);
+#pragma unroll
+        for (int h = 0; h < NF; ++h)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[c] += (double)bv[h][k] * (double)gv[h][c][k];
+    }
+    dots4_reduce(acc, out, sh);
+}
+
+// Exact scores from the operands:  sum_s b[s] * gamma * sum_r rto[a][o][r][s] * alpha_c[rs[a][r][s]]  (PROJ) or
+// sum_s b[s] * alpha_c[s], products of fp32 operands exact in fp64, fp64 sums.  Successors of consecutive states are
+// usually consecutive (grid moves): then the 4 (2) alpha values of a lane are one element-aligned 16-byte load.
+// Identical candidate rows give identical sums (same operations in the same order), so exact ties still go to the lower index.
 template <typename T, bool PROJ>
 __device__ __forceinline__ void exact_dots4(const T* __restrict__ brow, const T* const (&arow)[4], int nc /* candidates in use */,
                                             const ModelView<T>& mv, int a, int o, double gamma, TileList tl, double (&out)[4],
                                             double* sh /* >= 16 doubles */) {
+    constexpr int NS = 16 / (int)sizeof(T);                 // states per lane
+    constexpr int LPT = 32 / NS, TPP = 256 / LPT;           // lanes per tile, tiles per pass
+    typedef T TN __attribute__((ext_vector_type(NS)));
+    typedef int IN __attribute__((ext_vector_type(NS)));
     const int32_t* __restrict__ rs = mv.rs + (int64_t)a * mv.R * mv.S_pad;
     const T* __restrict__ rto = mv.rto + (int64_t)(a * mv.O + o) * mv.R * mv.S_pad;
-    const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int q = threadIdx.x / LPT, l = (threadIdx.x % LPT) * NS;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i0 = q; i0 < tl.count; i0 += 16) {            // two list entries per half-wave in flight
-        const int i1 = i0 + 8;
-        const bool ok1 = i1 < tl.count;
-        const int s0 = tl.at(i0) * 32 + l, s1 = tl.at(ok1 ? i1 : i0) * 32 + l;
-        const double b0 = (double)brow[s0], b1 = ok1 ? (double)brow[s1] : 0.0;
+    constexpr int NF = DOTS_IN_FLIGHT;
+    for (int i0 = q; i0 < tl.count; i0 += NF * TPP) {
+        int st[NF];
+        double bg[NF][NS];                                   // b[s] (* gamma), zero for a slot that is not there
+#pragma unroll
+        for (int h = 0; h < NF; ++h) {
+            const int i = i0 + TPP * h;
+            const bool ok = i < tl.count;
+            st[h] = tl.at(ok ? i : i0) * 32 + l;
+            const TN bv = *(const TN*)(brow + st[h]);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) bg[h][k] = ok ? (PROJ ? gamma * (double)bv[k] : (double)bv[k]) : 0.0;
+        }
         if constexpr (PROJ) {
-            double g0[4] = {0.0, 0.0, 0.0, 0.0}, g1[4] = {0.0, 0.0, 0.0, 0.0};
             for (int r = 0; r < mv.R; ++r) {
                 const int64_t ro = (int64_t)r * mv.S_pad;
-                const double w0 = (double)rto[ro + s0], w1 = (double)rto[ro + s1];
-                const int t0 = rs[ro + s0], t1 = rs[ro + s1];
+#pragma unroll
+                for (int h = 0; h < NF; ++h) {
+                    const IN idx = *(const IN*)(rs + ro + st[h]);
+                    const TN w = *(const TN*)(rto + ro + st[h]);
+                    bool contig = true;
+#pragma unroll
+                    for (int k = 1; k < NS; ++k) contig = contig && (idx[k] == idx[0] + k);
+                    double bw[NS];
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) bw[k] = bg[h][k] * (double)w[k];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < nc) {                        // block-uniform: no gathers for unused candidate slots
+                            TN av;
+                            if (contig) {
+                                const T* p = arow[c] + idx[0];
+#pragma unroll
+                                for (int k = 0; k < NS; ++k) av[k] = p[k];
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < NS; ++k) av[k] = arow[c][idx[k]];
+                            }
+#pragma unroll
+                            for (int k = 0; k < NS; ++k) acc[c] += bw[k] * (double)av[k];
+                        }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < NF; ++h)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (c < nc) {                            // block-uniform: no gathers for unused candidate slots
-                        g0[c] += w0 * (double)arow[c][t0];
-                        g1[c] += w1 * (double)arow[c][t1];
+                    if (c < nc) {
+                        const TN av = *(const TN*)(arow[c] + st[h]);       // inside the row's S_pad columns; valid for s < S only
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) acc[c] += (st[h] + k < mv.S) ? bg[h][k] * (double)av[k] : 0.0;
                     }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] += b0 * (gamma * g0[c]) + b1 * (gamma * g1[c]);
-        } else {
-            const bool in0 = s0 < mv.S, in1 = s1 < mv.S;   // alpha rows are valid for s < S only
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < nc) acc[c] += (in0 ? b0 * (double)arow[c][s0] : 0.0) + (in1 ? b1 * (double)arow[c][s1] : 0.0);
         }
     }
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = wave_sum(acc[c]);
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sh[wid * 4 + c] = acc[c];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 4; ++c) out[c] = ((sh[c] + sh[4 + c]) + sh[8 + c]) + sh[12 + c];
+    dots4_reduce(acc, out, sh);
 }
 
 // ------------------------------------------------------------------------- //
@@ -612,20 +663,40 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
         const int64_t col0 = (int64_t)g * V;
         const float* rowp = (const float*)sv.slabs + (int64_t)b * sv.ldc + col0;
         const int tm = b >> 8;
-        for (int c0 = lane * 4; c0 < V; c0 += 256) {
-            const int n = sv.nchunks[((col0 + c0) >> 8) * sv.tiles_m + tm];
-            F4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int z = 0; z < n; ++z) acc = acc + *(const F4*)(rowp + c0 + (int64_t)z * sv.slab_stride);
+        // four 256-column steps at a time: their slab counts first, then their first slabs, then what further slabs
+        // there are -- two rounds of independent loads per 1024 columns instead of eight dependent ones
+        for (int c00 = lane * 4; c00 < V; c00 += 1024) {
+            int n[4];
+            F4 acc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const T sc = (T)acc[j];
-                const int v = c0 + j;
-                if (sc > m || idx == 0x7fffffff) {
-                    m2 = (idx == 0x7fffffff) ? m2 : m;
-                    m = sc;
-                    idx = v;
-                } else if (sc > m2) {
-                    m2 = sc;
+                const int c0 = c00 + 256 * j;
+                n[j] = c0 < V ? sv.nchunks[((col0 + c0) >> 8) * sv.tiles_m + tm] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const F4 zero = {0.f, 0.f, 0.f, 0.f};
+                acc[j] = zero;
+                if (n[j] > 0) acc[j] = acc[j] + *(const F4*)(rowp + c00 + 256 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                for (int z = 1; z < n[j]; ++z) acc[j] = acc[j] + *(const F4*)(rowp + c00 + 256 * j + (int64_t)z * sv.slab_stride);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c0 = c00 + 256 * j;
+                if (c0 >= V) break;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const T sc = (T)acc[j][i];
+                    const int v = c0 + i;
+                    if (sc > m || idx == 0x7fffffff) {
+                        m2 = (idx == 0x7fffffff) ? m2 : m;
+                        m = sc;
+                        idx = v;
+                    } else if (sc > m2) {
+                        m2 = sc;
+                    }
                 }
             }
         }
@@ -714,6 +785,8 @@ hipError_t launch_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* dea
 //     per candidate).
 // ------------------------------------------------------------------------- //
 constexpr int REFINE_LIST_CAP = 2048;   // tiles kept in LDS (65536 states of support); longer lists stay global
+constexpr int REFINE_SPLIT = 16;        // k_refine_split: blocks per entry (parts of its tile list)
+constexpr int REFINE_SPLIT_CAND = 8;    // ... and candidates per entry it takes
 
 // exact score of one candidate over a tile list, computed by one wave (all lanes get the sum)
 template <typename T, bool PROJ>
@@ -916,6 +989,25 @@ __global__ void k_refine(SlabView<TS> sv, int V, int G, const int32_t* __restric
                     __syncthreads();
                     n2 = n2_sh;
                     if (n2 == 1) return;
+                    // What the projected rows cannot separate (duplicates on the belief's support: ~1 % of the entries) is
+                    // re-scored from alpha, RTO and the successor lists -- R gathers per state over the whole list.  Inside
+                    // this block that is one long chain per entry, and 30 such entries were 145 us of tail behind 3000 entries
+                    // that had finished (R = 5, |S| = 30000): they go to k_refine_split, REFINE_SPLIT blocks per entry.
+                    if (work.q2_entry != nullptr && n2 <= REFINE_SPLIT_CAND) {
+                        if (tid == 0) {
+                            const int qi = atomicAdd(&work.cnt[2], 1);
+                            sh_slot = qi < work.q2_cap ? qi : -1;
+                            if (qi < work.q2_cap) {
+                                work.q2_entry[qi] = e;
+                                work.q2_n[qi] = n2;
+                                for (int c = 0; c < n2; ++c) work.q2_cand[(int64_t)qi * REFINE_SPLIT_CAND + c] = c1[c];
+                            }
+                        }
+                        __syncthreads();
+                        if (sh_slot >= 0) return;
+                        if (tid == 0) sh_slot = -1;           // (no room: scored here, as before)
+                        __syncthreads();
+                    }
                 }
             }
             if constexpr (!l1) {    // exact scores of all of them together, four per pass; first maximum
@@ -1025,6 +1117,103 @@ __global__ void k_refine(SlabView<TS> sv, int V, int G, const int32_t* __restric
             work.ib_val[slot] = bv;
             work.ib_idx[slot] = bi;
         } else if (bi != 0x7fffffff) {
+            best_v[e] = bi;
+            best_score[e] = bv;
+            err[e] = 0.0;
+        }
+    }
+}
+
+// Exact re-decision of the entries k_refine's level-1 screen could not separate (RefineWork::q2_*): REFINE_SPLIT blocks per
+// entry, block (q, p) scoring the entry's surviving candidates over part p of its tile list (exact_dots4); the block that
+// arrives last adds the parts in order p = 0, 1, ... and writes the first maximum.  Identical candidate rows still give
+// identical sums.  grid = (entries at a time, REFINE_SPLIT).
+template <typename T, bool PROJ>
+__global__ void k_refine_split(int G, const T* __restrict__ bel, int ldb, const T* __restrict__ alpha, int lda, ModelView<T> mv,
+                               double gamma, const int32_t* __restrict__ btl, const int32_t* __restrict__ btc,
+                               const uint8_t* __restrict__ nzG, int32_t* __restrict__ best_v, double* __restrict__ best_score,
+                               double* __restrict__ err, RefineWork work) {
+    __shared__ int wcount[4];
+    __shared__ int ltile[REFINE_LIST_CAP];
+    __shared__ int lbase, loverflow, last;
+    __shared__ double red16[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, part = blockIdx.y;
+    const int n_q = min(work.cnt[2], work.q2_cap);
+    const int k_tiles = mv.S_pad >> 5;
+    for (int q = blockIdx.x; q < n_q; q += gridDim.x) {
+        const int e = work.q2_entry[q], nc_all = work.q2_n[q];
+        const int b = e / G, g = e % G;
+        const int a = PROJ ? g / mv.O : 0, o = PROJ ? g % mv.O : 0;
+        const T* brow = bel + (int64_t)b * ldb;
+        // the entry's tile list, as k_refine builds it (belief tiles filtered by the group's support tiles)
+        const int32_t* src = btl ? btl + (int64_t)b * k_tiles : nullptr;
+        const int n_src = btl ? btc[b] : k_tiles;
+        const uint8_t* zg = (PROJ && nzG) ? nzG + (int64_t)g * k_tiles : nullptr;
+        __syncthreads();                                     // (the previous entry's readers of ltile / lbase are done)
+        if (tid == 0) {
+            lbase = 0;
+            loverflow = 0;
+        }
+        __syncthreads();
+        for (int i0 = 0; i0 < n_src; i0 += 256) {
+            const int i = i0 + tid;
+            int t = 0, f = 0;
+            if (i < n_src) {
+                t = src ? src[i] : i;
+                f = zg ? (zg[t] != 0) : 1;
+            }
+            const unsigned long long mask = __ballot(f);
+            if (lane == 0) wcount[wid] = __popcll(mask);
+            __syncthreads();
+            int off = lbase;
+            for (int w = 0; w < wid; ++w) off += wcount[w];
+            const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+            const bool fits = lbase + tot <= REFINE_LIST_CAP;
+            if (f && fits) ltile[off + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+            __syncthreads();
+            if (tid == 0) {
+                if (fits) lbase += tot;
+                else loverflow = 1;
+            }
+            __syncthreads();
+            if (loverflow) break;
+        }
+        const int* L = loverflow ? src : ltile;              // overflow: the belief's own list (zero tiles add exact zeros)
+        const int n_tiles = loverflow ? n_src : lbase;
+        const int lo = (int)((int64_t)n_tiles * part / REFINE_SPLIT), hi = (int)((int64_t)n_tiles * (part + 1) / REFINE_SPLIT);
+        const TileList tl{L + lo, hi - lo};
+        double* mine = work.q2_part + ((int64_t)q * REFINE_SPLIT + part) * REFINE_SPLIT_CAND;
+        for (int c0 = 0; c0 < nc_all; c0 += 4) {
+            const T* rows[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rows[j] = alpha + (int64_t)work.q2_cand[(int64_t)q * REFINE_SPLIT_CAND + (c0 + j < nc_all ? c0 + j : c0)] * lda;
+            double d[4];
+            exact_dots4<T, PROJ>(brow, rows, nc_all - c0 < 4 ? nc_all - c0 : 4, mv, a, o, gamma, tl, d, red16);
+            if (tid == 0)
+                for (int j = 0; j < 4 && c0 + j < nc_all; ++j) mine[c0 + j] = d[j];
+        }
+        // the last of the entry's blocks to arrive combines
+        if (tid == 0) {
+            __threadfence();
+            const int arrived = atomicAdd(&work.q2_done[q], 1);
+            last = arrived == REFINE_SPLIT - 1;
+            if (last) work.q2_done[q] = 0;                   // ready for the next launch
+        }
+        __syncthreads();
+        if (last && tid == 0) {
+            __threadfence();
+            const volatile double* parts = work.q2_part + (int64_t)q * REFINE_SPLIT * REFINE_SPLIT_CAND;
+            double bv = 0.0;
+            int bi = -1;
+            for (int c = 0; c < nc_all; ++c) {               // candidates ascend: first maximum
+                double sum = 0.0;
+                for (int p = 0; p < REFINE_SPLIT; ++p) sum += parts[p * REFINE_SPLIT_CAND + c];
+                if (bi < 0 || sum > bv) {
+                    bv = sum;
+                    bi = work.q2_cand[(int64_t)q * REFINE_SPLIT_CAND + c];
+                }
+            }
             best_v[e] = bi;
             best_score[e] = bv;
             err[e] = 0.0;
@@ -1191,10 +1380,13 @@ hipError_t launch_refine_scan(bool proj, SlabView<TS> sv, int V, int G, int max_
     }
     if (proj)
     {
-        if (work.gam != nullptr && sizeof(T) == 4)
+        if (work.gam != nullptr && sizeof(T) == 4) {
             hipLaunchKernelGGL((k_refine<T, TS, true, true>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,
                                alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
-        else
+            if (work.q2_entry != nullptr)                    // what its level-1 screen left undecided, 16 blocks per entry
+                hipLaunchKernelGGL((k_refine_split<T, true>), dim3(work.q2_cap < 256 ? work.q2_cap : 256, REFINE_SPLIT), dim3(256), 0,
+                                   st, G, bel, ldb, alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, work);
+        } else
             hipLaunchKernelGGL((k_refine<T, TS, true, false>), dim3(max_entries), dim3(256), 0, st, sv, V, G, queue, qcount, bel, ldb,
                                alpha, lda, mv, gamma, btl, btc, nzG, best_v, best_score, err, cand_total, work);
     }

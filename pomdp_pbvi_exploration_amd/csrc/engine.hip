@@ -720,6 +720,7 @@ class EngineT : public EngineBase {
     void* host_stage_ = nullptr;                            // pinned bounce buffer for rows going to pageable host memory
     size_t host_stage_cap_ = 0;
     DevBuf keys_tmp_, keys_act_, keys_best_, keys_rows_;    // unique-row keys out / rows from keys in (multi-GPU exchange)
+    DevBuf rf_q2_, rf_q2p_, rf_q2d_;                         // k_refine_split: entries / candidates, partial scores, arrival counters
     DevBuf rf_v_, rf_slot_, rf_sc_, rf_entry_, rf_n_, rf_tiles_, rf_ibv_, rf_ibi_, rf_cnt_, rf_W_, rf_Cx_, rf_nzW_, rf_klW_, rf_kcW_;   // refinement work list
     int formulation_ = 0;                                   // 0 auto, 1 project alpha-vectors, 2 project beliefs
     int last_formulation_ = 1;
@@ -804,7 +805,7 @@ class EngineT : public EngineBase {
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &snz_, &sbtl_, &sbtc_, &vmax_bk_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
-                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_, &scr_flag_, &ctile_, &e_bv_, &e_bs_, &e_err_, &e_rdot_, &e_act_, &e_ares_, &e_bres_, &e_rep_, &e_uniq_, &e_inv_, &e_slotd_, &e_cnt_, &e_out_, &e_slot_};
+                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_, &scr_flag_, &ctile_, &rf_q2_, &rf_q2p_, &rf_q2d_, &e_bv_, &e_bs_, &e_err_, &e_rdot_, &e_act_, &e_ares_, &e_bres_, &e_rep_, &e_uniq_, &e_inv_, &e_slotd_, &e_cnt_, &e_out_, &e_slot_};
         // every call is checked only to name a failure when PBVI_DEBUG is set; the thread's sticky last-error is cleared at
         // the end either way, so that a later launch check does not report a stale error of this teardown
         static const bool dbg = getenv("PBVI_DEBUG") != nullptr;
@@ -1574,7 +1575,7 @@ class EngineT : public EngineBase {
                           &bu_mass_, &bu_out_, &bu_row_, &walk64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_,
                           &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_, &snz_, &sbtl_, &sbtc_, &vmax_bk_,
                           &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_, &nzAlpha_, &prod_, &klistD_,
-                          &kcountD_, &nchunksD_, &mat_, &vlist_, &rowflags_, &ctile_, &e_bv_, &e_bs_, &e_err_, &e_rdot_, &e_act_, &e_ares_, &e_bres_, &e_rep_, &e_uniq_, &e_inv_, &e_slotd_, &e_out_, &e_slot_};
+                          &kcountD_, &nchunksD_, &mat_, &vlist_, &rowflags_, &ctile_, &rf_q2_, &rf_q2p_, &rf_q2d_, &e_bv_, &e_bs_, &e_err_, &e_rdot_, &e_act_, &e_ares_, &e_bres_, &e_rep_, &e_uniq_, &e_inv_, &e_slotd_, &e_out_, &e_slot_};
         for (DevBuf* b : drop) {
             bytes_ -= (int64_t)b->cap;
             b->release();
@@ -2247,6 +2248,22 @@ class EngineT : public EngineBase {
         w->ib_val = rf_ibv_.as<double>();
         w->ib_idx = rf_ibi_.as<int32_t>();
         w->cnt = rf_cnt_.as<int>();
+        {   // hand-over to k_refine_split (entries the level-1 screen leaves undecided; ~1 % of the queue)
+            const int64_t q2 = std::min<int64_t>(max_entries, 16384);
+            const size_t need = (size_t)q2 * (2 + 8) * sizeof(int32_t);
+            if ((rc = rf_q2_.ensure(need, &bytes_))) return rc;
+            if ((rc = rf_q2p_.ensure((size_t)q2 * 16 * 8 * sizeof(double), &bytes_))) return rc;
+            if (rf_q2d_.cap < (size_t)q2 * sizeof(int)) {
+                if ((rc = rf_q2d_.ensure((size_t)q2 * sizeof(int), &bytes_))) return rc;
+                HIPCHK(hipMemsetAsync(rf_q2d_.p, 0, rf_q2d_.cap, stream_));      // arrival counters: zero between launches
+            }
+            w->q2_entry = rf_q2_.as<int32_t>();
+            w->q2_n = rf_q2_.as<int32_t>() + q2;
+            w->q2_cand = rf_q2_.as<int32_t>() + 2 * q2;
+            w->q2_part = rf_q2p_.as<double>();
+            w->q2_done = rf_q2d_.as<int>();
+            w->q2_cap = (int)q2;
+        }
         w->item_cap = (int)items;
         w->slot_cap = (int)slots;
         // GEMM path of the tie-heavy entries: fp64 weight rows for as many slots as ~2 GiB holds
