@@ -168,49 +168,90 @@ __device__ __forceinline__ void exact_dots4(const T* __restrict__ brow, const T*
     const int q = threadIdx.x / LPT, l = (threadIdx.x % LPT) * NS;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     constexpr int NF = DOTS_IN_FLIGHT;
-    for (int i0 = q; i0 < tl.count; i0 += NF * TPP) {
-        int st[NF];
-        double bg[NF][NS];                                   // b[s] (* gamma), zero for a slot that is not there
+    if constexpr (PROJ) {
+        // Software-pipelined over (pass, successor slot): the tables of the next step (belief, successor indices, weights)
+        // are requested before the alpha gathers of the current one -- one round trip per step instead of two -- and the
+        // gathers of both passes of a step leave together (one branch on "every lane's successors are consecutive").
+        struct Step {
+            int st[NF];
+            bool ok[NF];
+            TN bv[NF], w[NF];
+            IN idx[NF];
+        };
+        auto fetch = [&](int i0, int r, Step& x) {
+            const int64_t ro = (int64_t)r * mv.S_pad;
 #pragma unroll
-        for (int h = 0; h < NF; ++h) {
-            const int i = i0 + TPP * h;
-            const bool ok = i < tl.count;
-            st[h] = tl.at(ok ? i : i0) * 32 + l;
-            const TN bv = *(const TN*)(brow + st[h]);
-#pragma unroll
-            for (int k = 0; k < NS; ++k) bg[h][k] = ok ? (PROJ ? gamma * (double)bv[k] : (double)bv[k]) : 0.0;
-        }
-        if constexpr (PROJ) {
-            for (int r = 0; r < mv.R; ++r) {
-                const int64_t ro = (int64_t)r * mv.S_pad;
-#pragma unroll
-                for (int h = 0; h < NF; ++h) {
-                    const IN idx = *(const IN*)(rs + ro + st[h]);
-                    const TN w = *(const TN*)(rto + ro + st[h]);
-                    bool contig = true;
-#pragma unroll
-                    for (int k = 1; k < NS; ++k) contig = contig && (idx[k] == idx[0] + k);
-                    double bw[NS];
-#pragma unroll
-                    for (int k = 0; k < NS; ++k) bw[k] = bg[h][k] * (double)w[k];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (c < nc) {                        // block-uniform: no gathers for unused candidate slots
-                            TN av;
-                            if (contig) {
-                                const T* p = arow[c] + idx[0];
-#pragma unroll
-                                for (int k = 0; k < NS; ++k) av[k] = p[k];
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < NS; ++k) av[k] = arow[c][idx[k]];
-                            }
-#pragma unroll
-                            for (int k = 0; k < NS; ++k) acc[c] += bw[k] * (double)av[k];
-                        }
-                }
+            for (int h = 0; h < NF; ++h) {
+                const int i = i0 + TPP * h;
+                x.ok[h] = i < tl.count;
+                x.st[h] = tl.at(x.ok[h] ? i : i0) * 32 + l;
+                x.bv[h] = *(const TN*)(brow + x.st[h]);
+                x.idx[h] = *(const IN*)(rs + ro + x.st[h]);
+                x.w[h] = *(const TN*)(rto + ro + x.st[h]);
             }
-        } else {
+        };
+        int i0 = q, r = 0;
+        bool live = i0 < tl.count;
+        Step cur, nxt;
+        if (live) fetch(i0, r, cur);
+        while (live) {
+            int ni0 = i0, nr = r + 1;
+            if (nr == mv.R) {
+                nr = 0;
+                ni0 = i0 + NF * TPP;
+            }
+            const bool nlive = ni0 < tl.count;
+            if (nlive) fetch(ni0, nr, nxt);
+            bool contig = true;
+#pragma unroll
+            for (int h = 0; h < NF; ++h)
+#pragma unroll
+                for (int k = 1; k < NS; ++k) contig = contig && (cur.idx[h][k] == cur.idx[h][0] + k);
+            double bw[NF][NS];
+#pragma unroll
+            for (int h = 0; h < NF; ++h)
+#pragma unroll
+                for (int k = 0; k < NS; ++k) bw[h][k] = (cur.ok[h] ? gamma * (double)cur.bv[h][k] : 0.0) * (double)cur.w[h][k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nc) {                                // block-uniform: no gathers for unused candidate slots
+                    TN av[NF];
+                    if (contig) {
+#pragma unroll
+                        for (int h = 0; h < NF; ++h) {
+                            const T* p = arow[c] + cur.idx[h][0];
+#pragma unroll
+                            for (int k = 0; k < NS; ++k) av[h][k] = p[k];
+                        }
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < NF; ++h)
+#pragma unroll
+                            for (int k = 0; k < NS; ++k) av[h][k] = arow[c][cur.idx[h][k]];
+                    }
+#pragma unroll
+                    for (int h = 0; h < NF; ++h)
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) acc[c] += bw[h][k] * (double)av[h][k];
+                }
+            cur = nxt;
+            i0 = ni0;
+            r = nr;
+            live = nlive;
+        }
+    } else {
+        for (int i0 = q; i0 < tl.count; i0 += NF * TPP) {
+            int st[NF];
+            double bg[NF][NS];                               // b[s], zero for a slot that is not there
+#pragma unroll
+            for (int h = 0; h < NF; ++h) {
+                const int i = i0 + TPP * h;
+                const bool ok = i < tl.count;
+                st[h] = tl.at(ok ? i : i0) * 32 + l;
+                const TN bv = *(const TN*)(brow + st[h]);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) bg[h][k] = ok ? (double)bv[k] : 0.0;
+            }
 #pragma unroll
             for (int h = 0; h < NF; ++h)
 #pragma unroll
@@ -1566,6 +1607,9 @@ hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0
     return hipGetLastError();
 }
 
+// (These dots keep the one-state-per-lane loops: the whole-solve test test_end_to_end_fsvi_at_headline_scale_matches_reference
+// follows the reference through exact ties of its action values for 40 backups with THIS summation order; the 16-byte-per-lane
+// dots of k_refine here -- 80 -> 25 us at R = 5 -- leave the reference's trajectory after backup 25.)
 // Exact (f64) value of every candidate action of a flagged belief.  One block per (queued belief, action, term, part):
 // term 0 is b . ER[:,a], term 1 + o the score of observation o -- the 1 + O dots of an action used to run one after the
 // other in one block (60 us of dependent latency for two dozen beliefs) -- and each dot is cut into ACTION_SPLIT parts of
