@@ -435,8 +435,9 @@ def main():
                 # the HBM-bound stages beside the GEMM: PMC bytes of the stage's main kernel / the stage's live time
                 # (the stage time also holds its small helper kernels, so these fractions are lower bounds)
                 sec = {}
-                for stage, kern in (('ms_argmax', 'k_argmax<float>'), ('ms_refine', 'k_refine<float, float, true>')):
-                    if kern in pmc['kernels']:
+                for stage, prefix in (('ms_argmax', 'k_argmax<float>'), ('ms_refine', 'k_refine<float, float, true')):
+                    kern = next((k for k in pmc['kernels'] if k.startswith(prefix)), None)
+                    if kern is not None:
                         ms = out['stage_ms'][stage]
                         tb = pmc['kernels'][kern]['traffic_bytes']
                         gbs = tb / (ms * 1e-3) / 1e9

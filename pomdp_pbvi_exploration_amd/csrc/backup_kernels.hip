@@ -437,7 +437,7 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
                     const int64_t row = (v < V - 1) ? ao * (V - 1) + v : (int64_t)mv.A * mv.O * (V - 1) + ao;
                     if (mat == nullptr || irr_here || mat[row >> 8]) {
                         const int64_t at = ctile != nullptr ? (int64_t)ctile[row >> 8] * 256 + (row & 255) : row;
-                        *(TN*)(gam + at * ldg + s) = gamma * acc[vj][oj];
+                        __builtin_nontemporal_store(gamma * acc[vj][oj], (TN*)(gam + at * ldg + s));
                     }
                 }
     }
