@@ -389,7 +389,9 @@ int pbvi_engine_set_rto_f64(pbvi_engine_t* e, const double* rto);
  *   1 = alpha-vectors, the reference's order (Gamma[a,o,v,:], src/pomdp.py:1489-1491; GEMM [B] x [A*O*V]);
  *   2 = beliefs (bp[a,o,b,:] = gamma * sum b[s] RTO[s,a,o,r] scattered to rs[s,a,r]; GEMM [B*A*O] x [V]);
  *   0 = automatic (default): the cheaper of the two by projected rows and 256-row tile count -- the belief side
- *       when B << V, e.g. the solve loop's ~100 new beliefs against thousands of alpha-vectors.
+ *       when B << V, e.g. the solve loop's ~100 new beliefs against thousands of alpha-vectors -- unless Gamma and its
+ *       score slabs exceed what the engine may still allocate (its cap, or the free device memory) while the projected
+ *       beliefs fit: then the belief side, whatever it costs.  (The reference dies there: Sea_Robin_Real.ipynb:913.)
  */
 int pbvi_set_formulation(pbvi_engine_t* e, int formulation);
 
