@@ -533,3 +533,71 @@ def test_reference_toy_notebooks_run_unchanged_against_this_src():
     out = subprocess.run([sys.executable, os.path.join(GOLDEN, 'run_notebooks.py')], capture_output=True, text=True,
                          timeout=900, env=env)
     assert out.returncode == 0 and 'notebooks ok' in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_backup_in_belief_chunks_halves_until_one_fits_and_gives_the_block_result():
+    """PBVI_Solver._backup_in_chunks (what backup does after the engine's MemoryError): the belief list goes through in chunks,
+    halved until one fits, the value function is uploaded again after every failure (the engine forgets everything on OOM),
+    the caller's formulation setting comes back, the result is the block's, and a single belief that does not fit re-raises."""
+    from types import SimpleNamespace
+    model, _ = load_POMDP_file(os.path.join(EXAMPLES, '4x3.95-no_loop_2_grid.POMDP'))
+    rng = np.random.default_rng(5)
+    S = model.state_count
+    vf = ValueFunction(model, rng.normal(size=(9, S)), rng.integers(0, model.action_count, 9))
+    bel = rng.random((37, S))
+    bel /= bel.sum(axis=1, keepdims=True)
+    beliefs = [Belief(model, r) for r in bel]
+    solver = PBVI_Solver(gamma=0.95, eps=1e-6)
+
+    class Dev:
+        """NumPy stand-in for the engine calls of the chunk loop; `fits` beliefs at most per run."""
+        def __init__(self, fits):
+            self.fits, self.formulation, self.log, self.alpha, self.block = fits, 'alpha', [], None, None
+
+        def set_formulation(self, which):
+            self.formulation = which
+            self.log.append(('formulation', which))
+
+        def sync_rows(self, which, objs, values_of, owner=None):
+            rows = np.array([values_of(x) for x in objs])
+            if which == 'alpha':
+                self.alpha = rows
+                self.log.append(('alpha', len(rows)))
+            else:
+                self.block = rows
+
+        def run(self, gamma, prune):
+            if len(self.block) > self.fits:
+                self.alpha = self.block = None                       # pbvi_engine_after_oom: nothing resident any more
+                self.log.append(('oom', None))
+                raise MemoryError('stub: block too large')
+            assert self.alpha is not None, 'the value function was not uploaded again after the failure'
+            assert self.formulation == 'belief'
+            self.log.append(('run', len(self.block)))
+            return {}
+
+        def fetch(self):
+            rows, acts = solver._backup_numpy(model, self.block, self.alpha, False)
+            return SimpleNamespace(value_function_rows=lambda use_keep=False: (rows, acts))
+
+    want_rows, want_acts = solver._backup_numpy(model, bel, vf.alpha_vector_array, False)
+    want = ValueFunction(model, want_rows, want_acts)
+    dev = Dev(fits=6)
+    rows, acts = solver._backup_in_chunks(dev, vf, beliefs, False)
+    got = ValueFunction(model, rows, acts)
+    assert solver._belief_chunk == 5                                 # 19 -> 10 -> 5
+    assert [x for x in dev.log if x[0] == 'oom'] == [('oom', None)] * 2
+    assert [n for k, n in dev.log if k == 'run'] == [5] * 7 + [2]
+    assert sum(1 for k, _ in dev.log if k == 'alpha') == 3          # once per attempt
+    assert dev.formulation == 'alpha'                               # the caller's setting
+    assert len(got) == len(want)
+    key = lambda v: (v.alpha_vector_array[np.lexsort(v.alpha_vector_array.T[::-1])], )
+    np.testing.assert_array_equal(key(got)[0], key(want)[0])
+    # a later, larger block of the same solve starts at the size that fitted
+    dev2 = Dev(fits=6)
+    solver._backup_in_chunks(dev2, vf, beliefs, False)
+    assert not [x for x in dev2.log if x[0] == 'oom']
+    # nothing fits: the error reaches the caller (solve turns it into the partial result)
+    solver._belief_chunk = None
+    with pytest.raises(MemoryError):
+        solver._backup_in_chunks(Dev(fits=0), vf, beliefs, False)
