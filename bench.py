@@ -90,6 +90,29 @@ def attach_traffic(roofline, tag):
         roofline['traffic_source'] = f'profiles/r03_pmc_traffic.json[{tag}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
 
 
+def stage_rooflines(stage_ms, tag):
+    """The HBM-bound stages beside the GEMM: PMC bytes per launch of the stage's main kernel (rocprofv3 passes on this
+    configuration, profiles/r03_pmc_traffic.json) over the stage's live time from this run.  The stage time also holds its
+    small helper kernels and, under pbvi_backup_run_fetch, what runs beside it (the rows' PCIe copy beside the refinement),
+    so these fractions are lower bounds of the kernels' own."""
+    pmc = load_pmc().get(tag)
+    if not pmc or not stage_ms:
+        return None
+    sec = {}
+    for stage, prefix in (('ms_project', 'k_project<'), ('ms_argmax', 'k_argmax<'), ('ms_refine', 'k_refine<')):
+        kern = next((k for k in pmc['kernels'] if k.startswith(prefix)), None)
+        ms = stage_ms.get(stage, 0.0)
+        if kern is None or ms <= 0.0:
+            continue
+        tb = pmc['kernels'][kern]['traffic_bytes']
+        if tb < 50e6:                                          # (a residual launch, e.g. the fused engines' one projected tile)
+            continue
+        gbs = tb / (ms * 1e-3) / 1e9
+        sec[kern] = {'stage': stage, 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
+                     'traffic': tb, 'ms': ms}
+    return sec or None
+
+
 class HostResults:
     """Page-locked destination of one step's results (pbvi_host_alloc): U rows (room for B), index, actions."""
 
@@ -201,6 +224,9 @@ def measure_config(name, m, alpha, beliefs, dtype, mode, steps, warmup, fence, t
                'unique_rows': int(stats[-1]['n_unique'])}
         if pmc_tag:
             attach_traffic(out['roofline'], pmc_tag)
+            sr = stage_rooflines(out['stage_ms'], pmc_tag)
+            if sr:
+                out['stage_roofline'] = sr
         host.close()
         eng.close()
         return out
@@ -430,21 +456,9 @@ def main():
         if (sparse and args.dtype == 'f32' and m.S == 30000 and m.R == 1 and args.alphas == 1024 and B == 1024
                 and out['roofline'] is not None):
             attach_traffic(out['roofline'], 'c4')
-            pmc = load_pmc().get('c4')
-            if pmc:
-                # the HBM-bound stages beside the GEMM: PMC bytes of the stage's main kernel / the stage's live time
-                # (the stage time also holds its small helper kernels, so these fractions are lower bounds)
-                sec = {}
-                for stage, prefix in (('ms_argmax', 'k_argmax<float>'), ('ms_refine', 'k_refine<float, float, true')):
-                    kern = next((k for k in pmc['kernels'] if k.startswith(prefix)), None)
-                    if kern is not None:
-                        ms = out['stage_ms'][stage]
-                        tb = pmc['kernels'][kern]['traffic_bytes']
-                        gbs = tb / (ms * 1e-3) / 1e9
-                        sec[kern] = {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
-                                     'traffic': tb, 'ms': ms}
-                if sec:
-                    out['stage_roofline'] = sec
+            sr = stage_rooflines(out['stage_ms'], 'c4')
+            if sr:
+                out['stage_roofline'] = sr
         if host_ms is not None:
             out['pcie_inclusive'] = {'ms_per_step': host_ms, 'value': B / (host_ms * 1e-3), 'unit': 'backups/s',
                                      'what': 'pageable beliefs (engine dtype) uploaded + run + unique rows and the expanded [B][S] alpha\' matrix fetched into a pageable array the caller keeps; mean of 3 after one warm-up'}
