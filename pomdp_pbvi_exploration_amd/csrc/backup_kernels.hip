@@ -392,39 +392,45 @@ __global__ void k_project(const T* __restrict__ alpha, int lda, int V, ModelView
         for (int vj = 0; vj < 4; ++vj)
 #pragma unroll
             for (int oj = 0; oj < OB; ++oj) acc[vj][oj] = zero;
-        for (int r = 0; r < mv.R; ++r) {
-            const IN idx = *(const IN*)(mv.rs + ((int64_t)a * mv.R + r) * mv.S_pad + s);
-            bool contig = true;
-#pragma unroll
-            for (int j = 1; j < NS; ++j) contig = contig && (idx[j] == idx[0] + j);
-            TN w[OB];
+        // Software-pipelined over the successor slots: slot r + 1's indices and weights are requested before slot r's alpha
+        // gathers, and the gathers of the four alpha rows leave together behind ONE branch on "this lane's successors are
+        // consecutive" (a branch per row made every row's gather its own round trip: 25 dependent rounds per block at R = 5).
+        auto load_slot = [&](int r, IN& idx, TN (&w)[OB]) {
+            idx = *(const IN*)(mv.rs + ((int64_t)a * mv.R + r) * mv.S_pad + s);
 #pragma unroll
             for (int oj = 0; oj < OB; ++oj)
                 w[oj] = (oj < no && want[oj]) ? *(const TN*)(mv.rto + (((int64_t)a * mv.O + o0 + oj) * mv.R + r) * mv.S_pad + s)
                                                : zero;
+        };
+        IN idx;
+        TN w[OB];
+        for (int r = 0; r < mv.R; ++r) {
+            load_slot(r, idx, w);
+            bool contig = true;
 #pragma unroll
-            for (int vj = 0; vj < 4; ++vj) {
-                if (vj < nv) {
-                    const T* arow = alpha + (int64_t)(v0 + vj) * lda;
-                    // successors of consecutive states are usually consecutive (grid moves): one 16-byte
-                    // (element-aligned) load instead of NS gathers
-                    TN av;
-                    if (contig) {
-#if defined(PBVI_PROJ_EXP) && PBVI_PROJ_EXP == 1       // diagnosis: aligned loads only (wrong results, timing only)
-                        const T* p = arow + (idx[0] & ~3);
-#else
-                        const T* p = arow + idx[0];
-#endif
+            for (int j = 1; j < NS; ++j) contig = contig && (idx[j] == idx[0] + j);
+            // successors of consecutive states are usually consecutive (grid moves): one 16-byte (element-aligned) load
+            // per alpha row instead of NS gathers
+            TN av[4];
+            if (contig) {
 #pragma unroll
-                        for (int j = 0; j < NS; ++j) av[j] = p[j];
-                    } else {
+                for (int vj = 0; vj < 4; ++vj) {
+                    const T* p = alpha + (int64_t)(v0 + (vj < nv ? vj : 0)) * lda + idx[0];
 #pragma unroll
-                        for (int j = 0; j < NS; ++j) av[j] = arow[idx[j]];
-                    }
+                    for (int j = 0; j < NS; ++j) av[vj][j] = p[j];
+                }
+            } else {
 #pragma unroll
-                    for (int oj = 0; oj < OB; ++oj) acc[vj][oj] = acc[vj][oj] + w[oj] * av;
+                for (int vj = 0; vj < 4; ++vj) {
+                    const T* arow = alpha + (int64_t)(v0 + (vj < nv ? vj : 0)) * lda;
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) av[vj][j] = arow[idx[j]];
                 }
             }
+#pragma unroll
+            for (int vj = 0; vj < 4; ++vj)
+#pragma unroll
+                for (int oj = 0; oj < OB; ++oj) acc[vj][oj] = acc[vj][oj] + w[oj] * av[vj];
         }
 #pragma unroll
         for (int vj = 0; vj < 4; ++vj)
