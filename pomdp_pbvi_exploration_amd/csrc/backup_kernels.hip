@@ -704,12 +704,14 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
     // (16 bytes per slab) and looks the pair's slab count up once per 4 columns instead of once per score; columns
     // and chunks ascend per lane, so "first maximum" is unchanged.
     bool vec4 = false;
-    if constexpr (sizeof(T) == 4) vec4 = !sv.push && sv.nchunks != nullptr && (V & 3) == 0 && (sv.ldc & 3) == 0;
+    if constexpr (sizeof(T) == 4) vec4 = sv.nchunks != nullptr && (sv.push || (V & 3) == 0) && (sv.ldc & 3) == 0;
     if (vec4) {
         typedef float F4 __attribute__((ext_vector_type(4)));
-        const int64_t col0 = (int64_t)g * V;
-        const float* rowp = (const float*)sv.slabs + (int64_t)b * sv.ldc + col0;
-        const int tm = b >> 8;
+        // alpha side: row b, columns g * V + v; belief side: row (o, a, b), columns v
+        const int64_t row = sv.push ? sv.push_row(b, g) : (int64_t)b;
+        const int64_t col0 = sv.push ? 0 : (int64_t)g * V;
+        const float* rowp = (const float*)sv.slabs + row * sv.ldc + col0;
+        const int tm = (int)(row >> 8);
         // four 256-column steps at a time: their slab counts first, then their first slabs, then what further slabs
         // there are -- two rounds of independent loads per 1024 columns instead of eight dependent ones
         for (int c00 = lane * 4; c00 < V; c00 += 1024) {
@@ -737,6 +739,7 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
                 for (int i = 0; i < 4; ++i) {
                     const T sc = (T)acc[j][i];
                     const int v = c0 + i;
+                    if (v >= V) break;                          // (belief side: V need not be a multiple of 4)
                     if (sc > m || idx == 0x7fffffff) {
                         m2 = (idx == 0x7fffffff) ? m2 : m;
                         m = sc;
@@ -1980,53 +1983,80 @@ hipError_t launch_belief_update(const T* bel, int ldb, int B, ModelView<T> mv, c
 //   score[b,a,o,v] = bp[g,b,:] . alpha[v,:]   ( = b . Gamma[a,o,v,:] of src/pomdp.py:1489-1495, re-associated)
 // Pull form over the inverse transition lists (no atomics on bp), f64 accumulation, one rounding to T.
 // ------------------------------------------------------------------------- //
+constexpr int PUSH_NB = 4;   // beliefs per thread of k_push_project
 template <typename T>
 __global__ void k_push_project(const T* __restrict__ bel, int ldb, int B, ModelView<T> mv,
                                const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src, double gamma,
                                const T* __restrict__ amax, T* __restrict__ bp, int ldp, double* __restrict__ mag) {
-    __shared__ double red[16];
-    const int sp = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, a = blockIdx.z;
+    // One thread per target state s' and PUSH_NB beliefs: the inverse list of (a, s') and the weights of its entries do not
+    // depend on the belief, so they are read once for the four (one belief per thread re-read them per belief: 1.07 ms for
+    // 100 beliefs at the Sea-Robin shape, 0.74 TB/s).  Per (belief, observation) the sum runs over the list in order, as before:
+    // an entry whose belief value is zero adds an exact zero.
+    __shared__ double red[PUSH_NB][16];
+    const int sp = blockIdx.x * 256 + threadIdx.x, b0 = blockIdx.y * PUSH_NB, a = blockIdx.z;
+    const int nb = B - b0 < PUSH_NB ? B - b0 : PUSH_NB;
     const int G = mv.A * mv.O;
-    const T* brow = bel + (int64_t)b * ldb;
     const int32_t* ptr = in_ptr + (int64_t)a * (mv.S + 1);
     const int32_t* src = in_src + (int64_t)a * mv.S * mv.R;
     const int j0 = sp < mv.S ? ptr[sp] : 0, j1 = sp < mv.S ? ptr[sp + 1] : 0;
     const double am = sp < mv.S ? fabs((double)amax[sp]) : 0.0;
     for (int o0 = 0; o0 < mv.O; o0 += 4) {
         const int no = mv.O - o0 < 4 ? mv.O - o0 : 4;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        double acc[PUSH_NB][4];
+#pragma unroll
+        for (int k = 0; k < PUSH_NB; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[k][q] = 0.0;
         for (int j = j0; j < j1; ++j) {
             const int e = src[j];                           // e = s * R + r
             const int s = mv.R == 1 ? e : e / mv.R, r = e - s * mv.R;
-            const double bs = (double)brow[s];
-            if (bs != 0.0) {
+            double bs[PUSH_NB];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < PUSH_NB; ++k) {
+                bs[k] = k < nb ? (double)bel[(int64_t)(b0 + k) * ldb + s] : 0.0;
+                any = any || bs[k] != 0.0;
+            }
+            if (any) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (q < no) acc[q] += bs * (double)mv.rto[((int64_t)(a * mv.O + o0 + q) * mv.R + r) * mv.S_pad + s];
+                    if (q < no) {
+                        const double w = (double)mv.rto[((int64_t)(a * mv.O + o0 + q) * mv.R + r) * mv.S_pad + s];
+#pragma unroll
+                        for (int k = 0; k < PUSH_NB; ++k) acc[k][q] += bs[k] * w;
+                    }
             }
         }
-        double mg[4] = {0.0, 0.0, 0.0, 0.0};
+        double mg[PUSH_NB][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q >= no) break;                             // uniform across the block
-            const T val = (T)(gamma * acc[q]);
-            const int64_t row = push_row_index(o0 + q, a, b, mv.A, B);           // see SlabView
-            if (sp < ldp) bp[row * ldp + sp] = val;                         // pad columns get exact zeros
-            mg[q] = fabs((double)val) * am;
-        }
-        // magnitudes: one barrier for all (up to four) observations of this pass
+        for (int k = 0; k < PUSH_NB; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mg[q] = wave_sum(mg[q]);
+            for (int q = 0; q < 4; ++q) {
+                mg[k][q] = 0.0;
+                if (q < no && k < nb) {                     // uniform across the block
+                    const T val = (T)(gamma * acc[k][q]);
+                    const int64_t row = push_row_index(o0 + q, a, b0 + k, mv.A, B);      // see SlabView
+                    if (sp < ldp) bp[row * ldp + sp] = val;                         // pad columns get exact zeros
+                    mg[k][q] = fabs((double)val) * am;
+                }
+            }
+        // magnitudes: one barrier for all beliefs and (up to four) observations of this pass
+#pragma unroll
+        for (int k = 0; k < PUSH_NB; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mg[k][q] = wave_sum(mg[k][q]);
         __syncthreads();                                    // red[] of the previous pass has been read
         if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) red[(threadIdx.x >> 6) * 4 + q] = mg[q];
+            for (int k = 0; k < PUSH_NB; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[k][(threadIdx.x >> 6) * 4 + q] = mg[k][q];
         }
         __syncthreads();
-        if ((int)threadIdx.x < no) {
-            const int q = threadIdx.x;
-            const double part = ((red[q] + red[4 + q]) + red[8 + q]) + red[12 + q];
-            if (part != 0.0) atomicAdd(&mag[(int64_t)b * G + a * mv.O + o0 + q], part);
+        if ((int)threadIdx.x < no * nb) {
+            const int k = threadIdx.x / no, q = threadIdx.x % no;
+            const double part = ((red[k][q] + red[k][4 + q]) + red[k][8 + q]) + red[k][12 + q];
+            if (part != 0.0) atomicAdd(&mag[(int64_t)(b0 + k) * G + a * mv.O + o0 + q], part);
         }
     }
 }
@@ -2037,7 +2067,7 @@ hipError_t launch_push_project(const T* bel, int ldb, int B, ModelView<T> mv, co
                                hipStream_t st) {
     if (B <= 0) return hipSuccess;
     if (B > 65535 || mv.A > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_push_project<T>, dim3((ldp + 255) / 256, B, mv.A), dim3(256), 0, st, bel, ldb, B, mv, in_ptr,
+    hipLaunchKernelGGL(k_push_project<T>, dim3((ldp + 255) / 256, (B + PUSH_NB - 1) / PUSH_NB, mv.A), dim3(256), 0, st, bel, ldb, B, mv, in_ptr,
                        in_src, gamma, amax, bp, ldp, mag);
     return hipGetLastError();
 }
@@ -2046,21 +2076,22 @@ template <typename T>
 __global__ void k_rdot(const T* __restrict__ bel, int ldb, ModelView<T> mv, const int32_t* __restrict__ btl,
                        const int32_t* __restrict__ btc, double* __restrict__ rd) {
     __shared__ double red[4];
-    const int b = blockIdx.x;
+    // One block per (belief, action).  (One block per belief walking the actions was B blocks for the whole chip: 2.4 ms
+    // for 100 beliefs x 16 actions at |S| = 61875 -- and since it runs on the side stream beside the persistent score GEMM,
+    // whose blocks need a CU to themselves, the GEMM started on the 156 CUs it left free: 5.9 ms at 0.69 of peak.)
+    const int b = blockIdx.x, a = blockIdx.y;
     const int k_tiles = mv.S_pad >> 5;
     const TileList tl{btl ? btl + (int64_t)b * k_tiles : nullptr, btl ? btc[b] : k_tiles};
     const T* brow = bel + (int64_t)b * ldb;
-    for (int a = 0; a < mv.A; ++a) {
-        const double v = block_sum(plain_dot_partial(brow, mv.er + (int64_t)a * mv.S_pad, mv.S, tl), red);
-        if (threadIdx.x == 0) rd[(int64_t)b * mv.A + a] = v;
-    }
+    const double v = block_sum(plain_dot_partial(brow, mv.er + (int64_t)a * mv.S_pad, mv.S, tl), red);
+    if (threadIdx.x == 0) rd[(int64_t)b * mv.A + a] = v;
 }
 
 template <typename T>
 hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* btl, const int32_t* btc, double* rd,
                        hipStream_t st) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rdot<T>, dim3(B), dim3(256), 0, st, bel, ldb, mv, btl, btc, rd);
+    hipLaunchKernelGGL(k_rdot<T>, dim3(B, mv.A), dim3(256), 0, st, bel, ldb, mv, btl, btc, rd);
     return hipGetLastError();
 }
 
