@@ -103,7 +103,7 @@ hipError_t launch_dead(const T* bel, int ldb, int B, ModelView<T> mv,
 template <typename T>
 hipError_t launch_push_project(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* in_ptr,
                                const int32_t* in_src, double gamma, const T* amax, T* bp, int ldp, double* mag,
-                               hipStream_t st);
+                               hipStream_t st, uint8_t* nzP = nullptr /* zero-tile map of the projected rows, [rows/256][ldp/32] */);
 // rd[b][a] = b . ER[:,a] in f64 over the belief's non-zero tiles
 template <typename T>
 hipError_t launch_rdot(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* btl, const int32_t* btc, double* rd,

@@ -1984,62 +1984,79 @@ hipError_t launch_belief_update(const T* bel, int ldb, int B, ModelView<T> mv, c
 // Pull form over the inverse transition lists (no atomics on bp), f64 accumulation, one rounding to T.
 // ------------------------------------------------------------------------- //
 constexpr int PUSH_NB = 4;   // beliefs per thread of k_push_project
+constexpr int PUSH_NT = 8;   // 256-state chunks per block
 template <typename T>
 __global__ void k_push_project(const T* __restrict__ bel, int ldb, int B, ModelView<T> mv,
                                const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src, double gamma,
-                               const T* __restrict__ amax, T* __restrict__ bp, int ldp, double* __restrict__ mag) {
+                               const T* __restrict__ amax, T* __restrict__ bp, int ldp, double* __restrict__ mag,
+                               uint8_t* __restrict__ nzP /* [rows / 256][ldp / 32], zeroed by the caller: set where a projected
+                                                            row has a non-zero in the K tile (or nullptr) */) {
     // One thread per target state s' and PUSH_NB beliefs: the inverse list of (a, s') and the weights of its entries do not
-    // depend on the belief, so they are read once for the four (one belief per thread re-read them per belief: 1.07 ms for
-    // 100 beliefs at the Sea-Robin shape, 0.74 TB/s).  Per (belief, observation) the sum runs over the list in order, as before:
-    // an entry whose belief value is zero adds an exact zero.
+    // depend on the belief, so they are read once for the four.  A block walks PUSH_NT chunks of 256 states and reduces the
+    // magnitudes once at its end: with one chunk per block the per-thread work (one or two list entries) was a tenth of the
+    // block's reduction and its atomics -- 0.89 ms for 100 beliefs at the Sea-Robin shape whether or not anything was
+    // gathered or stored.  Per (belief, observation) the sum runs over the list in order, as before: an entry whose belief
+    // value is zero adds an exact zero.
     __shared__ double red[PUSH_NB][16];
-    const int sp = blockIdx.x * 256 + threadIdx.x, b0 = blockIdx.y * PUSH_NB, a = blockIdx.z;
+    const int b0 = blockIdx.y * PUSH_NB, a = blockIdx.z;
     const int nb = B - b0 < PUSH_NB ? B - b0 : PUSH_NB;
     const int G = mv.A * mv.O;
     const int32_t* ptr = in_ptr + (int64_t)a * (mv.S + 1);
     const int32_t* src = in_src + (int64_t)a * mv.S * mv.R;
-    const int j0 = sp < mv.S ? ptr[sp] : 0, j1 = sp < mv.S ? ptr[sp + 1] : 0;
-    const double am = sp < mv.S ? fabs((double)amax[sp]) : 0.0;
     for (int o0 = 0; o0 < mv.O; o0 += 4) {
         const int no = mv.O - o0 < 4 ? mv.O - o0 : 4;
-        double acc[PUSH_NB][4];
-#pragma unroll
-        for (int k = 0; k < PUSH_NB; ++k)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[k][q] = 0.0;
-        for (int j = j0; j < j1; ++j) {
-            const int e = src[j];                           // e = s * R + r
-            const int s = mv.R == 1 ? e : e / mv.R, r = e - s * mv.R;
-            double bs[PUSH_NB];
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < PUSH_NB; ++k) {
-                bs[k] = k < nb ? (double)bel[(int64_t)(b0 + k) * ldb + s] : 0.0;
-                any = any || bs[k] != 0.0;
-            }
-            if (any) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q < no) {
-                        const double w = (double)mv.rto[((int64_t)(a * mv.O + o0 + q) * mv.R + r) * mv.S_pad + s];
-#pragma unroll
-                        for (int k = 0; k < PUSH_NB; ++k) acc[k][q] += bs[k] * w;
-                    }
-            }
-        }
         double mg[PUSH_NB][4];
 #pragma unroll
         for (int k = 0; k < PUSH_NB; ++k)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                mg[k][q] = 0.0;
-                if (q < no && k < nb) {                     // uniform across the block
-                    const T val = (T)(gamma * acc[k][q]);
-                    const int64_t row = push_row_index(o0 + q, a, b0 + k, mv.A, B);      // see SlabView
-                    if (sp < ldp) bp[row * ldp + sp] = val;                         // pad columns get exact zeros
-                    mg[k][q] = fabs((double)val) * am;
+            for (int q = 0; q < 4; ++q) mg[k][q] = 0.0;
+        for (int c = 0; c < PUSH_NT; ++c) {
+            const int sp = (blockIdx.x * PUSH_NT + c) * 256 + threadIdx.x;
+            if (sp >= ldp) break;                           // (whole waves: ldp is a multiple of 32, chunks of 256)
+            const int j0 = sp < mv.S ? ptr[sp] : 0, j1 = sp < mv.S ? ptr[sp + 1] : 0;
+            const double am = sp < mv.S ? fabs((double)amax[sp]) : 0.0;
+            double acc[PUSH_NB][4];
+#pragma unroll
+            for (int k = 0; k < PUSH_NB; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[k][q] = 0.0;
+            for (int j = j0; j < j1; ++j) {
+                const int e = src[j];                       // e = s * R + r
+                const int s = mv.R == 1 ? e : e / mv.R, r = e - s * mv.R;
+                double bs[PUSH_NB];
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < PUSH_NB; ++k) {
+                    bs[k] = k < nb ? (double)bel[(int64_t)(b0 + k) * ldb + s] : 0.0;
+                    any = any || bs[k] != 0.0;
+                }
+                if (any) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q < no) {
+                            const double w = (double)mv.rto[((int64_t)(a * mv.O + o0 + q) * mv.R + r) * mv.S_pad + s];
+#pragma unroll
+                            for (int k = 0; k < PUSH_NB; ++k) acc[k][q] += bs[k] * w;
+                        }
                 }
             }
+#pragma unroll
+            for (int k = 0; k < PUSH_NB; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < no && k < nb) {                 // uniform across the block
+                        const T val = (T)(gamma * acc[k][q]);
+                        const int64_t row = push_row_index(o0 + q, a, b0 + k, mv.A, B);      // see SlabView
+                        bp[row * ldp + sp] = val;           // pad columns get exact zeros
+                        mg[k][q] += fabs((double)val) * am;
+                        if (nzP != nullptr) {               // the GEMM's zero-tile map, while the values are in registers
+                            const unsigned long long nzm = __ballot(val != T(0));
+                            const int lane = threadIdx.x & 63;
+                            if ((lane == 0 && (nzm & 0xffffffffull)) || (lane == 32 && (nzm >> 32)))
+                                nzP[(row >> 8) * (ldp >> 5) + (sp >> 5)] = 1;
+                        }
+                    }
+        }
         // magnitudes: one barrier for all beliefs and (up to four) observations of this pass
 #pragma unroll
         for (int k = 0; k < PUSH_NB; ++k)
@@ -2064,11 +2081,11 @@ __global__ void k_push_project(const T* __restrict__ bel, int ldb, int B, ModelV
 template <typename T>
 hipError_t launch_push_project(const T* bel, int ldb, int B, ModelView<T> mv, const int32_t* in_ptr,
                                const int32_t* in_src, double gamma, const T* amax, T* bp, int ldp, double* mag,
-                               hipStream_t st) {
+                               hipStream_t st, uint8_t* nzP) {
     if (B <= 0) return hipSuccess;
     if (B > 65535 || mv.A > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_push_project<T>, dim3((ldp + 255) / 256, (B + PUSH_NB - 1) / PUSH_NB, mv.A), dim3(256), 0, st, bel, ldb, B, mv, in_ptr,
-                       in_src, gamma, amax, bp, ldp, mag);
+    hipLaunchKernelGGL(k_push_project<T>, dim3((ldp + 256 * PUSH_NT - 1) / (256 * PUSH_NT), (B + PUSH_NB - 1) / PUSH_NB, mv.A), dim3(256), 0, st, bel, ldb, B, mv, in_ptr,
+                       in_src, gamma, amax, bp, ldp, mag, nzP);
     return hipGetLastError();
 }
 
@@ -2269,7 +2286,7 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
                                                 const int32_t*, const int32_t*, const int32_t*, double*, double*, T*,  \
                                                 int, hipStream_t);                                                     \
     template hipError_t launch_push_project<T>(const T*, int, int, ModelView<T>, const int32_t*, const int32_t*,       \
-                                               double, const T*, T*, int, double*, hipStream_t);                      \
+                                               double, const T*, T*, int, double*, hipStream_t, uint8_t*);                      \
     template hipError_t launch_rdot<T>(const T*, int, int, ModelView<T>, const int32_t*, const int32_t*, double*,      \
                                        hipStream_t);                                                                   \
     template hipError_t launch_walk_step<T>(const double*, ModelView<T>, const double*, const int32_t*, const int32_t*, \

@@ -2652,12 +2652,22 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
         HIPCHK(hipMemcpyAsync(bp_.as<T>() + (size_t)M * S_pad_, bel_.p, (size_t)B_ * S_pad_ * sizeof(T), hipMemcpyDeviceToDevice, stream_));
         if (M_pad > Mx)
             HIPCHK(hipMemsetAsync(bp_.as<T>() + (size_t)Mx * S_pad_, 0, (size_t)(M_pad - Mx) * S_pad_ * sizeof(T), stream_));
+        // the GEMM's zero-tile map of bp: the projection marks the tiles of its own rows while it writes them; only the row
+        // tiles that also hold the belief rows / the pad are scanned afterwards (a pass over all of bp was 0.18 ms at the
+        // Sea-Robin shape)
+        HIPCHK(hipMemsetAsync(nzP_.p, 0, (size_t)(M_pad / GEMM_BM) * k_tiles, stream_));
         HIPCHK(launch_push_project<T>(bel_.as<T>(), S_pad_, (int)B_, mv, in_ptr_.as<int32_t>(), in_src_.as<int32_t>(), gamma,
-                                      alpha_.as<T>() + (size_t)V_ * S_pad_, bp_.as<T>(), S_pad_, pmag_.as<double>(), stream_));
-        if constexpr (kF32)
-            HIPCHK(launch_tile_nonzero_f32((const float*)bp_.p, S_pad_, (int)M_pad, k_tiles, nzP_.as<uint8_t>(), stream_));
-        else
-            HIPCHK(launch_tile_nonzero_f64((const double*)bp_.p, S_pad_, (int)M_pad, k_tiles, nzP_.as<uint8_t>(), stream_));
+                                      alpha_.as<T>() + (size_t)V_ * S_pad_, bp_.as<T>(), S_pad_, pmag_.as<double>(), stream_,
+                                      nzP_.as<uint8_t>()));
+        {
+            const int64_t t0 = M / GEMM_BM;                  // first row tile with a row that is not a projected one
+            const T* from = bp_.as<T>() + (size_t)t0 * GEMM_BM * S_pad_;
+            uint8_t* to = nzP_.as<uint8_t>() + (size_t)t0 * k_tiles;
+            if constexpr (kF32)
+                HIPCHK(launch_tile_nonzero_f32((const float*)from, S_pad_, (int)(M_pad - t0 * GEMM_BM), k_tiles, to, stream_));
+            else
+                HIPCHK(launch_tile_nonzero_f64((const double*)from, S_pad_, (int)(M_pad - t0 * GEMM_BM), k_tiles, to, stream_));
+        }
         HIPCHK(hipEventRecord(io.ev[1], stream_));
         if ((rc = score_gemm(alpha_.as<T>(), V_, nullptr, 1, (int)V_, &sv, bp_.as<T>(), Mx, nzP_.as<uint8_t>()))) return rc;
         out->extra_row0 = M;
