@@ -43,6 +43,9 @@ struct SlabView {
     const int* nchunks;   // [tiles_n][tiles_m] or nullptr
     int tiles_m;
     int fixed;
+    // Stream-K layout (GemmPlan::c_floats): chunk 0 of every pair in the full slab, chunk z >= 1 of pair p in the 256 x 256
+    // tile of block first_block[p] + z behind it; nullptr: chunk z at slabs + z * slab_stride.
+    const int* first_block = nullptr;   // [tiles_n][tiles_m]
     // Belief-side formulation (beliefs projected, not alpha-vectors): rows are (observation, action, belief) =
     // ((o * A + a) * push_B + b) -- observation-major, so the rows of a rarely-seen observation (near-empty after
     // the RTO product) share 256-row tiles and those tiles are skipped -- columns are the alpha index; the
@@ -53,8 +56,17 @@ struct SlabView {
     const double* aux_rd = nullptr;    // [B][A]  b . ER[:,a], accumulated in f64
     __device__ __forceinline__ T at(int64_t row, int64_t col) const {
         const T* p = slabs + row * ldc + col;
-        const int n = nchunks ? nchunks[(col >> 8) * tiles_m + (row >> 8)] : fixed;
+        const int64_t pair = nchunks ? (col >> 8) * tiles_m + (row >> 8) : 0;
+        const int n = nchunks ? nchunks[pair] : fixed;
         T s = T(0);
+        if (first_block != nullptr) {
+            if (n > 0) s += p[0];
+            if (n > 1) {
+                const T* x = slabs + slab_stride + (int64_t)(first_block[pair] + 1) * (256 * 256) + (row & 255) * 256 + (col & 255);
+                for (int z = 1; z < n; ++z, x += 256 * 256) s += *x;
+            }
+            return s;
+        }
         for (int z = 0; z < n; ++z) s += p[(int64_t)z * slab_stride];
         return s;
     }

@@ -715,12 +715,14 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
         // four 256-column steps at a time: their slab counts first, then their first slabs, then what further slabs
         // there are -- two rounds of independent loads per 1024 columns instead of eight dependent ones
         for (int c00 = lane * 4; c00 < V; c00 += 1024) {
-            int n[4];
+            int n[4], fb[4];
             F4 acc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c0 = c00 + 256 * j;
-                n[j] = c0 < V ? sv.nchunks[((col0 + c0) >> 8) * sv.tiles_m + tm] : 0;
+                const int64_t pair = ((col0 + c0) >> 8) * sv.tiles_m + tm;
+                n[j] = c0 < V ? sv.nchunks[pair] : 0;
+                fb[j] = (c0 < V && sv.first_block != nullptr) ? sv.first_block[pair] : 0;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -729,8 +731,16 @@ __global__ void k_argmax(SlabView<T> sv, int V, int G, int B, const uint8_t* __r
                 if (n[j] > 0) acc[j] = acc[j] + *(const F4*)(rowp + c00 + 256 * j);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                for (int z = 1; z < n[j]; ++z) acc[j] = acc[j] + *(const F4*)(rowp + c00 + 256 * j + (int64_t)z * sv.slab_stride);
+            for (int j = 0; j < 4; ++j) {
+                if (n[j] <= 1) continue;
+                if (sv.first_block != nullptr) {             // continuation tiles behind the full slab (SlabView)
+                    const float* x = (const float*)sv.slabs + sv.slab_stride + (int64_t)(fb[j] + 1) * (256 * 256) +
+                                     (row & 255) * 256 + ((col0 + c00 + 256 * j) & 255);
+                    for (int z = 1; z < n[j]; ++z, x += 256 * 256) acc[j] = acc[j] + *(const F4*)x;
+                } else {
+                    for (int z = 1; z < n[j]; ++z) acc[j] = acc[j] + *(const F4*)(rowp + c00 + 256 * j + (int64_t)z * sv.slab_stride);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c0 = c00 + 256 * j;

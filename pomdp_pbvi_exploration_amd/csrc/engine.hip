@@ -2352,7 +2352,7 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
         if (m_pad > 0x7fffffff || n_pad > 0x7fffffff) FAIL(PBVI_EUNSUPPORTED, "score_gemm: operand rows exceed int32");
         plan_ = make_gemm_plan((int)m_pad, (int)n_pad, S_pad_);
         const size_t pairs = (size_t)plan_.tiles_m * plan_.tiles_n;
-        if ((rc = slabs_.ensure((size_t)plan_.max_chunks * plan_.slab_stride * sizeof(float), &bytes_))) return rc;
+        if ((rc = slabs_.ensure((size_t)plan_.c_floats * sizeof(float), &bytes_))) return rc;
         if ((rc = klist_.ensure(pairs * plan_.k_tiles * sizeof(int), &bytes_))) return rc;
         if ((rc = kcount_.ensure(pairs * sizeof(int), &bytes_))) return rc;
         if ((rc = nchunks_.ensure(pairs * sizeof(int), &bytes_))) return rc;
@@ -2367,6 +2367,9 @@ int EngineT<T>::score_gemm(const T* Y, int64_t rows_y, const uint8_t* nzB, int G
         sv->nchunks = nchunks_.as<int>();
         sv->tiles_m = plan_.tiles_m;
         sv->fixed = 0;
+        // (the stream-K plan's first_block array: launch_gemm_nt_f32 lays the workspace out as prefix[pairs + 1],
+        // start_pair[nblocks], first_block[pairs], plan[2])
+        sv->first_block = plan_.streamk ? skws_.as<int>() + (pairs + 1) + plan_.nblocks : nullptr;
     } else {
         const int kt32s = S_pad_ / GEMM_BK;
         const int split = f64_uses_mfma(m_rows, rows_y) ? gemm_f64_split((int)m_rows, (int)rows_y, kt32s) : 1;
@@ -2550,10 +2553,9 @@ bool EngineT<T>::choose_push(int64_t N) const {
     const int64_t n_pull = kF32 ? round_up(N, GEMM_BN) : N, m_push = round_up((int64_t)B_ * AO + B_, GEMM_BM);
     const int64_t gam_new = gamma_compact ? 0 : std::max<int64_t>(0, n_pull * row - (int64_t)gam_.cap);
     if (gam_new > ((int64_t)1 << 28)) {
-        // the score slabs count too: [rows][columns] partial sums, one slab per K part (stream-K: up to 9)
+        // the score slabs count too
         auto slabs = [&](int64_t m, int64_t n) {
-            if constexpr (kF32) return (int64_t)make_gemm_plan((int)round_up(m, GEMM_BM), (int)round_up(n, GEMM_BN), S_pad_).max_chunks *
-                                       round_up(m, GEMM_BM) * round_up(n, GEMM_BN) * 4;
+            if constexpr (kF32) return make_gemm_plan((int)round_up(m, GEMM_BM), (int)round_up(n, GEMM_BN), S_pad_).c_floats * 4;
             else return (int64_t)gemm_f64_split((int)m, (int)n, S_pad_ / GEMM_BK) * m * n * 8;
         };
         const int64_t pull = gam_new + std::max<int64_t>(0, slabs(B_, N) - (int64_t)slabs_.cap);

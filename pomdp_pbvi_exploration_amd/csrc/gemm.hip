@@ -299,7 +299,9 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk(
             tile_zero(acc);
             tile_run(t, lds, A + (int64_t)tm * 256 * lda, lda, B + (int64_t)tn * 256 * ldb, ldb,
                      klist + (int64_t)p * k_tiles, lo, hi, acc);
-            tile_store(t, C + (int64_t)(L - first_block[p]) * slab_stride, ldc, tm, tn, acc);
+            // first chunk of the pair: the full slab; a continuation: this block's tile behind it (GemmPlan::c_floats)
+            const bool cont = L != first_block[p];
+            tile_store(t, cont ? C + slab_stride + (int64_t)L * (256 * 256) : C, cont ? 256 : ldc, cont ? 0 : tm, cont ? 0 : tn, acc);
         }
         pos += u_hi - u_lo;
         ++p;
@@ -491,7 +493,9 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk_fused(
                                (int64_t)64 * fb.lda, fb.gamma,
                                klist + (int64_t)p * k_tiles, lo, hi, acc);
             }
-            tile_store(t, C + (int64_t)(L - first_block[p]) * slab_stride, ldc, tm, tn, acc);
+            // first chunk of the pair: the full slab; a continuation: this block's tile behind it (GemmPlan::c_floats)
+            const bool cont = L != first_block[p];
+            tile_store(t, cont ? C + slab_stride + (int64_t)L * (256 * 256) : C, cont ? 256 : ldc, cont ? 0 : tm, cont ? 0 : tn, acc);
         }
         pos += u_hi - u_lo;
         ++p;
@@ -725,7 +729,9 @@ __global__ __launch_bounds__(512) void k_gemm_nt_f32_streamk_fused_r(
                                  fb.S_pad, fb.alpha + (int64_t)(v0 + t.srow[0]) * fb.lda, (int64_t)64 * fb.lda, fb.gamma,
                                  klist + (int64_t)p * k_tiles, lo, hi, acc);
             }
-            tile_store(t, C + (int64_t)(L - first_block[p]) * slab_stride, ldc, tm, tn, acc);
+            // first chunk of the pair: the full slab; a continuation: this block's tile behind it (GemmPlan::c_floats)
+            const bool cont = L != first_block[p];
+            tile_store(t, cont ? C + slab_stride + (int64_t)L * (256 * 256) : C, cont ? 256 : ldc, cont ? 0 : tm, cont ? 0 : tn, acc);
         }
         pos += u_hi - u_lo;
         ++p;
@@ -978,10 +984,13 @@ GemmPlan make_gemm_plan(int M_pad, int N_pad, int K_pad, bool single_chunk) {
         const int max_split = 8;
         pl.chunk_len = pl.k_tiles;          // only used for the (overwritten) provisional nchunks
         pl.max_chunks = max_split + 1;
+        pl.c_floats = pl.slab_stride + (int64_t)pl.nblocks * (256 * 256);
+        return pl;
     } else {
         pl.chunk_len = choose_chunk_len(pl.tiles_m * pl.tiles_n, pl.k_tiles);
         pl.max_chunks = (pl.k_tiles + pl.chunk_len - 1) / pl.chunk_len;
     }
+    pl.c_floats = (int64_t)pl.max_chunks * pl.slab_stride;
     return pl;
 }
 

@@ -30,6 +30,11 @@ struct GemmPlan {
     int64_t slab_stride;
     bool streamk;      // persistent stream-K scheduler (score GEMMs); else one block per (pair, chunk)
     int nblocks;       // stream-K grid = CUs of the device
+    // Floats of C to allocate.  One block per (pair, chunk): max_chunks full slabs.  Stream-K: ONE full slab (every pair's
+    // first chunk) + one 256 x 256 tile per block behind it -- a block continues at most one pair that an earlier block
+    // began (the first pair of its share), so chunk z >= 1 of pair p lives in the tile of block first_block[p] + z
+    // (9 full slabs were allocated for the <= nblocks continuation tiles that exist: 690 MB instead of 140 at C4).
+    int64_t c_floats;
 };
 int set_gemm_force_dense(int enable);   // returns the previous setting (see gemm.hip)
 int gemm_force_dense();
