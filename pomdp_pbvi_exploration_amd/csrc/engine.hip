@@ -2249,7 +2249,8 @@ class EngineT : public EngineBase {
         w->ib_idx = rf_ibi_.as<int32_t>();
         w->cnt = rf_cnt_.as<int>();
         {   // hand-over to k_refine_split (entries the level-1 screen leaves undecided; ~1 % of the queue)
-            const int64_t q2 = std::min<int64_t>(max_entries, 16384);
+            int64_t q2 = std::min<int64_t>(max_entries, 16384);
+            if (const char* c = getenv("PBVI_REFINE_Q2_CAP")) q2 = std::max<int64_t>(1, std::min<int64_t>(q2, atoll(c)));   // tests: force the hand-over's overflow path
             const size_t need = (size_t)q2 * (2 + 8) * sizeof(int32_t);
             if ((rc = rf_q2_.ensure(need, &bytes_))) return rc;
             if ((rc = rf_q2p_.ensure((size_t)q2 * 16 * 8 * sizeof(double), &bytes_))) return rc;

@@ -1866,3 +1866,27 @@ def test_backup_that_does_not_fit_is_done_in_belief_chunks():
         rg, ag = key(got)
         assert rw.shape == rg.shape and np.array_equal(aw, ag)
         np.testing.assert_allclose(rg, rw, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize('q2_cap', [None, 3])
+def test_duplicate_rows_through_the_level1_screen_and_the_split_rescoring(q2_cap, monkeypatch):
+    """An alpha set in which every row has a twin (and some a triplet): on an fp32 engine with projected rows in HBM (R = 5)
+    the level-1 screen of the refinement cannot separate the twins, so every queued entry goes to ``k_refine_split`` -- or,
+    with room for only 3 entries in the hand-over, most of them stay with the entry's own block.  Either way the first of
+    the tied rows wins, as in the reference (np.argmax)."""
+    if q2_cap is not None:
+        monkeypatch.setenv('PBVI_REFINE_Q2_CAP', str(q2_cap))
+    z, rs, rto, er = small(5)
+    S, A, Rr = rs.shape
+    base = z['alpha'].astype(np.float32)
+    alpha = np.concatenate([base, base, base[:7]]).astype(np.float64)          # row v, its twin at v + V, triplets for v < 7
+    b = z['beliefs'].astype(np.float64)
+    gamma = float(z['gamma'])
+    want_rows, want_a, want_v = orc.backup_core(alpha, b, rs, rto, er, gamma)
+    assert want_v.max() < len(base)                                           # the reference picks the first of the tied rows
+    eng = Engine(S, A, rto.shape[2], Rr, rs, rto, er, dtype='f32')
+    res = eng.backup_full(alpha.astype(np.float32), b.astype(np.float32), gamma)
+    assert np.array_equal(res.best_alpha_ind, want_v) and np.array_equal(res.actions, want_a)
+    np.testing.assert_allclose(res.alpha, want_rows, rtol=1e-6, atol=1e-7)
+    assert res.stats['n_refined'] > 0
+    eng.close()
