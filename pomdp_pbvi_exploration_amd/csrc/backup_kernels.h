@@ -210,14 +210,15 @@ hipError_t launch_tail_rows(ModelView<T> mv, T* gam /* row 0 */, int64_t row0 /*
 template <typename T>
 hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, const int* chain_steps,
                          const double* best_score, const double* err, double* rdot, double* rdot_err, int32_t* action,
-                         int32_t* aqueue, int* aqcount, hipStream_t st, double tol_extra = 0.0);
+                         int32_t* aqueue, int* aqcount, hipStream_t st, double tol_extra = 0.0,
+                         uint8_t* acand = nullptr /* [B][A] out: action inside the window of the best lower bound */);
 constexpr int ACTION_SPLIT = 8;          // parts each exact dot of the action refinement is cut into (val_exact: [B][A][1+O][ACTION_SPLIT])
 template <typename T>
 hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, int lda, ModelView<T> mv, double gamma,
                                 const int32_t* btl, const int32_t* btc, const int32_t* aqueue, const int* aqcount,
                                 const double* rdot, const double* rdot_err, const int32_t* best_v,
                                 const double* best_score, const double* err, double* val_exact /* [B][A][1+O][ACTION_SPLIT] scratch */,
-                                int32_t* action, hipStream_t st);
+                                int32_t* action, hipStream_t st, const uint8_t* acand = nullptr /* launch_action's */);
 
 // K3: out[u][s] = ER[s,a*] + sum_o gamma * sum_r rto[a*][o][r][s] * alpha[v*[b,a*,o]][rs[a*][r][s]], b = rows[u]
 // (rows/n_rows on the device: only the unique (a*, v*) keys are assembled; nullptr = every belief)

@@ -1560,7 +1560,8 @@ template <typename T>
 __global__ void k_action_select(int B, int per_block, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, double tol_extra,
                                 const int* __restrict__ chain_steps, const double* __restrict__ best_score,
                                 const double* __restrict__ err, double* __restrict__ rdot, double* __restrict__ rdot_err,
-                                int32_t* __restrict__ action, int32_t* __restrict__ aqueue, int* __restrict__ aqcount) {
+                                int32_t* __restrict__ action, int32_t* __restrict__ aqueue, int* __restrict__ aqcount,
+                                uint8_t* __restrict__ acand /* [B][A]: action within the window of the best lower bound (or nullptr) */) {
     __shared__ double sv_[256], se_[256];
     const int A = mv.A;
     const int lb = threadIdx.x / A, a = threadIdx.x - lb * A;
@@ -1609,6 +1610,7 @@ __global__ void k_action_select(int B, int per_block, ModelView<T> mv, SlabView<
                 ++ncand;
                 anyerr |= (E > 0.0);
             }
+            if (acand != nullptr) acand[(int64_t)b * A + x] = (v + E >= lo) ? 1 : 0;
         }
         if (ncand > 1 && anyerr) aqueue[atomicAdd(aqcount, 1)] = b;
     }
@@ -1617,12 +1619,12 @@ __global__ void k_action_select(int B, int per_block, ModelView<T> mv, SlabView<
 template <typename T>
 hipError_t launch_action(int B, ModelView<T> mv, SlabView<T> sv, int64_t rd_col0, double tol_rel, const int* chain_steps,
                          const double* best_score, const double* err, double* rdot, double* rdot_err, int32_t* action,
-                         int32_t* aqueue, int* aqcount, hipStream_t st, double tol_extra) {
+                         int32_t* aqueue, int* aqcount, hipStream_t st, double tol_extra, uint8_t* acand) {
     if (B <= 0) return hipSuccess;
     if (mv.A > 256) return hipErrorInvalidValue;
     const int per_block = 256 / mv.A;
     hipLaunchKernelGGL(k_action_select<T>, dim3((B + per_block - 1) / per_block), dim3(256), 0, st, B, per_block, mv, sv, rd_col0,
-                       tol_rel, tol_extra, chain_steps, best_score, err, rdot, rdot_err, action, aqueue, aqcount);
+                       tol_rel, tol_extra, chain_steps, best_score, err, rdot, rdot_err, action, aqueue, aqcount, acand);
     return hipGetLastError();
 }
 
@@ -1640,7 +1642,8 @@ __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __r
                                 const int32_t* __restrict__ btc, const int32_t* __restrict__ aqueue, const int* __restrict__ aqcount,
                                 const double* __restrict__ rdot, const double* __restrict__ rdot_err,
                                 const int32_t* __restrict__ best_v, const double* __restrict__ best_score,
-                                const double* __restrict__ err, double* __restrict__ val_parts /* [B][A][1+O] */) {
+                                const double* __restrict__ err, double* __restrict__ val_parts /* [B][A][1+O] */,
+                                const uint8_t* __restrict__ acand /* k_action_select's window test per (belief, action), or nullptr */) {
     __shared__ double red[4];
     __shared__ int cand_sh;
     const int n_q = *aqcount;
@@ -1649,7 +1652,9 @@ __global__ void k_refine_action(const T* __restrict__ bel, int ldb, const T* __r
     for (int q = blockIdx.x; q < n_q; q += gridDim.x) {
         const int b = aqueue[q];
         __syncthreads();
-        if (tid == 0) {   // is action a within the error window of the best lower bound?
+        if (tid == 0 && acand != nullptr) {
+            cand_sh = acand[(int64_t)b * mv.A + a];
+        } else if (tid == 0) {   // is action a within the error window of the best lower bound?
             double lo = -std::numeric_limits<double>::infinity(), va = 0.0, Ea = 0.0;
             for (int x = 0; x < mv.A; ++x) {
                 double v = rdot[(int64_t)b * mv.A + x], E = rdot_err[(int64_t)b * mv.A + x];
@@ -1721,13 +1726,15 @@ hipError_t launch_refine_action(const T* bel, int ldb, int B, const T* alpha, in
                                 const int32_t* btl, const int32_t* btc, const int32_t* aqueue, const int* aqcount,
                                 const double* rdot, const double* rdot_err, const int32_t* best_v,
                                 const double* best_score, const double* err, double* val_exact, int32_t* action,
-                                hipStream_t st) {
+                                hipStream_t st, const uint8_t* acand) {
     if (B <= 0) return hipSuccess;
     const int terms = 1 + mv.O;
     if ((int64_t)mv.A * terms > 65535) return hipErrorInvalidValue;
-    const int gx = B < 512 ? B : 512;                           // queued beliefs are few: a bounded grid strides over them
+    // queued beliefs are few (two dozen of 1024 at C4): a bounded grid strides over them.  (512 x 24 x 8 blocks, of which 23 x 24 x 8
+    // had work, spent 15 of the kernel's 28 us dispatching empty blocks.)
+    const int gx = B < 64 ? B : 64;
     hipLaunchKernelGGL(k_refine_action<T>, dim3(gx, mv.A * terms, ACTION_SPLIT), dim3(256), 0, st, bel, ldb, alpha, lda, mv, gamma, btl, btc,
-                       aqueue, aqcount, rdot, rdot_err, best_v, best_score, err, val_exact);
+                       aqueue, aqcount, rdot, rdot_err, best_v, best_score, err, val_exact, acand);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_action_final, dim3((B + 255) / 256), dim3(256), 0, st, mv.A, terms, aqueue, aqcount, val_exact, action);
@@ -2282,11 +2289,11 @@ hipError_t launch_walk_step(const double* base, ModelView<T> mv, const double* r
                                          const T*, int, ModelView<T>, double, const int32_t*, const int32_t*,          \
                                          const uint8_t*, int32_t*, double*, double*, int*, RefineWork, hipStream_t);   \
     template hipError_t launch_action<T>(int, ModelView<T>, SlabView<T>, int64_t, double, const int*, const double*,   \
-                                         const double*, double*, double*, int32_t*, int32_t*, int*, hipStream_t, double); \
+                                         const double*, double*, double*, int32_t*, int32_t*, int*, hipStream_t, double, uint8_t*); \
     template hipError_t launch_refine_action<T>(const T*, int, int, const T*, int, ModelView<T>, double,               \
                                                 const int32_t*, const int32_t*, const int32_t*, const int*,            \
                                                 const double*, const double*, const int32_t*, const double*,           \
-                                                const double*, double*, int32_t*, hipStream_t);                        \
+                                                const double*, double*, int32_t*, hipStream_t, const uint8_t*);                        \
     template hipError_t launch_assemble<T>(const T*, int, ModelView<T>, double, const int32_t*, const int32_t*,        \
                                            const int32_t*, const int*, int, T*, int, hipStream_t);                     \
     template hipError_t launch_expand_rows<T>(const T*, const int32_t*, T*, int, int, hipStream_t);                    \

@@ -720,6 +720,7 @@ class EngineT : public EngineBase {
     void* host_stage_ = nullptr;                            // pinned bounce buffer for rows going to pageable host memory
     size_t host_stage_cap_ = 0;
     DevBuf keys_tmp_, keys_act_, keys_best_, keys_rows_;    // unique-row keys out / rows from keys in (multi-GPU exchange)
+    DevBuf acand_;                                           // [B][A] action inside the window (k_action_select -> k_refine_action)
     DevBuf rf_q2_, rf_q2p_, rf_q2d_;                         // k_refine_split: entries / candidates, partial scores, arrival counters
     DevBuf rf_v_, rf_slot_, rf_sc_, rf_entry_, rf_n_, rf_tiles_, rf_ibv_, rf_ibi_, rf_cnt_, rf_W_, rf_Cx_, rf_nzW_, rf_klW_, rf_kcW_;   // refinement work list
     int formulation_ = 0;                                   // 0 auto, 1 project alpha-vectors, 2 project beliefs
@@ -805,7 +806,7 @@ class EngineT : public EngineBase {
                          &action_res_, &best_res_, &rep_, &uniq_, &inv_, &slot_, &out_full_, &btl_, &btc_, &val_exact_, &store_[0], &store_[1], &ids_, &in_ptr_, &in_src_, &bu_act_, &bu_obs_,
                          &bu_unnorm_, &bu_mass_, &bu_out_, &bu_row_, &walk64_, &rto64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_, &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_,
                          &snz_, &sbtl_, &sbtc_, &vmax_bk_, &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_,
-                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_, &scr_flag_, &ctile_, &rf_q2_, &rf_q2p_, &rf_q2d_, &e_bv_, &e_bs_, &e_err_, &e_rdot_, &e_act_, &e_ares_, &e_bres_, &e_rep_, &e_uniq_, &e_inv_, &e_slotd_, &e_cnt_, &e_out_, &e_slot_};
+                         &dense_, &nzD_, &nzAlpha_, &prod_, &klistD_, &kcountD_, &nchunksD_, &mat_, &vlist_, &irr_, &rowflags_, &nzBw_, &scr_flag_, &ctile_, &acand_, &rf_q2_, &rf_q2p_, &rf_q2d_, &e_bv_, &e_bs_, &e_err_, &e_rdot_, &e_act_, &e_ares_, &e_bres_, &e_rep_, &e_uniq_, &e_inv_, &e_slotd_, &e_cnt_, &e_out_, &e_slot_};
         // every call is checked only to name a failure when PBVI_DEBUG is set; the thread's sticky last-error is cleared at
         // the end either way, so that a later launch check does not report a stale error of this teardown
         static const bool dbg = getenv("PBVI_DEBUG") != nullptr;
@@ -1575,7 +1576,7 @@ class EngineT : public EngineBase {
                           &bu_mass_, &bu_out_, &bu_row_, &walk64_, &bp_, &nzP_, &pmag_, &prd_, &keys_tmp_, &keys_act_, &keys_best_,
                           &keys_rows_, &rf_v_, &rf_slot_, &rf_sc_, &rf_entry_, &rf_n_, &rf_tiles_, &snz_, &sbtl_, &sbtc_, &vmax_bk_,
                           &rf_ibv_, &rf_ibi_, &rf_cnt_, &rf_W_, &rf_Cx_, &rf_nzW_, &rf_klW_, &rf_kcW_, &nzAlpha_, &prod_, &klistD_,
-                          &kcountD_, &nchunksD_, &mat_, &vlist_, &rowflags_, &ctile_, &rf_q2_, &rf_q2p_, &rf_q2d_, &e_bv_, &e_bs_, &e_err_, &e_rdot_, &e_act_, &e_ares_, &e_bres_, &e_rep_, &e_uniq_, &e_inv_, &e_slotd_, &e_out_, &e_slot_};
+                          &kcountD_, &nchunksD_, &mat_, &vlist_, &rowflags_, &ctile_, &acand_, &rf_q2_, &rf_q2p_, &rf_q2d_, &e_bv_, &e_bs_, &e_err_, &e_rdot_, &e_act_, &e_ares_, &e_bres_, &e_rep_, &e_uniq_, &e_inv_, &e_slotd_, &e_out_, &e_slot_};
         for (DevBuf* b : drop) {
             bytes_ -= (int64_t)b->cap;
             b->release();
@@ -2892,6 +2893,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     if ((rc = rdot_.ensure((size_t)B_ * A_ * 2 * sizeof(double), &bytes_))) return rc;
     if ((rc = action_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
     if ((rc = aqueue_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
+    if ((rc = acand_.ensure((size_t)B_ * A_, &bytes_))) return rc;
     if ((rc = out_.ensure((size_t)B_ * S_ * sizeof(T), &bytes_))) return rc;
     if ((rc = keep_.ensure((size_t)B_, &bytes_))) return rc;
     int* qcount = counters_.as<int>();
@@ -3104,13 +3106,14 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         double* rdot_err = rdot_.as<double>() + (size_t)B_ * A_;
         HIPCHK(launch_action<TS>((int)B_, scorer.view(), sv, sc.rd_col0, sc.tol_rel, sc.chain, best_score_.as<double>(),
                                  err_.as<double>(), rdot_.as<double>(), rdot_err, action_.as<int32_t>(),
-                                 windows ? aqueue_.as<int32_t>() : nullptr, aqcount, stream_, io.tol_extra));
+                                 windows ? aqueue_.as<int32_t>() : nullptr, aqcount, stream_, io.tol_extra,
+                                 windows ? acand_.as<uint8_t>() : nullptr));
         if (windows)
             HIPCHK(launch_refine_action<T>(bel_.as<T>(), S_pad_, (int)B_, alpha_.as<T>(), S_pad_, mv, gamma,
                                            btl_.as<int32_t>(), btc_.as<int32_t>(),
                                            aqueue_.as<int32_t>(), aqcount, rdot_.as<double>(), rdot_err, best_v_.as<int32_t>(),
                                            best_score_.as<double>(), err_.as<double>(), val_exact_.as<double>(),
-                                           action_.as<int32_t>(), stream_));
+                                           action_.as<int32_t>(), stream_, acand_.as<uint8_t>()));
         HIPCHK(hipEventRecord(ev_[5], stream_));
         // results to the caller's belief order, then K6: dedup by (a*, v*) key
         if (sorted_) {
