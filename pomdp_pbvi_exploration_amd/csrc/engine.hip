@@ -532,6 +532,24 @@ __global__ void k_unpermute(int B, int AO, const int32_t* __restrict__ perm, con
 }
 
 // ---- early rows (pbvi_backup_run_fetch) ---------------------------------------------------------------------------- //
+// The small results of a run_fetch step -- slot, index and action per belief, the call's counters -- stored straight into the
+// caller's page-locked arrays and the engine's pinned flag words by one kernel: five D2H copies of 4 KB or less (one of them
+// into pageable stack memory) cost the end of every step ~25 us of copy-engine round trips.
+__global__ void k_publish(int B, const int32_t* __restrict__ slot, const int32_t* __restrict__ index, const int32_t* __restrict__ action,
+                          int32_t* __restrict__ h_slot, int32_t* __restrict__ h_index, int32_t* __restrict__ h_action,
+                          const int* __restrict__ counters /* 8 */, const int* __restrict__ e_cnt /* 3 */,
+                          const int* __restrict__ scr_flag /* or nullptr */, int* __restrict__ h_flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B) {
+        h_slot[i] = slot[i];
+        h_index[i] = index[i];
+        h_action[i] = action[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) h_flag[16 + threadIdx.x] = counters[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 11) h_flag[4 + threadIdx.x - 8] = e_cnt[threadIdx.x - 8];
+    if (blockIdx.x == 0 && threadIdx.x == 11 && scr_flag != nullptr) h_flag[1] = scr_flag[0];
+}
+
 // One block per distinct key u of the FINAL result: is it among the provisional keys (whose rows are on their way to the
 // host already)?  Yes: slot[u] = its provisional position.  No: the row gets the next free slot behind the provisional
 // ones and this block copies it there.  cnt[0] = provisional keys, cnt[1] += new rows, cnt[2] = 1 on overflow of the slots.
@@ -1178,7 +1196,7 @@ class EngineT : public EngineBase {
     // one page-locked int for flags read back with the results (a stack variable would be written by the copy after an
     // early error return had released it)
     int* pinned_flag() {
-        if (!h_flag_ && hipHostMalloc((void**)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) {
+        if (!h_flag_ && hipHostMalloc((void**)&h_flag_, 128, hipHostMallocDefault) != hipSuccess) {   // 32 ints: [16..23] = run_fetch's counters
             (void)hipGetLastError();
             h_flag_ = nullptr;
         }
@@ -3102,6 +3120,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     int* ucount = counters_.as<int>() + 3;
     int h_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // all counters in the one read-back that precedes the final sync
     auto later_stages = [&]() -> int {
+        bool publish = false;
         // K4: action
         double* rdot_err = rdot_.as<double>() + (size_t)B_ * A_;
         HIPCHK(launch_action<TS>((int)B_, scorer.view(), sv, sc.rd_col0, sc.tol_rel, sc.chain, best_score_.as<double>(),
@@ -3145,7 +3164,10 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
             HIPCHK(hipGetLastError());
             int* f = pinned_flag();
             if (!f) FAIL(PBVI_ENOMEM, "run_fetch: pinned flag");
-            HIPCHK(hipMemcpyAsync(f + 4, e_cnt_.p, 3 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            publish = rf_dst_.slot != nullptr && !(flags & PBVI_BELIEF_DOMINANCE) && rf_dst_.best == nullptr && rf_dst_.keep == nullptr &&
+                      is_pinned_host_pointer(rf_dst_.slot) && is_pinned_host_pointer(rf_dst_.index) &&
+                      is_pinned_host_pointer(rf_dst_.action);
+            if (!publish) HIPCHK(hipMemcpyAsync(f + 4, e_cnt_.p, 3 * sizeof(int), hipMemcpyDeviceToHost, stream_));
         }
         HIPCHK(hipEventRecord(ev_[6], stream_));
         if (xr_pending) {                            // the extra rows' maxima read the slabs K5's GEMM is about to overwrite
@@ -3162,6 +3184,18 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
             HIPCHK(hipMemsetAsync(keep_.p, 1, (size_t)B_, stream_));
         }
         rf_dst_.queued = false;
+        if (publish) {                                       // run_fetch into page-locked arrays: one kernel stores everything small
+            int* f = pinned_flag();
+            hipLaunchKernelGGL(k_publish, dim3((unsigned)((B_ + 255) / 256)), dim3(256), 0, stream_, (int)B_, e_slot_.as<int32_t>(),
+                               inv_.as<int32_t>(), res_action_, (int32_t*)rf_dst_.slot, (int32_t*)rf_dst_.index, (int32_t*)rf_dst_.action,
+                               counters_.as<int>(), e_cnt_.as<int>(), (screened && scr_flag_.p) ? scr_flag_.as<int>() : nullptr, f);
+            HIPCHK(hipGetLastError());
+            rf_dst_.queued = true;
+            HIPCHK(hipEventRecord(ev_[7], stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            std::memcpy(h_cnt, f + 16, sizeof(h_cnt));
+            return PBVI_OK;
+        }
         if (early_used_ && rf_dst_.slot != nullptr) {        // run_fetch: slots, index, actions (best, keep) with this read-back
             int rc2;
             if ((rc2 = out_begin())) return rc2;
@@ -3173,13 +3207,15 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
             if (rf_dst_.keep && (rc2 = out_add(rf_dst_.keep, keep_.p, (size_t)B_))) return rc2;
             rf_dst_.queued = true;
         }
-        HIPCHK(hipMemcpyAsync(h_cnt, counters_.p, sizeof(h_cnt), hipMemcpyDeviceToHost, stream_));
+        int* fc = pinned_flag();                             // (page-locked words: a copy into the stack array is staged by the runtime)
+        HIPCHK(hipMemcpyAsync(fc ? (void*)(fc + 16) : (void*)h_cnt, counters_.p, sizeof(h_cnt), hipMemcpyDeviceToHost, stream_));
         if constexpr (screened) {   // did an alpha value leave the fp32 range when the screen's copy was made?
             int* f = pinned_flag();
             if (f && scr_flag_.p) HIPCHK(hipMemcpyAsync(f + 1, scr_flag_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
         }
         HIPCHK(hipEventRecord(ev_[7], stream_));
         HIPCHK(hipStreamSynchronize(stream_));
+        if (fc) std::memcpy(h_cnt, fc + 16, sizeof(h_cnt));
         return PBVI_OK;
     };
     if ((rc = rep_.ensure((size_t)B_ * sizeof(int32_t), &bytes_))) return rc;
