@@ -778,6 +778,8 @@ class EngineT : public EngineBase {
     DevBuf dense_, nzD_, nzAlpha_, prod_, klistD_, kcountD_, nchunksD_;   // dense projection mode
     int64_t rows_pad_s_ = 0, dense_pairs_ = 0;
     std::vector<int> h_kcountD_;
+    int* kc_pin_ = nullptr;                                   // page-locked landing area of the score GEMM's list lengths (statistics)
+    size_t kc_pin_cap_ = 0;
     hipStream_t stream2_ = nullptr;                  // belief-only kernels run beside projection + GEMM
     hipStream_t stream3_ = nullptr;                  // the score GEMM's tile lists / stream-K plan: beside both (a few us of
                                                      // work that the GEMM waits for must not queue behind k_dead's 100 us)
@@ -837,6 +839,7 @@ class EngineT : public EngineBase {
         if (host_stage_) chk(hipHostFree(host_stage_), "hipHostFree(stage)");
         if (ids_pin_) chk(hipHostFree(ids_pin_), "hipHostFree(ids)");
         if (h_flag_) chk(hipHostFree(h_flag_), "hipHostFree(flag)");
+        if (kc_pin_) chk(hipHostFree(kc_pin_), "hipHostFree(kcount)");
         for (hipEvent_t& ev : ev_early_)
             if (ev) chk(hipEventDestroy(ev), "hipEventDestroy(early)");
         if (ev_ids_) chk(hipEventDestroy(ev_ids_), "hipEventDestroy(ids)");
@@ -2706,7 +2709,9 @@ int EngineT<T>::stage_scores(double gamma, bool use_push, const ScoreIO& io, Sco
         const FusedB* fused = nullptr;
         // f64 engines: the 128-row tiles of their MFMA GEMM nest inside these 256-row ones, so the set is a superset;
         // the plain kernel (tiny problems) reads every Gamma element and needs them all written.
-        if (kF32 || f64_uses_mfma(B_, N)) {
+        // (a fused engine projects one or two tiles' worth of rows -- the tiles that straddle groups, the tail: all of their K
+        // tiles are written, and the 12 us of k_need_tiles leave the front of every backup)
+        if ((kF32 || f64_uses_mfma(B_, N)) && !(will_fuse && R_ == 1)) {
             if ((rc = need_.ensure((size_t)AO * k_tiles, &bytes_))) return rc;
             HIPCHK(launch_need_tiles(nzA_.as<uint8_t>(), (int)(B_pad_ / GEMM_BM), nzB_.as<uint8_t>(), AO, (int)V_, k_tiles,
                                      need_.as<uint8_t>(), stream_));
@@ -2997,15 +3002,28 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
             xr_pending = true;
         }
     }
-    std::vector<int> h_kcount;
+    // List lengths of this GEMM, for the statistics (K5 rebuilds the lists for its own GEMM later): into PAGE-LOCKED memory.
+    // (The copy used to land in a std::vector: a device-to-pageable copy is staged by the runtime and holds the host until
+    // the GEMM and the argmax in front of it have finished, so nothing behind the argmax was enqueued before then.)
+    const int* h_kcount = nullptr;
+    size_t n_kcount = 0;
     const int64_t f64_pairs = sc.f64_pairs;
-    if (!windows && st && f64_pairs > 0) {
-        h_kcount.resize((size_t)f64_pairs);
-        HIPCHK(hipMemcpyAsync(h_kcount.data(), scorer.kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    }
-    if (windows && st) {   // list lengths of this GEMM (K5 rebuilds the lists for its own GEMM later)
-        h_kcount.resize((size_t)plan.tiles_m * plan.tiles_n);
-        HIPCHK(hipMemcpyAsync(h_kcount.data(), scorer.kcount_.p, h_kcount.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (st && (windows || f64_pairs > 0)) {
+        n_kcount = windows ? (size_t)plan.tiles_m * plan.tiles_n : (size_t)f64_pairs;
+        if (n_kcount > kc_pin_cap_) {
+            if (kc_pin_) (void)hipHostFree(kc_pin_);         // (no copy into it is pending: every call ends synchronised)
+            kc_pin_ = nullptr;
+            kc_pin_cap_ = 0;
+            const size_t want = std::max<size_t>(n_kcount * 2, 4096);
+            if (hipHostMalloc((void**)&kc_pin_, want * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                kc_pin_ = nullptr;
+                FAIL(PBVI_ENOMEM, "pinned buffer for the list lengths");
+            }
+            kc_pin_cap_ = want;
+        }
+        HIPCHK(hipMemcpyAsync(kc_pin_, scorer.kcount_.p, n_kcount * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        h_kcount = kc_pin_;
     }
     // fp64 re-decision of near-ties.  The per-entry pass hands entries with many tied candidates on to grid-wide
     // passes whose launch needs the host to know how many there are -- a read-back in the middle of the pipeline
@@ -3283,14 +3301,14 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         st->score_flops = 2 * B_ * (int64_t)S_ * AO * V_;
         if (windows) {
             int64_t kt_sum = 0;
-            for (int c : h_kcount) kt_sum += c;
+            for (size_t i = 0; i < n_kcount; ++i) kt_sum += h_kcount[i];
             st->score_flops_executed = kt_sum * 2LL * GEMM_BM * GEMM_BN * GEMM_BK;
             st->score_tiles_dense = (int64_t)plan.tiles_m * plan.tiles_n * plan.k_tiles;
             st->score_tiles_run = kt_sum;
             st->split_k = plan.max_chunks;
         } else if (f64_pairs > 0) {   // fp64 MFMA path: 128 x 128 tiles, lists in 32-column steps
             int64_t kt_sum = 0;
-            for (int c : h_kcount) kt_sum += c;
+            for (size_t i = 0; i < n_kcount; ++i) kt_sum += h_kcount[i];
             st->score_flops_executed = kt_sum * 2LL * 128 * gemm_f64_bn((int)std::min<int64_t>(use_push ? V_ : N, 0x7fffffff)) * 32;
             st->score_tiles_dense = f64_pairs * (S_pad_ / GEMM_BK);
             st->score_tiles_run = kt_sum;
