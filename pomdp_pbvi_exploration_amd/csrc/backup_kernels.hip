@@ -1241,7 +1241,7 @@ __global__ void k_refine_split(int G, const T* __restrict__ bel, int ldb, const 
         const int* L = loverflow ? src : ltile;              // overflow: the belief's own list (zero tiles add exact zeros)
         const int n_tiles = loverflow ? n_src : lbase;
         const int lo = (int)((int64_t)n_tiles * part / REFINE_SPLIT), hi = (int)((int64_t)n_tiles * (part + 1) / REFINE_SPLIT);
-        const TileList tl{L + lo, hi - lo};
+        const TileList tl{L != nullptr ? L + lo : nullptr, hi - lo, lo};       // (no list at all: tiles lo, lo + 1, ...)
         double* mine = work.q2_part + ((int64_t)q * REFINE_SPLIT + part) * REFINE_SPLIT_CAND;
         for (int c0 = 0; c0 < nc_all; c0 += 4) {
             const T* rows[4];
