@@ -3038,7 +3038,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     // keys are matched against the provisional ones (k_match_rows): rows already on the host keep their slot, the few
     // that the refinement changed are appended.  Snapshots, because the refinement rewrites best_v / best_score in place.
     early_used_ = false;
-    if (windows && early_rows_ != nullptr && !use_push && !(flags & PBVI_BELIEF_DOMINANCE) && early_cap_ >= B_ && !no_side) {
+    if (windows && early_rows_ != nullptr && !(flags & PBVI_BELIEF_DOMINANCE) && early_cap_ >= B_ && !no_side) {
         int rc2;
         if ((rc2 = e_bv_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc2;
         if ((rc2 = e_rdot_.ensure((size_t)B_ * A_ * 2 * sizeof(double), &bytes_))) return rc2;
