@@ -422,27 +422,37 @@ __global__ void k_rank_sort(const int32_t* __restrict__ key, int B, int32_t* __r
 }
 
 // dst row y = src row ids[perm[y]] (either map may be null), 16 bytes per lane; ld is a multiple of 32 elements
+__device__ __forceinline__ void tile_or_block(const uint8_t* __restrict__ flags, const int32_t* __restrict__ perm, int B, int k_tiles,
+                                              uint8_t* __restrict__ nz, int bx, int tile);
 template <typename T>
 __global__ void k_gather_rows_v(const T* __restrict__ src, T* __restrict__ dst, int ld, const int32_t* __restrict__ perm,
-                                const int32_t* __restrict__ ids) {
+                                const int32_t* __restrict__ ids, const uint8_t* __restrict__ flags = nullptr, int B = 0,
+                                int k_tiles = 0, uint8_t* __restrict__ nz = nullptr, int or_rows = 0) {
+    // The first or_rows rows of the grid build the block's zero map (k_tile_or's blocks: they need the order only, like the
+    // gather): as a kernel of its own in front of the gather it was 14 us on the path to the score GEMM.
+    if ((int)blockIdx.y < or_rows) {
+        if ((int)blockIdx.x * 64 < k_tiles) tile_or_block(flags, perm, B, k_tiles, nz, blockIdx.x, blockIdx.y);
+        return;
+    }
     constexpr int NS = 16 / (int)sizeof(T);
     typedef T TN __attribute__((ext_vector_type(NS)));
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c * NS >= ld) return;
-    int r = blockIdx.y;
+    const int row = blockIdx.y - or_rows;
+    int r = row;
     if (perm) r = perm[r];
     if (ids) r = ids[r];
-    *(TN*)(dst + (int64_t)blockIdx.y * ld + (int64_t)c * NS) = *(const TN*)(src + (int64_t)r * ld + (int64_t)c * NS);
+    *(TN*)(dst + (int64_t)row * ld + (int64_t)c * NS) = *(const TN*)(src + (int64_t)r * ld + (int64_t)c * NS);
 }
 
 // nz[tile][kt] = OR of flags[perm[r]][kt] over the rows r of the 256-row tile (rows >= B are padding).  Block =
 // 16 row slices x 16 words of 4 K tiles: 16 rows per thread, then an OR over the slices in LDS (one thread per K tile
 // looping over 256 rows was a 76 us chain of dependent byte loads in front of the GEMM's tile lists).
-__global__ void k_tile_or(const uint8_t* __restrict__ flags, const int32_t* __restrict__ perm, int B, int k_tiles,
-                          uint8_t* __restrict__ nz) {
+__device__ __forceinline__ void tile_or_block(const uint8_t* __restrict__ flags, const int32_t* __restrict__ perm, int B, int k_tiles,
+                                              uint8_t* __restrict__ nz, int bx, int tile) {
     __shared__ uint32_t part[16][17];
-    const int cw = threadIdx.x & 15, rs = threadIdx.x >> 4, tile = blockIdx.y;
-    const int kt0 = (blockIdx.x * 16 + cw) * 4;                  // this thread's 4 K tiles
+    const int cw = threadIdx.x & 15, rs = threadIdx.x >> 4;
+    const int kt0 = (bx * 16 + cw) * 4;                          // this thread's 4 K tiles
     const int r1 = (tile + 1) * 256 < B ? (tile + 1) * 256 : B;
     uint32_t f = 0;
     if (kt0 < k_tiles) {
@@ -463,6 +473,10 @@ __global__ void k_tile_or(const uint8_t* __restrict__ flags, const int32_t* __re
         for (int x = 1; x < 16; ++x) f |= part[x][cw];
         for (int e = 0; e < 4 && kt0 + e < k_tiles; ++e) nz[(int64_t)tile * k_tiles + kt0 + e] = ((f >> (8 * e)) & 0xffu) ? 1 : 0;
     }
+}
+__global__ void k_tile_or(const uint8_t* __restrict__ flags, const int32_t* __restrict__ perm, int B, int k_tiles,
+                          uint8_t* __restrict__ nz) {
+    tile_or_block(flags, perm, B, k_tiles, nz, blockIdx.x, blockIdx.y);
 }
 
 template <typename T>
@@ -1175,16 +1189,14 @@ class EngineT : public EngineBase {
             HIPCHK(hipGetLastError());
             perm = perm_.as<int32_t>();
         }
-        // the zero map first: the score GEMM's tile lists (another stream) need nothing else of the block
-        hipLaunchKernelGGL(k_tile_or, dim3((k_tiles + 63) / 64, (unsigned)(Bp / GEMM_BM)), dim3(256), 0, stream_,
-                           rowflags_.as<uint8_t>(), perm, (int)B, k_tiles, nzA_.as<uint8_t>());
+        // the zero map (the first rows of the grid) and the rows in that order, one launch
+        constexpr int NS = 16 / (int)sizeof(T);
+        const int or_rows = (int)(Bp / GEMM_BM);
+        hipLaunchKernelGGL(k_gather_rows_v<T>, dim3((S_pad_ / NS + 255) / 256, (unsigned)(B + or_rows)), dim3(256), 0, stream_, src,
+                           bel_.as<T>(), S_pad_, perm, src_ids, rowflags_.as<uint8_t>(), (int)B, k_tiles, nzA_.as<uint8_t>(), or_rows);
         HIPCHK(hipGetLastError());
         if (!ev_nzA_) HIPCHK(hipEventCreateWithFlags(&ev_nzA_, hipEventDisableTiming));
         HIPCHK(hipEventRecord(ev_nzA_, stream_));
-        constexpr int NS = 16 / (int)sizeof(T);
-        hipLaunchKernelGGL(k_gather_rows_v<T>, dim3((S_pad_ / NS + 255) / 256, (unsigned)B), dim3(256), 0, stream_, src, bel_.as<T>(),
-                           S_pad_, perm, src_ids);
-        HIPCHK(hipGetLastError());
         B_ = B;
         B_pad_ = Bp;
         ++bel_ver_;
