@@ -2975,6 +2975,12 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         HIPCHK(launch_rdot<T>(bel_.as<T>(), S_pad_, (int)B_, mv, windows ? btl_.as<int32_t>() : nullptr,
                               windows ? btc_.as<int32_t>() : nullptr, prd_.as<double>(), side));
     }
+    // (run_fetch's provisional pipeline: its counters are cleared here, beside the projection, not in front of its kernels)
+    const bool early_wanted = windows && early_rows_ != nullptr && !(flags & PBVI_BELIEF_DOMINANCE) && early_cap_ >= B_ && !no_side;
+    if (early_wanted) {
+        if ((rc = e_cnt_.ensure(4 * sizeof(int), &bytes_))) return rc;
+        HIPCHK(hipMemsetAsync(e_cnt_.p, 0, 4 * sizeof(int), side));
+    }
     HIPCHK(hipEventRecord(ev_join_, side));
 
     ScoreIO io;
@@ -3034,8 +3040,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
             }
             kc_pin_cap_ = want;
         }
-        HIPCHK(hipMemcpyAsync(kc_pin_, scorer.kcount_.p, n_kcount * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        h_kcount = kc_pin_;
+        h_kcount = kc_pin_;                                  // (the copy itself is enqueued behind the refinement, below)
     }
     // fp64 re-decision of near-ties.  The per-entry pass hands entries with many tied candidates on to grid-wide
     // passes whose launch needs the host to know how many there are -- a read-back in the middle of the pipeline
@@ -3050,7 +3055,7 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
     // keys are matched against the provisional ones (k_match_rows): rows already on the host keep their slot, the few
     // that the refinement changed are appended.  Snapshots, because the refinement rewrites best_v / best_score in place.
     early_used_ = false;
-    if (windows && early_rows_ != nullptr && !(flags & PBVI_BELIEF_DOMINANCE) && early_cap_ >= B_ && !no_side) {
+    if (early_wanted) {
         int rc2;
         if ((rc2 = e_bv_.ensure((size_t)pairs * sizeof(int32_t), &bytes_))) return rc2;
         if ((rc2 = e_rdot_.ensure((size_t)B_ * A_ * 2 * sizeof(double), &bytes_))) return rc2;
@@ -3070,7 +3075,6 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         // refinement (which rewrites best_v / best_score in place), and only the copy -- 8 MB over PCIe, ~150 us, few blocks
         // -- goes to the side stream.  (Snapshots of the three arrays + the whole provisional pipeline beside the
         // refinement cost it 0.13 ms: a net loss.)
-        HIPCHK(hipMemsetAsync(e_cnt_.p, 0, 4 * sizeof(int), stream_));
         HIPCHK(launch_action<TS>((int)B_, scorer.view(), sv, sc.rd_col0, sc.tol_rel, sc.chain, best_score_.as<double>(), err_.as<double>(),
                                  e_rdot_.as<double>(), e_rdot_.as<double>() + (size_t)B_ * A_, e_act_.as<int32_t>(), nullptr, nullptr, stream_,
                                  io.tol_extra));
@@ -3145,6 +3149,8 @@ int EngineT<T>::run_pipeline(EngineT<TS>& scorer, double gamma, int flags, pbvi_
         HIPCHK(hipEventRecord(ev_early_[1], stream2_));
         early_dma_pending_ = false;
     }
+    if (h_kcount != nullptr)   // statistics: not in front of the provisional decision and the refinement (K5 re-uses kcount_ later)
+        HIPCHK(hipMemcpyAsync(kc_pin_, scorer.kcount_.p, n_kcount * sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipEventRecord(ev_[4], stream_));
     const int32_t* perm = sorted_ ? perm_.as<int32_t>() : nullptr;
     int* ucount = counters_.as<int>() + 3;
