@@ -1890,3 +1890,66 @@ def test_duplicate_rows_through_the_level1_screen_and_the_split_rescoring(q2_cap
     np.testing.assert_allclose(res.alpha, want_rows, rtol=1e-6, atol=1e-7)
     assert res.stats['n_refined'] > 0
     eng.close()
+
+
+def _random_case(seed):
+    """A random model and shapes: successors random / grid-like / mixed, sparse RTO, localized or scattered belief supports,
+    an alpha set with exact and near duplicates."""
+    rng = np.random.default_rng(seed)
+    S = int(rng.integers(33, 900)); A = int(rng.integers(1, 6)); O = int(rng.integers(1, 6)); R = int(rng.integers(1, 7))
+    V = int(rng.integers(2, 400)); B = int(rng.integers(1, 400))
+    if rng.random() < 0.3:
+        B = int(rng.integers(257, 700))                         # more than one row block: the sorted path
+    style = rng.integers(0, 3)
+    if style == 0:
+        rs = rng.integers(0, S, (S, A, R))
+    else:
+        off = rng.integers(-40, 41, (1, A, R)) if style == 1 else rng.integers(-5, 6, (1, A, R))
+        rs = np.clip(np.arange(S)[:, None, None] + off, 0, S - 1)      # consecutive successors: the 16-byte gathers
+        if style == 2:
+            rs = np.where(rng.random((S, A, R)) < 0.1, rng.integers(0, S, (S, A, R)), rs)
+    rto = rng.random((S, A, O, R)) * (rng.random((S, A, O, R)) < rng.uniform(0.2, 1.0))
+    rto /= np.maximum(rto.sum(axis=(2, 3), keepdims=True), 1e-9)
+    er = rng.normal(size=(S, A))
+    b = rng.random((B, S)) * (rng.random((B, S)) < rng.uniform(0.02, 1.0))
+    if rng.random() < 0.5:
+        w = max(1, int(S * rng.uniform(0.05, 0.5)))
+        for i in range(B):
+            s0 = int(rng.integers(0, S - w + 1))
+            b[i, :s0] = 0
+            b[i, s0 + w:] = 0
+    b[np.arange(B), rng.integers(0, S, B)] += 1e-3
+    b /= b.sum(axis=1, keepdims=True)
+    alpha = rng.normal(size=(V, S))
+    if rng.random() < 0.4 and V > 4:
+        k = int(rng.integers(1, max(2, V // 2)))
+        src, dst = rng.integers(0, V, k), rng.integers(0, V, k)
+        alpha[dst] = alpha[src]
+        if rng.random() < 0.5:
+            alpha[dst[: k // 2]] += rng.normal(size=(len(dst[: k // 2]), S)) * 1e-7
+    return S, A, O, R, rs.astype(np.int64), rto, er, alpha, b, float(rng.uniform(0.5, 0.99))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+def test_random_models_against_the_oracle(dtype):
+    """60 random models / shapes per engine type (1750 more were run once by hand in five engine modes): indices, actions and
+    rows against the oracle.  Between EXACT duplicates of an alpha row the engine returns the first (the tied scores are
+    equal in exact arithmetic); NumPy's BLAS may round the later column's dot product one ulp higher and pick that one --
+    the reference never holds duplicates (``ValueFunction`` drops them), so such entries are compared by row content."""
+    for seed in range(60):
+        S, A, O, R, rs, rto, er, alpha, b, gamma = _random_case(seed)
+        if dtype == 'f32':
+            alpha, b = alpha.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
+            rto, er = rto.astype(np.float32).astype(np.float64), er.astype(np.float32).astype(np.float64)
+        want_rows, want_a, want_v = orc.backup_core(alpha, b, rs, rto, er, gamma)
+        eng = Engine(S, A, O, R, rs, rto, er, dtype=dtype)
+        cast = (lambda x: x) if dtype == 'f64' else (lambda x: x.astype(np.float32))
+        res = eng.backup_full(cast(alpha), cast(b), gamma)
+        eng.close()
+        diff = np.argwhere(res.best_alpha_ind != want_v)
+        for bi, a, o in diff:
+            v1, v2 = res.best_alpha_ind[bi, a, o], want_v[bi, a, o]
+            assert v1 < v2 and np.array_equal(alpha[v1], alpha[v2]), (seed, bi, a, o, v1, v2)
+        assert np.array_equal(res.actions, want_a), seed
+        tol = 1e-6 if dtype == 'f32' else 1e-12
+        np.testing.assert_allclose(res.alpha, want_rows, rtol=tol, atol=tol * (np.abs(want_rows).max() + 1e-30), err_msg=str(seed))
