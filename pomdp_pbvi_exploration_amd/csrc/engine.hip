@@ -353,7 +353,7 @@ __global__ void k_project_mag(const T* __restrict__ amax, ModelView<T> mv, T gam
 //   k_rank_sort  rows ordered by key (stable): the 256-row blocks of the score GEMM get tighter joint supports and more
 //                zero tiles to skip (33.8 % -> 29.1 % of the tile steps at |S| = 30000)
 //   k_gather_rows_v  the block in that order, 16 bytes per lane, straight from the store rows (no staging copy)
-//   k_tile_or    the GEMM's zero map of the block from the row flags
+//   tile_or_block  the GEMM's zero map of the block from the row flags (the first rows of k_gather_rows_v's grid)
 // The per-belief tile lists and the dead-triple test (backup_kernels.hip) read the same flags.
 template <typename T>
 __global__ void k_row_flags(const T* __restrict__ src, int ld, const int32_t* __restrict__ ids, int S_pad, int k_tiles,
@@ -428,7 +428,7 @@ template <typename T>
 __global__ void k_gather_rows_v(const T* __restrict__ src, T* __restrict__ dst, int ld, const int32_t* __restrict__ perm,
                                 const int32_t* __restrict__ ids, const uint8_t* __restrict__ flags = nullptr, int B = 0,
                                 int k_tiles = 0, uint8_t* __restrict__ nz = nullptr, int or_rows = 0) {
-    // The first or_rows rows of the grid build the block's zero map (k_tile_or's blocks: they need the order only, like the
+    // The first or_rows rows of the grid build the block's zero map (they need the order only, like the
     // gather): as a kernel of its own in front of the gather it was 14 us on the path to the score GEMM.
     if ((int)blockIdx.y < or_rows) {
         if ((int)blockIdx.x * 64 < k_tiles) tile_or_block(flags, perm, B, k_tiles, nz, blockIdx.x, blockIdx.y);
@@ -473,10 +473,6 @@ __device__ __forceinline__ void tile_or_block(const uint8_t* __restrict__ flags,
         for (int x = 1; x < 16; ++x) f |= part[x][cw];
         for (int e = 0; e < 4 && kt0 + e < k_tiles; ++e) nz[(int64_t)tile * k_tiles + kt0 + e] = ((f >> (8 * e)) & 0xffu) ? 1 : 0;
     }
-}
-__global__ void k_tile_or(const uint8_t* __restrict__ flags, const int32_t* __restrict__ perm, int B, int k_tiles,
-                          uint8_t* __restrict__ nz) {
-    tile_or_block(flags, perm, B, k_tiles, nz, blockIdx.x, blockIdx.y);
 }
 
 template <typename T>
